@@ -1,0 +1,199 @@
+/*
+ * direct_ddp.h -- C-ABI of the MI355X-native batched IPDDP trajectory optimiser.
+ *
+ * This is the drop-in boundary for ONE path of ntu-caokun/DIRECT: the call
+ *
+ *   int ddpTrajOptimizer::polyCurveGeneration(const FlightCorridor&, ... 21 more args)
+ *       global_planner/include/global_planner/ddp_optimizer.h:267-289
+ *       global_planner/src/ddp_optimizer.cpp:5-438
+ *
+ * and the getters that read its result (ddp_optimizer.h:299-340).  The
+ * reference solves one corridor per call on the ROS spin thread; this library
+ * solves a batch of independent corridors per call, one 64-lane wavefront per
+ * trajectory, on a gfx950 device.  Plain pointers and sizes only: no C++,
+ * Eigen, ROS or torch types cross this boundary.
+ *
+ * Data layout ("batch-major": a trajectory's knot records are contiguous):
+ *   Real = float (DIRECT_F32) or double (DIRECT_F64), chosen at create time.
+ *   x0[b][9], xd[b][9]          start / goal state [pos xyz, vel xyz, acc xyz]
+ *                               (ddp_optimizer.cpp:104-121: rows 0 / 1 of pos,vel,acc)
+ *   T0[b][k]                    corridor.durations   (data_type.h:192)
+ *   n_planes[b][k]              Polytope.planes.size() (data_type.h:130)
+ *   planes[b][k][p][4]          (a,b,c,d), outward normal, inside <=> ax+by+cz+d <= 0
+ *                               (poly_utils.cpp:42-52); entries p >= n_planes are ignored
+ *   seeds[b][k][3]              Polytope.seed_coord (line-init only, may be NULL)
+ *   init_bez[b][k][18]          initbezCoeff row [x0..x5,y0..y5,z0..z5], time-scaled
+ *                               (ddp_optimizer.cpp:167); ignored when zero_init
+ *   k runs over 0..n_seg[b]-1; strides use n_seg_max and p_max.
+ */
+#ifndef DIRECT_DDP_H_
+#define DIRECT_DDP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIRECT_DDP_ABI_VERSION 1
+
+#define DIRECT_NX 9   /* dim*sys_order, ddp_optimizer.cpp:37-39 */
+#define DIRECT_NU 10  /* dim*sys_order+1 (c3,c4,c5 per axis + T), ddp_optimizer.cpp:126 */
+#define DIRECT_P_LIMIT 32 /* largest planes-per-polytope the kernels are built for */
+
+typedef enum {
+  DIRECT_OK = 0,
+  DIRECT_ERR_INVALID = 1,     /* bad argument (NULL, size, time_power not in {1,2}, ...) */
+  DIRECT_ERR_UNSUPPORTED = 2, /* e.g. p_max > DIRECT_P_LIMIT */
+  DIRECT_ERR_DEVICE = 3,      /* HIP allocation / launch / copy failure */
+  DIRECT_ERR_NO_DEVICE = 4    /* no gfx950 device visible: there is no CPU fallback */
+} direct_status_t;
+
+typedef enum { DIRECT_F32 = 0, DIRECT_F64 = 1 } direct_dtype_t;
+typedef enum { DIRECT_MEM_HOST = 0, DIRECT_MEM_DEVICE = 1 } direct_mem_t;
+
+/* Return codes of one solve, exactly the reference's (ddp_optimizer.cpp:33, 322, 360, 375, 393). */
+#define DIRECT_RTN_DONE 0        /* ran to iter_max, or optimality, or line-init exit */
+#define DIRECT_RTN_FEAS_OPT 1    /* phase 1: feasible + cost stagnation */
+#define DIRECT_RTN_FEAS_FOUND 2  /* phase 0: all c < 2e-4 */
+#define DIRECT_RTN_NEG_TIME (-3)
+#define DIRECT_RTN_BP_STUCK (-4)
+
+/* By-value scalar arguments of polyCurveGeneration (ddp_optimizer.h:275-289). */
+typedef struct {
+  double max_vel;     /* max_vel */
+  double max_acc;     /* max_acc */
+  double w_snap;      /* w_snap (weights the integral of jerk^2, ddp_optimizer.cpp:991-999) */
+  double w_terminal;  /* w_terminal */
+  double w_time;      /* w_time */
+  int32_t iter_max;   /* iter_max */
+  int32_t time_power; /* 1 or 2; anything else is UB in the reference -> DIRECT_ERR_INVALID */
+  int32_t zero_init;  /* zero_init_flag */
+  int32_t line_init;  /* line_init_flag */
+  int32_t minvo;      /* minvo_flag */
+  int32_t infeas;     /* initial value of `bool& infeas` for every problem (see infeas_in) */
+  /* Extensions with no reference counterpart (0 = reference behaviour): */
+  int32_t fixed_iters; /* benchmark: disable the optimality / feasibility early exits */
+  int32_t exact_dt;    /* use the exact Bezier dc/dT column instead of quirk Q1 */
+} direct_ddp_params_t;
+
+typedef struct {
+  int32_t batch;
+  int32_t n_seg_max;
+  int32_t p_max;
+  int32_t mem;               /* direct_mem_t: where every pointer below lives */
+  const int32_t* n_seg;      /* [batch] */
+  const void* x0;            /* [batch][9] Real */
+  const void* xd;            /* [batch][9] Real */
+  const void* T0;            /* [batch][n_seg_max] Real */
+  const int32_t* n_planes;   /* [batch][n_seg_max] */
+  const void* planes;        /* [batch][n_seg_max][p_max][4] Real */
+  const void* seeds;         /* [batch][n_seg_max][3] Real or NULL */
+  const void* init_bez;      /* [batch][n_seg_max][18] Real or NULL */
+  const uint8_t* infeas_in;  /* [batch] or NULL (then params.infeas) */
+} direct_ddp_batch_in_t;
+
+/* What the getters of ddp_optimizer.h:299-340 return, per problem.  Any pointer may be NULL. */
+typedef struct {
+  int32_t mem;               /* direct_mem_t */
+  int32_t* rtn;              /* [batch] return value of polyCurveGeneration */
+  int32_t* iter_used;        /* [batch] getIterUsed(): loop index at exit (quirk Q11) */
+  int32_t* fwd_passes;       /* [batch] forward passes executed = DDP iterations (the metric) */
+  uint8_t* infeas_out;       /* [batch] `bool& infeas` after the call */
+  uint8_t* line_failed_out;  /* [batch] `bool& line_failed` after the call */
+  void* cost;                /* [batch] getDDPObjective() */
+  void* costq;               /* [batch] running cost without the terminal term */
+  void* jerk_cost;           /* [batch] getJerkCost() */
+  void* terminal_norm2;      /* [batch] getTerminalNorm() */
+  void* opterr;              /* [batch] bp.opterr at exit */
+  void* mu;                  /* [batch] alg.mu at exit */
+  void* bez;                 /* [batch][n_seg_max][18] getBezCoeff() layout */
+  void* poly;                /* [batch][n_seg_max][18] getPolyCoeff(): [c0xyz..c5xyz] */
+  void* T;                   /* [batch][n_seg_max] getPolyTime() */
+} direct_ddp_batch_out_t;
+
+typedef struct {
+  int32_t dtype;         /* direct_dtype_t */
+  int32_t device;        /* HIP device ordinal */
+  int32_t max_batch;
+  int32_t n_seg_max;
+  int32_t p_max;
+  int32_t reserved;
+} direct_ddp_config_t;
+
+typedef struct direct_ddp_handle_s* direct_ddp_handle_t;
+
+int32_t direct_ddp_abi_version(void);
+const char* direct_ddp_last_error(void);
+
+direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_handle_t* out);
+direct_status_t direct_ddp_destroy(direct_ddp_handle_t h);
+
+/* HIP stream (hipStream_t cast to void*) the kernels are launched on; NULL = default stream. */
+direct_status_t direct_ddp_set_stream(direct_ddp_handle_t h, void* hip_stream);
+
+/* One polyCurveGeneration per problem (replaces ddp_optimizer.cpp:5-438).  Blocks until
+ * the results are in `out` when out->mem is host; with device memory the call returns
+ * after enqueueing on the handle's stream. */
+direct_status_t direct_ddp_solve_batch(direct_ddp_handle_t h, const direct_ddp_params_t* params,
+                                       const direct_ddp_batch_in_t* in, direct_ddp_batch_out_t* out);
+
+/* fastTrajPlanning's protocol (teach_repeat_planner.cpp:886-921) for a batch: phase 0
+ * (params0: zero init, infeasible start), UpdateTime where rtn0 == 2, phase 1 (params1) from
+ * the phase-0 Bezier coefficients.  out0 may be NULL. */
+direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_params_t* params0,
+                                      const direct_ddp_params_t* params1,
+                                      const direct_ddp_batch_in_t* in, direct_ddp_batch_out_t* out0,
+                                      direct_ddp_batch_out_t* out1);
+
+/* initTimeAllocation (teach_repeat_planner.cpp:583-639): trapezoid-profile duration per
+ * segment from start, seeds[1..n-1] and goal.  Host pointers, double precision. */
+direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const int32_t* n_seg,
+                                       const double* start, const double* goal,
+                                       const double* seeds, double max_vel, double max_acc,
+                                       double* T_out);
+
+/* ---- stepwise interface (per-pass parity tests and profiling) ------------------------ */
+/* begin: setup + initialroll + mu/filter/reg reset (ddp_optimizer.cpp:42-286). */
+direct_status_t direct_ddp_begin(direct_ddp_handle_t h, const direct_ddp_params_t* params,
+                                 const direct_ddp_batch_in_t* in);
+/* one backwardpass() (ddp_optimizer.cpp:440-644), no retry loop */
+direct_status_t direct_ddp_backward_pass(direct_ddp_handle_t h);
+/* one forwardpass() (ddp_optimizer.cpp:647-778) */
+direct_status_t direct_ddp_forward_pass(direct_ddp_handle_t h);
+/* n trips of the outer loop (ddp_optimizer.cpp:295-412) for every unfinished problem */
+direct_status_t direct_ddp_iterate(direct_ddp_handle_t h, int32_t n_iters);
+/* finalroll + conversions (ddp_optimizer.cpp:414-437) */
+direct_status_t direct_ddp_finish(direct_ddp_handle_t h, direct_ddp_batch_out_t* out);
+
+typedef enum {
+  DIRECT_FIELD_X = 0,      /* [b][n_seg_max+1][9] */
+  DIRECT_FIELD_U = 1,      /* [b][n_seg_max][10] */
+  DIRECT_FIELD_S = 2,      /* [b][n_seg_max][nc_max] */
+  DIRECT_FIELD_Y = 3,      /* [b][n_seg_max][nc_max] */
+  DIRECT_FIELD_C = 4,      /* [b][n_seg_max][nc_max] (recomputed from x,u on read) */
+  DIRECT_FIELD_KU = 5,     /* [b][n_seg_max][10] */
+  DIRECT_FIELD_KUU = 6,    /* [b][n_seg_max][10][9] */
+  DIRECT_FIELD_KS = 7,     /* [b][n_seg_max][nc_max] */
+  DIRECT_FIELD_KY = 8,     /* [b][n_seg_max][nc_max] */
+  DIRECT_FIELD_SCALARS = 9 /* [b][16]: cost,costq,logcost,err,mu,reg,opterr,stepsize,
+                              step,fp_failed,bp_failed,rtn,iter,done,filter_n,infeas */
+} direct_field_t;
+/* nc_max = 6*p_max + 55.  dst/src are HOST buffers of Real. */
+direct_status_t direct_ddp_get_field(direct_ddp_handle_t h, int32_t field, void* dst);
+direct_status_t direct_ddp_set_field(direct_ddp_handle_t h, int32_t field, const void* src);
+
+/* Device time of the last solve/iterate kernel(s), measured with HIP events on the handle's
+ * stream (milliseconds); *n_launches receives how many kernel launches that covered. */
+direct_status_t direct_ddp_last_kernel_ms(direct_ddp_handle_t h, double* ms, int32_t* n_launches);
+
+/* Config-5 reduction: index and value of the smallest cost among problems with rtn >= 0.
+ * cost/rtn are device or host arrays per `mem`; the result is written to host. */
+direct_status_t direct_ddp_best_cost(direct_ddp_handle_t h, int32_t mem, const void* cost,
+                                     const int32_t* rtn, int32_t batch, int32_t* best_index,
+                                     double* best_cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIRECT_DDP_H_ */
