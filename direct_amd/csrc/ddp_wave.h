@@ -1,0 +1,1275 @@
+// Wave-level IPDDP: one 64-lane wavefront owns one trajectory.
+//
+// Restructured (not translated) from ntu-caokun/DIRECT global_planner/src/ddp_optimizer.cpp ("DDP"):
+//   backward sweep   DDP:440-644   -> bwd_sweep()
+//   forward pass     DDP:647-778   -> fwd_pass()
+//   outer loop       DDP:295-412   -> iterate()
+//   setup/first roll DDP:42-286    -> begin()
+//   final conversion DDP:414-437   -> finish()
+// The reference materialises cx (nc x 9) and cu (nc x 10) and multiplies them densely.  Here every
+// constraint row is kept in its Kronecker form  [We[cr][:] (x) n | n . dval[cr]]  (SURVEY.md A.6), so
+// cu' D cu etc. collapse to 3x3 accumulators per control point, rows are spread over the 64 lanes,
+// and the 10x10 LLT + 10 right-hand sides run column-per-lane with v_readlane broadcasts.
+//
+// SIMT abstraction: code between LANES{...} is per-lane; everything outside is wave-uniform.
+// On gfx950 LANES binds `lane = threadIdx.x`; under DIRECT_EMULATE (tests only, never in the
+// product library) it is a 64-iteration loop so the very same source can be debugged on a CPU.
+#pragma once
+#include <stdint.h>
+
+#include "ddp_tables.h"
+
+#if defined(DIRECT_EMULATE)
+#include <cmath>
+namespace direct {
+using std::fabs; using std::fmax; using std::fmin; using std::log; using std::pow; using std::sqrt;
+}
+#define DDP_DEV inline
+#define LANES for (int lane = 0; lane < 64; ++lane)
+#define PLV(T, name) T name[64]
+#define PLA(T, name, n) T name[64][n]
+#define LV(name) name[lane]
+#define WSYNC() ((void)0)
+#define RDLANE(arr, idx, src) (arr[src][idx])
+#define DDP_UNIFORM_I(x) (x)
+#else
+#include <hip/hip_runtime.h>
+#define DDP_DEV __device__ __forceinline__
+#define LANES for (int lane = (int)threadIdx.x, lanes_once_ = 1; lanes_once_; lanes_once_ = 0)
+#define PLV(T, name) T name
+#define PLA(T, name, n) T name[n]
+#define LV(name) name
+#define WSYNC() __syncthreads()
+#define RDLANE(arr, idx, src) direct::readlane_real(arr[idx], src)
+#define DDP_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
+namespace direct {
+
+constexpr int kPLim = 32;  // DIRECT_P_LIMIT
+
+#if !defined(DIRECT_EMULATE)
+__device__ __forceinline__ float readlane_real(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double readlane_real(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_any(int v) { return __any(v) ? 1 : 0; }
+#define WAVE_SUM_D(name) direct::wave_sum_d((double)(name))
+#define WAVE_MAX_D(name) direct::wave_max_d((double)(name))
+#define WAVE_SUM_I(name) direct::wave_sum_i(name)
+#define WAVE_ANY(name) direct::wave_any(name)
+#else
+template <typename T>
+inline double emu_sum_d(const T* v) {
+  double vals[64];
+  for (int i = 0; i < 64; i++) vals[i] = (double)v[i];
+  for (int o = 32; o > 0; o >>= 1)  // same butterfly order as the device
+    for (int i = 0; i < o; i++) vals[i] += vals[i + o];
+  return vals[0];
+}
+template <typename T>
+inline double emu_max_d(const T* v) {
+  double m = (double)v[0];
+  for (int i = 1; i < 64; i++) m = std::fmax(m, (double)v[i]);
+  return m;
+}
+inline int emu_sum_i(const int* v) {
+  int s = 0;
+  for (int i = 0; i < 64; i++) s += v[i];
+  return s;
+}
+inline int emu_any(const int* v) {
+  for (int i = 0; i < 64; i++)
+    if (v[i]) return 1;
+  return 0;
+}
+#define WAVE_SUM_D(name) direct::emu_sum_d(name)
+#define WAVE_MAX_D(name) direct::emu_max_d(name)
+#define WAVE_SUM_I(name) direct::emu_sum_i(name)
+#define WAVE_ANY(name) direct::emu_any(name)
+#endif
+
+// ---- per-solve constants (by-value arguments of polyCurveGeneration, DDPH:275-289) ------------
+struct SolveConst {
+  double max_vel, max_acc, w_snap, w_term, w_time, reg_base, shift, tol;
+  int iter_max, time_power, zero_init, line_init, minvo, fixed_iters, exact_dt, pad;
+};
+
+// ---- per-trajectory solver state (algParam + the scalar members of fwdPass / bwdPass) ---------
+struct TrajState {
+  double cost, costq, logcost, err, mu, opterr, stepsize, prev_cost;
+  double sumlog, errsum;  // sum log(-c) or sum log(y); sum |c+y| of the CURRENT iterate
+  int reg, step, fp_failed, bp_failed;
+  int rtn, iter, done, nfilter;
+  int infeas, infeas_ref, line_failed, bp_no_upd;
+  int no_upd, fwd_passes, cur, viol;
+  int neg_time, nseg, nc0, pad;
+};
+
+// ---- device-resident batch (all pointers are device memory) -----------------------------------
+template <typename Real>
+struct Batch {
+  int B, nmax, pmax, ncs;  // ncs = row stride of S/Y/KS/KY (>= 6*pmax+55)
+  int fcap, pad0, pad1, pad2;
+  const int32_t* n_seg;
+  const Real* x0;
+  const Real* xd;
+  const Real* T0;
+  const int32_t* n_planes;
+  const Real* planes;
+  const Real* init_bez;
+  const uint8_t* infeas_in;
+  Real* X[2];   // [B][nmax+1][20]: x_k (9), u_k (10), pad
+  Real* S[2];   // [B][nmax][ncs]
+  Real* Y[2];   // [B][nmax][ncs]
+  Real* KU;     // [B][nmax][100]: ku (10), Ku (10x9 row-major)
+  Real* KS;     // [B][nmax][ncs]
+  Real* KY;     // [B][nmax][ncs]
+  double* filt; // [B][fcap][2]
+  TrajState* st;
+  SolveConst k;
+};
+
+constexpr int kXS = 20;  // knot record stride of X
+
+// ---- LDS (one per wave) ------------------------------------------------------------------------
+template <typename Real, int RPL>
+struct WaveLds {
+  Real WbE[90], WdE[90];  // base tables with Ek_inv folded in (fixed for the launch)
+  int pq[192];            // upper-triangle (p,q) of the 19x19 system, p | q << 8
+  Real z[kXS], zn[kXS], dz[kXS], xn[12], xnx[12];
+  Real pl[4 * kPLim];
+  Real We[90];
+  Real val[48], dval[48], valn[48], G[48];
+  Real drow[64 * RPL], grow[64 * RPL];
+  Real Sp[36], hp[18], dl[27], gm[27], Sd[48], last[4];
+  Real H[18], Hp[18], fT[12];
+  Real Ru[9], Rpu[9], Rppu[9], qs[4];
+  Real V[81], Vx[12];
+  Real VZ[176];
+  Real Hzz[361], Hz[20];
+  Real KU[100];
+  Real W1[81], W2[90], t10[10], hk[10];
+};
+
+template <typename Real>
+DDP_DEV Real powi(Real T, int e) {  // T^e for 0 <= e <= 7 without a register-array index
+  Real r = (Real)1;
+#pragma unroll
+  for (int q = 0; q < 7; q++) r = (q < e) ? r * T : r;
+  return r;
+}
+
+DDP_DEV int ctrl_off(int cr) { return cr < 6 ? 0 : (cr < 11 ? 1 : 2); }
+
+// H = [F | G] (DDP:862-871) and Hp = [F' | G'] (DDP:930-935), entry (c, i), i = 0..5
+template <typename Real>
+DDP_DEV void dyn_entry(Real T, int c, int i, Real& h, Real& hp) {
+  if (i < 3) {
+    int e = i - c;
+    h = (e < 0) ? (Real)0 : (e == 0 ? (Real)1 : (e == 1 ? T : (Real)0.5 * T * T));
+    hp = (e <= 0) ? (Real)0 : (e == 1 ? (Real)1 : T);
+  } else {
+    int a = i - 3;
+    const Real g0 = (c == 0) ? (Real)1 : (c == 1 ? (Real)(3 + a) : (Real)((3 + a) * (2 + a)));
+    int e = 3 + a - c;
+    h = g0 * powi(T, e);
+    hp = g0 * (Real)e * powi(T, e - 1);
+  }
+}
+
+// jerk Gram matrix coefficients: R[a][a'] = Rc * T^(a+a'+1)  (DDP:991-999)
+DDP_DEV double gram_c(int a, int b) {
+  const double rc[3][3] = {{36, 72, 120}, {72, 192, 360}, {120, 360, 720}};
+  return rc[a][b];
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename Real, int RPL>
+struct Wave {
+  typedef WaveLds<Real, RPL> Lds;
+  const Batch<Real>& B;
+  Lds& L;
+  const int b;  // trajectory
+  int N;        // segments
+  TrajState st;
+
+  DDP_DEV Wave(const Batch<Real>& batch, Lds& lds, int traj) : B(batch), L(lds), b(traj) {}
+
+  DDP_DEV Real* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * kXS; }
+  DDP_DEV Real* Sp_(Real* base, int k) const { return base + ((size_t)b * B.nmax + k) * B.ncs; }
+  DDP_DEV const Real* planes_(int k) const { return B.planes + ((size_t)b * B.nmax + k) * B.pmax * 4; }
+  DDP_DEV int np_(int k) const { return B.n_planes[(size_t)b * B.nmax + k]; }
+  DDP_DEV Real* KUp(int k) const { return B.KU + ((size_t)b * B.nmax + k) * 100; }
+
+  // one-time LDS tables
+  DDP_DEV void init_tables() {
+    const int mv = B.k.minvo ? 1 : 0;
+    LANES {
+      for (int e = lane; e < 90; e += 64) {
+        int cr = e / 6, i = e % 6;
+        double eps = (i == 2) ? 0.5 : 1.0;  // Ek_inv = {1,1,1/2} (DDP:101-103), 1 for the u part
+        double v = kValueTab[mv][cr][i];
+        double d = kDtTab[cr][i];
+        if (B.k.exact_dt) d = (double)(i - ctrl_off(cr)) * v;  // non-parity: exact d/dT
+        L.WbE[e] = (Real)(v * eps);
+        L.WdE[e] = (Real)(d * eps);
+      }
+      for (int e = lane; e < 192; e += 64) {
+        // e -> (p,q), p <= q < 19, row-major over the upper triangle
+        int p = 0, rem = e;
+        while (p < 19 && rem >= 19 - p) {
+          rem -= 19 - p;
+          p++;
+        }
+        L.pq[e] = (e < 190) ? (p | ((p + rem) << 8)) : 0;
+      }
+    }
+    WSYNC();
+  }
+
+  // ---- shared pieces ---------------------------------------------------------------------------
+  // constraint value of row r from control values `val` (DDP:1181-1188, 1236-1238, 1274-1279)
+  DDP_DEV Real row_c(const Real* val, int r, int P, Real T) const {
+    const Real sh = (Real)B.k.shift;
+    int rr = r - 6 * P;
+    if (rr < 0) {
+      int j = r / P, q = r - j * P;
+      const Real* n = &L.pl[4 * q];
+      return n[0] * val[3 * j] + n[1] * val[3 * j + 1] + n[2] * val[3 * j + 2] + n[3] - sh;
+    } else if (rr < 30) {
+      int q = rr < 15 ? rr : rr - 15;
+      Real v = val[18 + q];
+      return (rr < 15 ? v : -v) - (Real)B.k.max_vel - sh;
+    } else if (rr < 54) {
+      int r2 = rr - 30;
+      int q = r2 < 12 ? r2 : r2 - 12;
+      Real v = val[33 + q];
+      return (r2 < 12 ? v : -v) - (Real)B.k.max_acc - sh;
+    }
+    return -T + (Real)0.3 - sh;
+  }
+  // A_r . w  where w is given per control row as G[cr][d] and for the T_min row as wT
+  DDP_DEV Real row_dot(const Real* G, int r, int P, Real wT) const {
+    int rr = r - 6 * P;
+    if (rr < 0) {
+      int j = r / P, q = r - j * P;
+      const Real* n = &L.pl[4 * q];
+      return n[0] * G[3 * j] + n[1] * G[3 * j + 1] + n[2] * G[3 * j + 2];
+    } else if (rr < 30) {
+      int q = rr < 15 ? rr : rr - 15;
+      return rr < 15 ? G[18 + q] : -G[18 + q];
+    } else if (rr < 54) {
+      int r2 = rr - 30;
+      int q = r2 < 12 ? r2 : r2 - 12;
+      return r2 < 12 ? G[33 + q] : -G[33 + q];
+    }
+    return -wT;
+  }
+
+  // dynamics x+ = (F(x)I) x + (G(x)I) u  (DDP:1062-1067) from a 19-word knot record in LDS
+  DDP_DEV Real next_x(const Real* zz, int a) const {
+    int c = a / 3, d = a % 3;
+    Real T = zz[18], acc = (Real)0;
+    for (int i = 0; i < 6; i++) {
+      Real h, hp;
+      dyn_entry(T, c, i, h, hp);
+      acc += h * zz[3 * i + d];
+    }
+    return acc;
+  }
+  // running cost q (DDP:1294-1305) of a knot record
+  DDP_DEV Real run_cost(const Real* zz) const {
+    Real T = zz[18], acc = (Real)0;
+    for (int a = 0; a < 3; a++)
+      for (int a2 = 0; a2 < 3; a2++) {
+        Real r = (Real)gram_c(a, a2) * powi(T, a + a2 + 1);
+        acc += r * (zz[9 + 3 * a] * zz[9 + 3 * a2] + zz[10 + 3 * a] * zz[10 + 3 * a2] + zz[11 + 3 * a] * zz[11 + 3 * a2]);
+      }
+    Real q = (Real)0.5 * (Real)B.k.w_snap * acc;
+    if (B.k.time_power == 2) return q + (Real)0.5 * T * (Real)B.k.w_time * T;
+    return q + (Real)0.5 * (Real)B.k.w_time * T;
+  }
+
+  // ---- evaluation sweep over one iterate buffer: costs, log / error sums, violation count.
+  // With do_roll it also propagates x (initialroll, DDP:1608-1620).
+  DDP_DEV void eval_sweep(int buf, bool do_roll) {
+    PLV(Real, slog);
+    PLV(Real, serr);
+    PLV(int, nviol);
+    LANES { LV(slog) = 0; LV(serr) = 0; LV(nviol) = 0; }
+    double qsum = 0.0;
+    int neg = 0;
+    for (int k = 0; k < N; k++) {
+      const int P = np_(k);
+      const int nc = 6 * P + 55;
+      LANES {
+        if (lane < 19) L.z[lane] = Xp(buf, k)[lane];
+        for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
+      }
+      WSYNC();
+      const Real T = L.z[18];
+      if (T < 0) neg = 1;
+      LANES {
+        if (lane < 45) {
+          int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
+          Real v = 0;
+          for (int i = 0; i < 6; i++) v += L.WbE[cr * 6 + i] * powi(T, i - o) * L.z[3 * i + d];
+          L.val[lane] = v;
+        }
+        if (do_roll && lane >= 48 && lane < 57) L.xnx[lane - 48] = next_x(L.z, lane - 48);
+        if (lane == 63) L.qs[0] = run_cost(L.z);
+      }
+      WSYNC();
+      qsum += (double)L.qs[0];
+      LANES {
+        const Real* yk = Sp_(B.Y[buf], k);
+        for (int i = 0; i < RPL; i++) {
+          int r = lane + 64 * i;
+          if (r < nc) {
+            Real c = row_c(L.val, r, P, T);
+            if (st.infeas) {
+              Real y = yk[r];
+              LV(slog) += log(y);
+              LV(serr) += fabs(c + y);
+            } else {
+              LV(slog) += log(-c);
+            }
+            if (c >= (Real)2.0e-4) LV(nviol)++;
+          }
+        }
+        if (do_roll && lane < 9) Xp(buf, k + 1)[lane] = L.xnx[lane];
+      }
+      WSYNC();
+    }
+    // terminal cost (DDP:1289-1292)
+    LANES {
+      if (lane < 9) L.z[lane] = Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane];
+    }
+    WSYNC();
+    double pterm = 0.0;
+    for (int a = 0; a < 9; a++) pterm += (double)(L.z[a] * L.z[a]);
+    WSYNC();
+    st.costq = qsum;
+    st.cost = qsum + 0.5 * B.k.w_term * pterm;
+    st.sumlog = WAVE_SUM_D(slog);
+    st.errsum = WAVE_SUM_D(serr);
+    st.viol = WAVE_SUM_I(nviol);
+    st.neg_time = neg;
+  }
+
+  // resetfilter (DDP:1636-1662) from the sums of the current iterate
+  DDP_DEV void reset_filter() {
+    double logcost = st.cost - st.mu * st.sumlog;
+    double err = 0.0;
+    if (st.infeas) {
+      err = st.errsum;
+      if (err < B.k.tol) err = 0.0;
+    }
+    st.logcost = logcost;
+    st.err = err;
+    double* f = B.filt + (size_t)b * B.fcap * 2;
+    f[0] = logcost;  // wave-uniform store: every lane writes the same value
+    f[1] = err;
+    st.nfilter = 1;
+    st.step = 0;
+    st.fp_failed = 0;
+  }
+
+  // ---- setup (DDP:104-286 without line-init) ----------------------------------------------------
+  DDP_DEV void begin() {
+    N = B.n_seg[b];
+    st.nseg = N;
+    st.cur = 0;
+    st.infeas = B.infeas_in ? (int)B.infeas_in[b] : 0;
+    st.infeas_ref = st.infeas;
+    st.line_failed = 1;
+    const Real* T0 = B.T0 + (size_t)b * B.nmax;
+    LANES {
+      if (lane < 9) Xp(0, 0)[lane] = B.x0[(size_t)b * 9 + lane];
+      // u: zero init (DDP:126-127) or the tail of the Bezier->poly row (DDP:167-193)
+      for (int k = lane; k < N; k += 64) {
+        Real* u = Xp(0, k) + 9;
+        Real T = T0[k];
+        if (B.k.zero_init || B.init_bez == nullptr) {
+          for (int a = 0; a < 9; a++) u[a] = 0;
+        } else {
+          const Real* row = B.init_bez + ((size_t)b * B.nmax + k) * 18;  // [x0..x5,y0..y5,z0..z5]
+          for (int i = 3; i < 6; i++)
+            for (int d = 0; d < 3; d++) {
+              Real acc = 0;
+              for (int l = 0; l < 6; l++) acc += (Real)kBez2Mono[l][i] * (T * row[d * 6 + l]);
+              u[(i - 3) * 3 + d] = acc / powi(T, i);
+            }
+        }
+        u[9] = T;
+      }
+    }
+    for (int k = 0; k < N; k++) {  // s = 0.1, y = 0.01 (DDP:150-151)
+      const int nc = 6 * np_(k) + 55;
+      LANES {
+        for (int i = 0; i < RPL; i++) {
+          int r = lane + 64 * i;
+          if (r < nc) {
+            Sp_(B.S[0], k)[r] = (Real)0.1;
+            Sp_(B.Y[0], k)[r] = (Real)0.01;
+          }
+        }
+      }
+    }
+    WSYNC();
+    eval_sweep(0, true);
+    st.prev_cost = st.cost;
+    st.nc0 = 6 * np_(0) + 55;
+    st.mu = st.cost / (double)N / (double)st.nc0;  // DDP:281 (quirk Q6)
+    reset_filter();
+    st.reg = 0;
+    st.bp_failed = 0;
+    st.opterr = 0.0;
+    st.stepsize = 0.0;
+    st.rtn = 0;
+    st.iter = 0;
+    st.done = 0;
+    st.bp_no_upd = 0;
+    st.no_upd = 0;
+    st.fwd_passes = 0;
+  }
+
+  // ---- backward sweep (DDP:440-644).  Returns 1 on success, 0 when the LLT failed. ---------------
+  DDP_DEV int bwd_sweep() {
+    // regulariser schedule (DDP:452-474)
+    if (st.fp_failed || st.bp_failed) {
+      st.reg += 1;
+    } else if (st.step == 0) {
+      st.reg -= 1;
+    } else if (st.step > 3) {
+      st.reg += 1;
+    }
+    if (st.reg < 0) st.reg = 0;
+    if (st.reg > 24) st.reg = 24;
+    double lam_d = 1.0;
+    for (int q = 0; q < st.reg; q++) lam_d *= B.k.reg_base;
+    const Real lam = (Real)(lam_d - 1.0);  // DDP:529
+    const int buf = st.cur;
+    const int infeas = st.infeas;
+    const Real mu = (Real)st.mu;
+    const Real wsn = (Real)B.k.w_snap;
+
+    // terminal derivatives (DDP:1318-1323)
+    LANES {
+      for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Real)B.k.w_term : (Real)0;
+      if (lane < 9) L.Vx[lane] = (Real)B.k.w_term * (Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane]);
+    }
+    WSYNC();
+    PLV(Real, e_mu);
+    PLV(Real, e_c);
+    LANES { LV(e_mu) = 0; LV(e_c) = 0; }
+    double qu_err = 0.0;
+
+    for (int k = N - 1; k >= 0; k--) {
+      const int P = np_(k);
+      const int nc = 6 * P + 55;
+      PLA(Real, rs, RPL);
+      PLA(Real, ry, RPL);
+      PLA(Real, rc, RPL);
+      PLA(Real, rr, RPL);  // r (feasible) or rhat (infeasible)
+      // ---- L: load the knot
+      LANES {
+        if (lane < 19) L.z[lane] = Xp(buf, k)[lane];
+        for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
+        for (int i = 0; i < RPL; i++) {
+          int r = lane + 64 * i;
+          LV(rs)[i] = (r < nc) ? Sp_(B.S[buf], k)[r] : (Real)0;
+          LV(ry)[i] = (r < nc && infeas) ? Sp_(B.Y[buf], k)[r] : (Real)1;
+        }
+      }
+      WSYNC();
+      const Real T = L.z[18];
+      // ---- T1: scaled value table, dynamics tables, jerk-cost vectors
+      LANES {
+        for (int e = lane; e < 90; e += 64) {
+          int cr = e / 6, i = e % 6;
+          L.We[e] = L.WbE[e] * powi(T, i - ctrl_off(cr));
+        }
+        if (lane < 18) {
+          Real h, hp;
+          dyn_entry(T, lane / 6, lane % 6, h, hp);
+          L.H[lane] = h;
+          L.Hp[lane] = hp;
+        }
+        if (lane >= 32 && lane < 59) {  // Ru, R'u, R''u (DDP:1349-1355)
+          int t = (lane - 32) / 9, a9 = (lane - 32) % 9, a = a9 / 3, d = a9 % 3;
+          Real acc = 0;
+          for (int a2 = 0; a2 < 3; a2++) {
+            int e = a + a2 + 1 - t;
+            Real cf = (Real)gram_c(a, a2);
+            if (t >= 1) cf *= (Real)(a + a2 + 1);
+            if (t == 2) cf *= (Real)(a + a2);
+            Real pw = (e >= 0) ? powi(T, e) : (Real)0;
+            acc += cf * pw * L.z[9 + 3 * a2 + d];
+          }
+          if (t == 0) L.Ru[a9] = acc;
+          else if (t == 1) L.Rpu[a9] = acc;
+          else L.Rppu[a9] = acc;
+        }
+      }
+      WSYNC();
+      // ---- T2: control values and their d/dT, fT, u'R'u, u'R''u
+      LANES {
+        if (lane < 45) {
+          int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
+          Real v = 0, dv = 0;
+          for (int i = 0; i < 6; i++) {
+            Real zi = L.z[3 * i + d];
+            v += L.We[cr * 6 + i] * zi;
+            int e = i - o - 1;
+            Real pw = (e >= 0) ? powi(T, e) : (Real)0;
+            dv += L.WdE[cr * 6 + i] * pw * zi;
+          }
+          L.val[lane] = v;
+          L.dval[lane] = dv;
+        } else if (lane < 54) {
+          int a = lane - 45, c = a / 3, d = a % 3;
+          Real acc = 0;
+          for (int i = 0; i < 6; i++) acc += L.Hp[c * 6 + i] * L.z[3 * i + d];
+          L.fT[a] = acc;  // DDP:1332
+        } else if (lane < 56) {
+          const Real* v = (lane == 54) ? L.Rpu : L.Rppu;
+          Real acc = 0;
+          for (int a = 0; a < 9; a++) acc += L.z[9 + a] * v[a];
+          L.qs[lane - 54] = acc;
+        }
+      }
+      WSYNC();
+      // ---- R1: constraint rows -> D, g ; VZ = Vxx * Z
+      LANES {
+        for (int i = 0; i < RPL; i++) {
+          int r = lane + 64 * i;
+          if (r < nc) {
+            Real c = row_c(L.val, r, P, T), s = LV(rs)[i], y = LV(ry)[i];
+            Real D, g, rv;
+            if (infeas) {  // DDP:535-539, 554
+              Real rm = s * y - mu;
+              rv = s * (c + y) - rm;  // rhat
+              Real yinv = (Real)1 / y;
+              D = s * yinv;
+              g = s + yinv * rv;
+              LV(e_mu) = fmax(LV(e_mu), fabs(rm));
+              LV(e_c) = fmax(LV(e_c), fabs(c + y));
+            } else {  // DDP:583-587, 601
+              rv = s * c + mu;
+              Real cinv = (Real)1 / c;
+              D = s * cinv;
+              g = -mu * cinv;  // s - r/c
+              LV(e_mu) = fmax(LV(e_mu), fabs(rv));
+            }
+            LV(rc)[i] = c;
+            LV(rr)[i] = rv;
+            L.drow[r] = D;
+            L.grow[r] = g;
+          }
+        }
+        for (int e = lane; e < 171; e += 64) {  // VZ[a][q]
+          int a = e / 19, q = e % 19;
+          Real acc = 0;
+          if (q < 18) {
+            int i = q / 3, d = q % 3;
+            for (int c = 0; c < 3; c++) acc += L.V[a * 9 + 3 * c + d] * L.H[c * 6 + i];
+          } else {
+            for (int c = 0; c < 9; c++) acc += L.V[a * 9 + c] * L.fT[c];
+          }
+          L.VZ[e] = acc;
+        }
+      }
+      WSYNC();
+      // ---- S: 3x3 accumulators per control row
+      LANES {
+        if (lane < 54) {
+          int j, d0, d1;
+          const Real* w;
+          if (lane < 36) {
+            const int e = lane % 6;
+            j = lane / 6;
+            d0 = (e < 3) ? 0 : (e < 5 ? 1 : 2);
+            d1 = (e < 3) ? e : (e < 5 ? e - 2 : 2);
+            w = L.drow;
+          } else {
+            j = (lane - 36) / 3;
+            d0 = (lane - 36) % 3;
+            d1 = 3;  // reads n[3] replaced by 1 below
+            w = L.grow;
+          }
+          Real acc = 0;
+          for (int q = 0; q < P; q++) {
+            const Real* n = &L.pl[4 * q];
+            Real f = (d1 == 3) ? (Real)1 : n[d1];
+            acc += w[j * P + q] * n[d0] * f;
+          }
+          if (lane < 36) L.Sp[lane] = acc;
+          else L.hp[lane - 36] = acc;
+        }
+        if (lane < 27) {  // velocity / acceleration rows: +/- pairs
+          int rp, rm;
+          if (lane < 15) {
+            rp = 6 * P + lane;
+            rm = rp + 15;
+          } else {
+            rp = 6 * P + 30 + (lane - 15);
+            rm = rp + 12;
+          }
+          L.dl[lane] = L.drow[rp] + L.drow[rm];
+          L.gm[lane] = L.grow[rp] - L.grow[rm];
+        }
+        if (lane == 63) {
+          L.last[0] = L.drow[nc - 1];
+          L.last[1] = L.grow[nc - 1];
+        }
+      }
+      WSYNC();
+      // ---- S2: Sd = S_cr * dval[cr]
+      LANES {
+        if (lane < 45) {
+          int cr = lane / 3, d = lane % 3;
+          Real acc;
+          if (cr < 6) {
+            const Real* S = &L.Sp[cr * 6];  // xx,xy,xz,yy,yz,zz
+            const Real* dv = &L.dval[cr * 3];
+            if (d == 0) acc = S[0] * dv[0] + S[1] * dv[1] + S[2] * dv[2];
+            else if (d == 1) acc = S[1] * dv[0] + S[3] * dv[1] + S[4] * dv[2];
+            else acc = S[2] * dv[0] + S[4] * dv[1] + S[5] * dv[2];
+          } else {
+            acc = L.dl[lane - 18] * L.dval[lane];
+          }
+          L.Sd[lane] = acc;
+        }
+      }
+      WSYNC();
+      // ---- H: assemble the 19x19 system  Hzz = Z'VZ + quu -/+ A'DA,  Hz = qz + Z'Vx + A'g
+      const Real sig = infeas ? (Real)1 : (Real)-1;
+      LANES {
+        for (int e = lane; e < 190; e += 64) {
+          int p = L.pq[e] & 255, q = L.pq[e] >> 8;
+          Real ada = 0, zvz = 0, quu = 0;
+          if (q < 18) {
+            int i = p / 3, d = p % 3, i2 = q / 3, d2 = q % 3;
+            int se = (d <= d2) ? (d * 3 - (d * (d - 1)) / 2 + (d2 - d)) : (d2 * 3 - (d2 * (d2 - 1)) / 2 + (d - d2));
+            for (int cr = 0; cr < 6; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.Sp[cr * 6 + se];
+            if (d == d2)
+              for (int cr = 6; cr < 15; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.dl[(cr - 6) * 3 + d];
+            for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + q];
+            if (i >= 3 && d == d2) quu = wsn * (Real)gram_c(i - 3, i2 - 3) * powi(T, i + i2 - 5);
+          } else if (p < 18) {
+            int i = p / 3, d = p % 3;
+            for (int cr = 0; cr < 15; cr++) ada += L.We[cr * 6 + i] * L.Sd[cr * 3 + d];
+            for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
+            if (i >= 3) quu = wsn * L.Rpu[p - 9];
+          } else {
+            for (int t = 0; t < 45; t++) ada += L.dval[t] * L.Sd[t];
+            ada += L.last[0];
+            for (int a = 0; a < 9; a++) zvz += L.fT[a] * L.VZ[a * 19 + 18];
+            quu = ((B.k.time_power == 2) ? (Real)B.k.w_time : (Real)0) + (Real)0.5 * wsn * L.qs[1];
+          }
+          Real v = zvz + quu + sig * ada;
+          L.Hzz[p * 19 + q] = v;
+          L.Hzz[q * 19 + p] = v;
+        }
+        if (lane < 19) {
+          int p = lane;
+          Real ag = 0, zv = 0, qz = 0;
+          if (p < 18) {
+            int i = p / 3, d = p % 3;
+            for (int cr = 0; cr < 6; cr++) ag += L.We[cr * 6 + i] * L.hp[cr * 3 + d];
+            for (int cr = 6; cr < 15; cr++) ag += L.We[cr * 6 + i] * L.gm[(cr - 6) * 3 + d];
+            for (int c = 0; c < 3; c++) zv += L.H[c * 6 + i] * L.Vx[3 * c + d];
+            if (i >= 3) qz = wsn * L.Ru[p - 9];
+          } else {
+            for (int t = 0; t < 18; t++) ag += L.dval[t] * L.hp[t];
+            for (int t = 18; t < 45; t++) ag += L.dval[t] * L.gm[t - 18];
+            ag -= L.last[1];
+            for (int a = 0; a < 9; a++) zv += L.fT[a] * L.Vx[a];
+            qz = ((B.k.time_power == 2) ? (Real)B.k.w_time * T : (Real)0.5 * (Real)B.k.w_time) + (Real)0.5 * wsn * L.qs[0];
+          }
+          L.Hz[p] = qz + zv + ag;
+        }
+      }
+      WSYNC();
+      // ---- C: LLT of Huu + lam I and the 10 right-hand sides, one column per lane
+      PLA(Real, m, 10);
+      LANES {
+        for (int a = 0; a < 10; a++) {
+          Real v = 0;
+          if (lane < 10) v = L.Hzz[(9 + a) * 19 + 9 + lane] + ((a == lane) ? lam : (Real)0);
+          else if (lane == 10) v = L.Hz[9 + a];
+          else if (lane < 20) v = L.Hzz[(9 + a) * 19 + (lane - 11)];
+          LV(m)[a] = v;
+        }
+      }
+      int ok = 1;
+#pragma unroll
+      for (int kk = 0; kk < 10; kk++) {
+        Real piv = RDLANE(m, kk, kk);
+        if (piv <= (Real)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
+        Real rinv = (Real)1 / sqrt(piv);
+        Real l[10];
+#pragma unroll
+        for (int i = kk + 1; i < 10; i++) l[i] = RDLANE(m, i, kk) * rinv;
+        LANES {
+          Real mk = LV(m)[kk] * rinv;
+          LV(m)[kk] = mk;
+#pragma unroll
+          for (int i = kk + 1; i < 10; i++) LV(m)[i] -= l[i] * mk;
+        }
+      }
+      ok = DDP_UNIFORM_I(ok);
+      if (!ok) {  // DDP:546-551, 595-600
+        st.bp_failed = 1;
+        st.opterr = INFINITY;
+        return 0;
+      }
+#pragma unroll
+      for (int i = 9; i >= 0; i--) {
+        Real dinv = (Real)1 / RDLANE(m, i, i);
+        Real uij[10];
+#pragma unroll
+        for (int j = i + 1; j < 10; j++) uij[j] = RDLANE(m, i, j);
+        LANES {
+          Real acc = LV(m)[i];
+#pragma unroll
+          for (int j = i + 1; j < 10; j++) acc -= uij[j] * LV(m)[j];
+          if (lane >= 10) LV(m)[i] = acc * dinv;
+        }
+      }
+      LANES {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
+        if (lane >= 10 && lane < 20) {
+          int col = lane - 10;
+          for (int a = 0; a < 10; a++) {
+            if (col == 0) L.KU[a] = -LV(m)[a];
+            else L.KU[10 + a * 9 + (col - 1)] = -LV(m)[a];
+          }
+        }
+      }
+      WSYNC();
+      // ---- G: cu*ku per control row; products for the V recursion
+      LANES {
+        if (lane < 45) {
+          int cr = lane / 3, d = lane % 3;
+          Real acc = L.dval[lane] * L.KU[9];
+          for (int i = 3; i < 6; i++) acc += L.We[cr * 6 + i] * L.KU[(i - 3) * 3 + d];
+          L.G[lane] = acc;
+        }
+        for (int e = lane; e < 190; e += 64) {
+          Real acc = 0;
+          if (e < 81) {  // W1 = Hxu * Ku
+            int a = e / 9, c2 = e % 9;
+            for (int c = 0; c < 10; c++) acc += L.Hzz[a * 19 + 9 + c] * L.KU[10 + c * 9 + c2];
+            L.W1[e] = acc;
+          } else if (e < 171) {  // W2 = Huu * Ku
+            int a = (e - 81) / 9, c2 = (e - 81) % 9;
+            for (int c = 0; c < 10; c++) acc += L.Hzz[(9 + a) * 19 + 9 + c] * L.KU[10 + c * 9 + c2];
+            L.W2[e - 81] = acc;
+          } else if (e < 181) {  // t10 = Huu * ku
+            int a = e - 171;
+            for (int c = 0; c < 10; c++) acc += L.Hzz[(9 + a) * 19 + 9 + c] * L.KU[c];
+            L.t10[a] = acc;
+          } else {  // hk = Hxu * ku
+            int a = e - 181;
+            for (int c = 0; c < 10; c++) acc += L.Hzz[a * 19 + 9 + c] * L.KU[c];
+            L.hk[a] = acc;
+          }
+        }
+      }
+      WSYNC();
+      for (int a = 0; a < 10; a++) qu_err = fmax(qu_err, fabs((double)L.Hz[9 + a]));  // DDP:633 (quirk Q10)
+      // ---- R2: slack / dual gains per row; V recursion; gains to HBM
+      LANES {
+        Real* ksg = Sp_(B.KS, k);
+        Real* kyg = Sp_(B.KY, k);
+        const Real kuT = L.KU[9];
+        for (int i = 0; i < RPL; i++) {
+          int r = lane + 64 * i;
+          if (r < nc) {
+            Real cuku = row_dot(L.G, r, P, kuT);
+            Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
+            if (infeas) {  // DDP:568, 571
+              Real y = LV(ry)[i];
+              ksg[r] = (rv + s * cuku) / y;
+              kyg[r] = -(c + y) - cuku;
+            } else {  // DDP:611
+              ksg[r] = -((rv + s * cuku) / c);
+            }
+          }
+        }
+        for (int e = lane; e < 100; e += 64) KUp(k)[e] = L.KU[e];
+        Real vnew = 0, vnew2 = 0;
+        int a = 0, c2 = 0;
+        if (lane < 45) {  // Vxx (DDP:627-628), pairs a <= c2
+          int rem = lane;
+          while (rem >= 9 - a) {
+            rem -= 9 - a;
+            a++;
+          }
+          c2 = a + rem;
+          Real m1 = L.Hzz[a * 19 + c2] + L.W1[a * 9 + c2] + L.W1[c2 * 9 + a];
+          Real m2 = m1;
+          for (int c = 0; c < 10; c++) {
+            m1 += L.KU[10 + c * 9 + a] * L.W2[c * 9 + c2];
+            m2 += L.KU[10 + c * 9 + c2] * L.W2[c * 9 + a];
+          }
+          vnew = (Real)0.5 * (m1 + m2);
+        } else if (lane < 54) {  // Vx (DDP:626)
+          int aa = lane - 45;
+          vnew2 = L.Hz[aa] + L.hk[aa];
+          for (int c = 0; c < 10; c++) vnew2 += L.KU[10 + c * 9 + aa] * (L.Hz[9 + c] + L.t10[c]);
+        }
+        // V / Vx are dead since phase H of this knot: safe to overwrite without another sync
+        if (lane < 45) {
+          L.V[a * 9 + c2] = vnew;
+          L.V[c2 * 9 + a] = vnew;
+        } else if (lane < 54) {
+          L.Vx[lane - 45] = vnew2;
+        }
+      }
+      WSYNC();
+    }
+    double mu_err = WAVE_MAX_D(e_mu);
+    double c_err = infeas ? WAVE_MAX_D(e_c) : 0.0;
+    st.bp_failed = 0;
+    st.opterr = fmax(fmax(qu_err, c_err), mu_err);  // DDP:641
+    return 1;
+  }
+
+  // ---- forward pass (DDP:647-778) ---------------------------------------------------------------
+  DDP_DEV void fwd_pass() {
+    const int cur = st.cur, nxt = 1 - st.cur;
+    const int infeas = st.infeas;
+    const double tau_d = fmax(0.99, 1.0 - st.mu);
+    const Real omt = (Real)(1.0 - tau_d);
+    double* filt = B.filt + (size_t)b * B.fcap * 2;
+    int accepted = 0, step = 0;
+    double cost = 0, costq = 0, logcost = 0, err = 0, sumlog = 0, errsum = 0, stepsize = 0;
+    int viol = 0, neg = 0;
+    for (step = 0; step < 11; step++) {
+      stepsize = 1.0;
+      for (int q = 0; q < step; q++) stepsize *= 0.5;  // DDP:670
+      const Real alpha = (Real)stepsize;
+      PLV(Real, slog);
+      PLV(Real, serr);
+      PLV(int, nviol);
+      LANES {
+        LV(slog) = 0; LV(serr) = 0; LV(nviol) = 0;
+        if (lane < 9) L.xn[lane] = Xp(cur, 0)[lane];
+      }
+      WSYNC();
+      double qsum = 0.0;
+      int failed = 0;
+      neg = 0;
+      for (int k = 0; k < N; k++) {
+        const int P = np_(k);
+        const int nc = 6 * P + 55;
+        PLA(Real, rs, RPL);
+        PLA(Real, ry, RPL);
+        PLA(Real, rks, RPL);
+        PLA(Real, rky, RPL);
+        LANES {
+          if (lane < 19) L.z[lane] = Xp(cur, k)[lane];
+          for (int e = lane; e < 100; e += 64) L.KU[e] = KUp(k)[e];
+          for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
+          for (int i = 0; i < RPL; i++) {
+            int r = lane + 64 * i;
+            bool in = r < nc;
+            LV(rs)[i] = in ? Sp_(B.S[cur], k)[r] : (Real)0;
+            LV(rks)[i] = in ? Sp_(B.KS, k)[r] : (Real)0;
+            LV(ry)[i] = (in && infeas) ? Sp_(B.Y[cur], k)[r] : (Real)1;
+            LV(rky)[i] = (in && infeas) ? Sp_(B.KY, k)[r] : (Real)0;
+          }
+        }
+        WSYNC();
+        // ---- D: dx, Ku dx, u+ (DDP:689 / 695)
+        LANES {
+          if (lane < 9) {
+            Real dx = L.xn[lane] - L.z[lane];
+            L.dz[lane] = dx;
+            L.zn[lane] = L.xn[lane];
+          } else if (lane < 19) {
+            int a = lane - 9;
+            Real acc = 0;
+            for (int c = 0; c < 9; c++) acc += L.KU[10 + a * 9 + c] * (L.xn[c] - L.z[c]);
+            L.dz[lane] = acc;
+            L.zn[lane] = L.z[lane] + alpha * L.KU[a] + acc;
+          }
+        }
+        WSYNC();
+        const Real To = L.z[18], Tn = L.zn[18];
+        if (Tn < 0) neg = 1;
+        // ---- T: control values at the old and the new iterate, A*[dx; Ku dx]
+        LANES {
+          if (lane < 45) {
+            int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
+            Real vo = 0, dvo = 0, vn = 0, gf = 0;
+            for (int i = 0; i < 6; i++) {
+              Real wb = L.WbE[cr * 6 + i];
+              Real w = wb * powi(To, i - o);
+              vo += w * L.z[3 * i + d];
+              gf += w * L.dz[3 * i + d];
+              int e = i - o - 1;
+              dvo += L.WdE[cr * 6 + i] * ((e >= 0) ? powi(To, e) : (Real)0) * L.z[3 * i + d];
+              vn += wb * powi(Tn, i - o) * L.zn[3 * i + d];
+            }
+            L.val[lane] = vo;
+            L.valn[lane] = vn;
+            L.G[lane] = gf + dvo * L.dz[18];
+          } else if (lane < 54) {
+            L.xnx[lane - 45] = next_x(L.zn, lane - 45);
+          } else if (lane == 54) {
+            L.qs[0] = run_cost(L.zn);
+          }
+        }
+        WSYNC();
+        qsum += (double)L.qs[0];
+        // ---- R: rows: s+, y+, c+, fraction-to-boundary tests
+        PLV(int, bad);
+        LANES {
+          LV(bad) = 0;
+          Real* sn = Sp_(B.S[nxt], k);
+          Real* yn = Sp_(B.Y[nxt], k);
+          const Real dzT = L.dz[18];
+          for (int i = 0; i < RPL; i++) {
+            int r = lane + 64 * i;
+            if (r < nc) {
+              Real az = row_dot(L.G, r, P, dzT);
+              Real cn = row_c(L.valn, r, P, Tn);
+              Real s = LV(rs)[i];
+              Real snew;
+              if (infeas) {  // DDP:680-687
+                Real y = LV(ry)[i];
+                Real ynew = y + alpha * LV(rky)[i] - az;
+                snew = s + alpha * LV(rks)[i] + (s / y) * az;
+                if (ynew < omt * y || snew < omt * s) LV(bad) = 1;
+                yn[r] = ynew;
+                LV(slog) += log(ynew);
+                LV(serr) += fabs(cn + ynew);
+              } else {  // DDP:694-703
+                Real co = row_c(L.val, r, P, To);
+                snew = s + alpha * LV(rks)[i] - (s / co) * az;
+                if (cn > omt * co || snew < omt * s) LV(bad) = 1;
+                LV(slog) += log(-cn);
+              }
+              sn[r] = snew;
+              if (cn >= (Real)2.0e-4) LV(nviol)++;
+            }
+          }
+          if (lane < 19) Xp(nxt, k)[lane] = L.zn[lane];
+          if (lane < 9) L.xn[lane] = L.xnx[lane];
+        }
+        failed = WAVE_ANY(bad);
+        WSYNC();
+        if (failed) break;
+      }
+      if (failed) continue;
+      LANES {
+        if (lane < 9) {
+          Xp(nxt, N)[lane] = L.xn[lane];
+          L.z[lane] = L.xn[lane] - B.xd[(size_t)b * 9 + lane];
+        }
+      }
+      WSYNC();
+      double pterm = 0.0;
+      for (int a = 0; a < 9; a++) pterm += (double)(L.z[a] * L.z[a]);
+      WSYNC();
+      costq = qsum;
+      cost = qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
+      sumlog = WAVE_SUM_D(slog);
+      errsum = WAVE_SUM_D(serr);
+      viol = WAVE_SUM_I(nviol);
+      logcost = cost - st.mu * sumlog;  // DDP:718-732
+      err = infeas ? fmax(B.k.tol, errsum) : 0.0;
+      // filter (DDP:737-757)
+      int nkeep = 0, rejected = 0;
+      for (int i = 0; i < st.nfilter; i++) {
+        double f0 = filt[2 * i], f1 = filt[2 * i + 1];
+        if (logcost >= f0 && err >= f1) {
+          rejected = 1;
+          break;
+        }
+      }
+      if (rejected) continue;
+      for (int i = 0; i < st.nfilter; i++) {
+        double f0 = filt[2 * i], f1 = filt[2 * i + 1];
+        if (logcost > f0 || err > f1) {  // wave-uniform stores (nkeep <= i)
+          filt[2 * nkeep] = f0;
+          filt[2 * nkeep + 1] = f1;
+          nkeep++;
+        }
+      }
+      filt[2 * nkeep] = logcost;
+      filt[2 * nkeep + 1] = err;
+      st.nfilter = nkeep + 1;
+      accepted = 1;
+      break;
+    }
+    if (!accepted) {  // DDP:760-762
+      st.fp_failed = 1;
+      st.stepsize = 0.0;
+    } else {  // DDP:763-776
+      st.cost = cost;
+      st.costq = costq;
+      st.logcost = logcost;
+      st.err = err;
+      st.sumlog = sumlog;
+      st.errsum = errsum;
+      st.viol = viol;
+      st.neg_time = neg;
+      st.stepsize = stepsize;
+      st.step = step;
+      st.fp_failed = 0;
+      st.cur = nxt;
+    }
+  }
+
+  // ---- one trip of the outer loop (DDP:295-412).  Sets st.done when the loop breaks. ------------
+  DDP_DEV void iterate_once() {
+    while (true) {  // DDP:297-310
+      if (bwd_sweep()) break;
+      if (st.reg == 24 && st.bp_failed) st.bp_no_upd++;
+      else st.bp_no_upd = 0;
+      if (st.bp_no_upd > 20) break;
+    }
+    fwd_pass();
+    st.fwd_passes++;
+    if (st.neg_time) {  // DDP:317-326
+      st.rtn = -3;
+      st.done = 1;
+      return;
+    }
+    const double prev_cost = st.prev_cost;
+    st.prev_cost = st.cost;
+    if (!B.k.fixed_iters && fmax(st.opterr, st.mu) <= B.k.tol) {  // DDP:335-338
+      st.done = 1;
+      return;
+    }
+    if (st.opterr <= 0.2 * st.mu) {  // DDP:340-344
+      st.mu = fmax(B.k.tol / 10.0, fmin(0.2 * st.mu, pow(st.mu, 1.2)));
+      reset_filter();
+      st.reg = 0;
+      st.bp_failed = 0;
+    }
+    if (st.viol == 0 && !B.k.fixed_iters) {  // DDP:346-390
+      if (B.k.zero_init) {
+        st.infeas_ref = 0;
+        st.rtn = 2;
+        st.done = 1;
+        return;
+      }
+      if (!B.k.line_init) {
+        double d = st.cost - prev_cost;
+        if (d * d < prev_cost * 1.0e-2 && st.opterr < 5.0e1) {
+          st.rtn = 1;
+          st.done = 1;
+          return;
+        }
+      } else {
+        double d = st.cost - prev_cost;
+        if (d * d < prev_cost * 0.01) {
+          st.line_failed = 0;
+          st.done = 1;
+          return;
+        }
+      }
+    }
+    if (st.bp_no_upd > 20) {  // DDP:392-396
+      st.rtn = -4;
+      st.done = 1;
+      return;
+    }
+    if (B.k.line_init) {  // DDP:398-409
+      if (st.stepsize < 1.0e-6) st.no_upd++;
+      else st.no_upd = 0;
+      if (st.no_upd > 100) {
+        st.done = 1;
+        return;
+      }
+    }
+  }
+
+  DDP_DEV void iterate(int n_iters) {
+    for (int it = 0; it < n_iters && !st.done; it++) {
+      if (st.iter >= B.k.iter_max) {
+        st.done = 1;
+        break;
+      }
+      iterate_once();
+      if (!st.done) {
+        st.iter++;
+        if (st.iter >= B.k.iter_max) st.done = 1;
+      }
+    }
+  }
+};
+
+// ---- results (DDP:414-437 and the getters of DDPH:299-340) --------------------------------------
+template <typename Real>
+struct OutPtrs {
+  int32_t *rtn, *iter_used, *fwd_passes;
+  uint8_t *infeas_out, *line_failed_out;
+  Real *cost, *costq, *jerk_cost, *terminal_norm2, *opterr, *mu, *bez, *poly, *T;
+};
+
+template <typename Real, int RPL>
+DDP_DEV void finish_wave(Wave<Real, RPL>& W, const OutPtrs<Real>& O) {
+  const Batch<Real>& B = W.B;
+  const int b = W.b, N = W.N, buf = W.st.cur;
+  PLV(Real, jc);
+  LANES {
+    LV(jc) = 0;
+    for (int k = lane; k < N; k += 64) {
+      const Real* zz = W.Xp(buf, k);
+      Real T = zz[18], acc = 0;  // finalroll, DDP:1624-1634
+      for (int a = 0; a < 3; a++)
+        for (int a2 = 0; a2 < 3; a2++) {
+          Real r = (Real)gram_c(a, a2) * powi(T, a + a2 + 1);
+          acc += r * (zz[9 + 3 * a] * zz[9 + 3 * a2] + zz[10 + 3 * a] * zz[10 + 3 * a2] + zz[11 + 3 * a] * zz[11 + 3 * a2]);
+        }
+      LV(jc) += acc;
+      Real poly[18];  // sysparam2polyFunc, DDP:814-823
+      for (int a = 0; a < 9; a++) poly[a] = ((a / 3 == 2) ? (Real)0.5 : (Real)1) * zz[a];
+      for (int a = 0; a < 9; a++) poly[9 + a] = zz[9 + a];
+      size_t row = ((size_t)b * B.nmax + k) * 18;
+      if (O.poly)
+        for (int a = 0; a < 18; a++) O.poly[row + a] = poly[a];
+      if (O.T) O.T[(size_t)b * B.nmax + k] = T;
+      if (O.bez) {  // poly2bezFunc + layout swap, DDP:799-812, 430-436
+        Real invT = (Real)1 / T;
+        for (int j = 0; j < 6; j++)
+          for (int d = 0; d < 3; d++) {
+            Real acc2 = 0;
+            for (int i = 0; i < 6; i++) acc2 += (invT * poly[3 * i + d]) * powi(T, i) * (Real)kMono2Bez[i][j];
+            O.bez[row + d * 6 + j] = acc2;
+          }
+      }
+    }
+  }
+  double jsum = WAVE_SUM_D(jc);
+  PLV(Real, tn);
+  LANES {
+    LV(tn) = 0;
+    if (lane < 9) {
+      Real d = W.Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane];
+      LV(tn) = d * d;
+    }
+  }
+  double tsum = WAVE_SUM_D(tn);
+  LANES {
+    if (lane == 0) {
+      const TrajState& s = W.st;
+      if (O.rtn) O.rtn[b] = s.rtn;
+      if (O.iter_used) O.iter_used[b] = s.iter;
+      if (O.fwd_passes) O.fwd_passes[b] = s.fwd_passes;
+      if (O.infeas_out) O.infeas_out[b] = (uint8_t)s.infeas_ref;
+      if (O.line_failed_out) O.line_failed_out[b] = (uint8_t)s.line_failed;
+      if (O.cost) O.cost[b] = (Real)s.cost;
+      if (O.costq) O.costq[b] = (Real)s.costq;
+      if (O.jerk_cost) O.jerk_cost[b] = (Real)jsum;
+      if (O.terminal_norm2) O.terminal_norm2[b] = (Real)tsum;
+      if (O.opterr) O.opterr[b] = (Real)s.opterr;
+      if (O.mu) O.mu[b] = (Real)s.mu;
+    }
+  }
+}
+
+// ---- stepwise interface helpers: dense read-out / injection of solver fields --------------------
+// Field ids and layouts: include/direct_ddp.h (direct_field_t); nc_max = 6*pmax + 55.
+template <typename Real, int RPL>
+DDP_DEV void get_field_wave(Wave<Real, RPL>& W, int field, Real* dst) {
+  const Batch<Real>& B = W.B;
+  const int b = W.b, N = W.N, buf = W.st.cur, ncm = 6 * B.pmax + 55;
+  if (field == 9) {
+    const TrajState& s = W.st;
+    Real* o = dst + (size_t)b * 16;
+    o[0] = (Real)s.cost; o[1] = (Real)s.costq; o[2] = (Real)s.logcost; o[3] = (Real)s.err;
+    o[4] = (Real)s.mu; o[5] = (Real)s.reg; o[6] = (Real)s.opterr; o[7] = (Real)s.stepsize;
+    o[8] = (Real)s.step; o[9] = (Real)s.fp_failed; o[10] = (Real)s.bp_failed; o[11] = (Real)s.rtn;
+    o[12] = (Real)s.iter; o[13] = (Real)s.done; o[14] = (Real)s.nfilter; o[15] = (Real)s.infeas;
+    return;
+  }
+  if (field == 0) {
+    LANES {
+      for (int e = lane; e < (N + 1) * 9; e += 64) dst[(size_t)b * (B.nmax + 1) * 9 + e] = W.Xp(buf, e / 9)[e % 9];
+    }
+    return;
+  }
+  for (int k = 0; k < N; k++) {
+    const int P = W.np_(k), nc = 6 * P + 55;
+    size_t rowbase = ((size_t)b * B.nmax + k) * ncm;
+    if (field == 1) {
+      LANES { if (lane < 10) dst[((size_t)b * B.nmax + k) * 10 + lane] = W.Xp(buf, k)[9 + lane]; }
+    } else if (field == 5) {
+      LANES { if (lane < 10) dst[((size_t)b * B.nmax + k) * 10 + lane] = W.KUp(k)[lane]; }
+    } else if (field == 6) {
+      LANES { for (int e = lane; e < 90; e += 64) dst[((size_t)b * B.nmax + k) * 90 + e] = W.KUp(k)[10 + e]; }
+    } else if (field == 4) {
+      LANES {
+        if (lane < 19) W.L.z[lane] = W.Xp(buf, k)[lane];
+        for (int e = lane; e < 4 * P; e += 64) W.L.pl[e] = W.planes_(k)[e];
+      }
+      WSYNC();
+      const Real T = W.L.z[18];
+      LANES {
+        if (lane < 45) {
+          int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
+          Real v = 0;
+          for (int i = 0; i < 6; i++) v += W.L.WbE[cr * 6 + i] * powi(T, i - o) * W.L.z[3 * i + d];
+          W.L.val[lane] = v;
+        }
+      }
+      WSYNC();
+      LANES {
+        for (int r = lane; r < nc; r += 64) dst[rowbase + r] = W.row_c(W.L.val, r, P, T);
+      }
+      WSYNC();
+    } else {
+      const Real* src = (field == 2) ? W.Sp_(B.S[buf], k) : (field == 3) ? W.Sp_(B.Y[buf], k)
+                        : (field == 7) ? W.Sp_(B.KS, k) : W.Sp_(B.KY, k);
+      LANES { for (int r = lane; r < nc; r += 64) dst[rowbase + r] = src[r]; }
+    }
+  }
+}
+
+template <typename Real, int RPL>
+DDP_DEV void set_field_wave(Wave<Real, RPL>& W, int field, const Real* src) {
+  const Batch<Real>& B = W.B;
+  const int b = W.b, N = W.N, buf = W.st.cur, ncm = 6 * B.pmax + 55;
+  if (field == 0) {
+    LANES {
+      for (int e = lane; e < (N + 1) * 9; e += 64) W.Xp(buf, e / 9)[e % 9] = src[(size_t)b * (B.nmax + 1) * 9 + e];
+    }
+    return;
+  }
+  for (int k = 0; k < N; k++) {
+    const int nc = 6 * W.np_(k) + 55;
+    size_t rowbase = ((size_t)b * B.nmax + k) * ncm;
+    if (field == 1) {
+      LANES { if (lane < 10) W.Xp(buf, k)[9 + lane] = src[((size_t)b * B.nmax + k) * 10 + lane]; }
+    } else if (field == 2 || field == 3) {
+      Real* d = (field == 2) ? W.Sp_(B.S[buf], k) : W.Sp_(B.Y[buf], k);
+      LANES { for (int r = lane; r < nc; r += 64) d[r] = src[rowbase + r]; }
+    }
+  }
+}
+
+}  // namespace direct

@@ -1,0 +1,606 @@
+// libdirect_ddp.so: gfx950 kernels + the C-ABI of include/direct_ddp.h.
+//
+// Replaces ddpTrajOptimizer::polyCurveGeneration (global_planner/src/ddp_optimizer.cpp:5-438) for a
+// batch of independent corridors.  One workgroup = one 64-lane wavefront = one trajectory
+// (ddp_wave.h); the host side below only moves data, launches and times.  There is no CPU path:
+// without a gfx950 device direct_ddp_create() fails with DIRECT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/direct_ddp.h"
+#include "ddp_wave.h"
+
+using namespace direct;
+
+// ---- kernels ---------------------------------------------------------------------------------------
+template <typename Real, int RPL>
+__global__ __launch_bounds__(64) void k_begin(Batch<Real> B) {
+  __shared__ WaveLds<Real, RPL> lds;
+  const int b = blockIdx.x;
+  Wave<Real, RPL> W(B, lds, b);
+  W.init_tables();
+  W.begin();
+  if (threadIdx.x == 0) B.st[b] = W.st;
+}
+
+// mode 0: n outer iterations; 1: one backwardpass(); 2: one forwardpass()
+template <typename Real, int RPL>
+__global__ __launch_bounds__(64) void k_iterate(Batch<Real> B, int n_iters, int mode) {
+  __shared__ WaveLds<Real, RPL> lds;
+  const int b = blockIdx.x;
+  Wave<Real, RPL> W(B, lds, b);
+  W.st = B.st[b];
+  if (W.st.done) return;
+  W.N = W.st.nseg;
+  W.init_tables();
+  if (mode == 0) W.iterate(n_iters);
+  else if (mode == 1) W.bwd_sweep();
+  else W.fwd_pass();
+  if (threadIdx.x == 0) B.st[b] = W.st;
+}
+
+template <typename Real, int RPL>
+__global__ __launch_bounds__(64) void k_finish(Batch<Real> B, OutPtrs<Real> O) {
+  __shared__ WaveLds<Real, RPL> lds;
+  const int b = blockIdx.x;
+  Wave<Real, RPL> W(B, lds, b);
+  W.st = B.st[b];
+  W.N = W.st.nseg;
+  finish_wave(W, O);
+}
+
+template <typename Real, int RPL>
+__global__ __launch_bounds__(64) void k_field(Batch<Real> B, int field, Real* buf, int set) {
+  __shared__ WaveLds<Real, RPL> lds;
+  const int b = blockIdx.x;
+  Wave<Real, RPL> W(B, lds, b);
+  W.st = B.st[b];
+  W.N = W.st.nseg;
+  W.init_tables();
+  if (set) set_field_wave(W, field, (const Real*)buf);
+  else get_field_wave(W, field, buf);
+}
+
+// UpdateTime + warm start between the two phases (teach_repeat_planner.cpp:911-918), on device
+template <typename Real>
+__global__ void k_chain(int B, int nmax, const int32_t* rtn0, const Real* T_phase0, const Real* T_in,
+                        const uint8_t* infeas0, Real* T_next, uint8_t* infeas_next) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nmax) return;
+  int b = i / nmax;
+  T_next[i] = (rtn0[b] == 2) ? T_phase0[i] : T_in[i];
+  if (i % nmax == 0) infeas_next[b] = infeas0[b];
+}
+
+// argmin of cost over problems with rtn >= 0 (config 5); one block
+template <typename Real>
+__global__ void k_best(const Real* cost, const int32_t* rtn, int n, int* best_idx, double* best_cost) {
+  __shared__ double sv[256];
+  __shared__ int si[256];
+  double v = INFINITY;
+  int idx = -1;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double c = (double)cost[i];
+    if (rtn[i] >= 0 && (c < v || (c == v && i < idx))) {
+      v = c;
+      idx = i;
+    }
+  }
+  sv[threadIdx.x] = v;
+  si[threadIdx.x] = idx;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      double v2 = sv[threadIdx.x + o];
+      int i2 = si[threadIdx.x + o];
+      bool take = i2 >= 0 && (si[threadIdx.x] < 0 || v2 < sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x]));
+      if (take) {
+        sv[threadIdx.x] = v2;
+        si[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *best_idx = si[0];
+    *best_cost = sv[0];
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static direct_status_t fail(direct_status_t st, const std::string& msg) {
+  g_err = msg;
+  return st;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(DIRECT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+struct direct_ddp_handle_s {
+  int dtype = 0, device = 0, max_batch = 0, nmax = 0, pmax = 0, ncs = 0, rpl = 2, fcap = 0;
+  size_t rsz = 4;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int n_launches = 0;
+  bool timed = false;
+  // device buffers
+  void *x0 = nullptr, *xd = nullptr, *T0 = nullptr, *planes = nullptr, *init_bez = nullptr, *T_next = nullptr;
+  int32_t *n_seg = nullptr, *n_planes = nullptr;
+  uint8_t *infeas_in = nullptr, *infeas_next = nullptr;
+  void *X[2] = {nullptr, nullptr}, *S[2] = {nullptr, nullptr}, *Y[2] = {nullptr, nullptr};
+  void *KU = nullptr, *KS = nullptr, *KY = nullptr;
+  double* filt = nullptr;
+  TrajState* st = nullptr;
+  void* fieldbuf = nullptr;
+  size_t fieldbuf_bytes = 0;
+  // staged outputs (when the caller's buffers are host memory)
+  struct {
+    int32_t *rtn, *iter_used, *fwd_passes;
+    uint8_t *infeas_out, *line_failed_out;
+    void *cost, *costq, *jerk_cost, *terminal_norm2, *opterr, *mu, *bez, *poly, *T;
+  } o = {};
+  int *best_idx = nullptr;
+  double* best_cost = nullptr;
+  // current batch
+  int B = 0;
+  bool begun = false;
+  direct_ddp_params_t params = {};
+  direct_ddp_batch_in_t cur_in = {};
+  std::vector<void*> allocs;
+};
+
+template <typename T>
+static direct_status_t dalloc(direct_ddp_handle_t h, T** p, size_t bytes) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+  if (e != hipSuccess) return fail(DIRECT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return DIRECT_OK;
+}
+#define TRY(expr)                            \
+  do {                                       \
+    direct_status_t s_ = (expr);             \
+    if (s_ != DIRECT_OK) return s_;          \
+  } while (0)
+
+template <typename Real>
+static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t& in, const direct_ddp_params_t& p) {
+  Batch<Real> B;
+  memset(&B, 0, sizeof(B));
+  B.B = in.batch; B.nmax = h->nmax; B.pmax = h->pmax; B.ncs = h->ncs; B.fcap = h->fcap;
+  B.n_seg = in.n_seg; B.x0 = (const Real*)in.x0; B.xd = (const Real*)in.xd; B.T0 = (const Real*)in.T0;
+  B.n_planes = in.n_planes; B.planes = (const Real*)in.planes; B.init_bez = (const Real*)in.init_bez;
+  B.infeas_in = in.infeas_in;
+  for (int i = 0; i < 2; i++) {
+    B.X[i] = (Real*)h->X[i]; B.S[i] = (Real*)h->S[i]; B.Y[i] = (Real*)h->Y[i];
+  }
+  B.KU = (Real*)h->KU; B.KS = (Real*)h->KS; B.KY = (Real*)h->KY; B.filt = h->filt; B.st = h->st;
+  SolveConst& k = B.k;
+  k.max_vel = p.max_vel; k.max_acc = p.max_acc; k.w_snap = p.w_snap; k.w_term = p.w_terminal;
+  k.w_time = p.w_time;
+  k.reg_base = p.zero_init ? 1.6 : 4.0;  // ddp_optimizer.cpp:60-61
+  k.shift = p.minvo ? 0.0 : 2.0e-4;      // ddp_optimizer.cpp:1281-1283
+  k.tol = 1.0e-7;                        // ddp_optimizer.cpp:43
+  k.iter_max = p.iter_max; k.time_power = p.time_power; k.zero_init = p.zero_init;
+  k.line_init = p.line_init; k.minvo = p.minvo; k.fixed_iters = p.fixed_iters; k.exact_dt = p.exact_dt;
+  return B;
+}
+
+#define RPL_LAUNCH(h, KERNEL, Real, grid, ...)                                                          \
+  do {                                                                                                   \
+    if ((h)->rpl <= 2) hipLaunchKernelGGL((KERNEL<Real, 2>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
+    else if ((h)->rpl == 3) hipLaunchKernelGGL((KERNEL<Real, 3>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<Real, 4>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__);       \
+  } while (0)
+
+template <typename Real>
+static void launch_begin_t(direct_ddp_handle_t h) {
+  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
+  RPL_LAUNCH(h, k_begin, Real, h->B, Bt);
+}
+template <typename Real>
+static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
+  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
+  RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n, mode);
+}
+template <typename Real>
+static void launch_field_t(direct_ddp_handle_t h, int field, int set) {
+  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
+  RPL_LAUNCH(h, k_field, Real, h->B, Bt, field, (Real*)h->fieldbuf, set);
+}
+template <typename Real>
+static OutPtrs<Real> out_ptrs(direct_ddp_handle_t h, const direct_ddp_batch_out_t* out) {
+  OutPtrs<Real> O;
+  const bool dev = out->mem == DIRECT_MEM_DEVICE;
+  // device memory: write straight into the caller's arrays; host memory: stage in the handle
+#define PICK(f) (dev ? out->f : (out->f ? h->o.f : nullptr))
+  O.rtn = PICK(rtn); O.iter_used = PICK(iter_used); O.fwd_passes = PICK(fwd_passes);
+  O.infeas_out = PICK(infeas_out); O.line_failed_out = PICK(line_failed_out);
+  O.cost = (Real*)PICK(cost); O.costq = (Real*)PICK(costq); O.jerk_cost = (Real*)PICK(jerk_cost);
+  O.terminal_norm2 = (Real*)PICK(terminal_norm2); O.opterr = (Real*)PICK(opterr); O.mu = (Real*)PICK(mu);
+  O.bez = (Real*)PICK(bez); O.poly = (Real*)PICK(poly); O.T = (Real*)PICK(T);
+#undef PICK
+  return O;
+}
+template <typename Real>
+static void launch_finish_t(direct_ddp_handle_t h, const direct_ddp_batch_out_t* out) {
+  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
+  auto O = out_ptrs<Real>(h, out);
+  RPL_LAUNCH(h, k_finish, Real, h->B, Bt, O);
+}
+
+extern "C" {
+
+int32_t direct_ddp_abi_version(void) { return DIRECT_DDP_ABI_VERSION; }
+const char* direct_ddp_last_error(void) { return g_err.c_str(); }
+
+direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_handle_t* out) {
+  if (!cfg || !out) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (cfg->dtype != DIRECT_F32 && cfg->dtype != DIRECT_F64) return fail(DIRECT_ERR_INVALID, "bad dtype");
+  if (cfg->max_batch <= 0 || cfg->n_seg_max <= 0 || cfg->p_max <= 0) return fail(DIRECT_ERR_INVALID, "bad sizes");
+  if (cfg->p_max > DIRECT_P_LIMIT) return fail(DIRECT_ERR_UNSUPPORTED, "p_max > DIRECT_P_LIMIT");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(DIRECT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(DIRECT_ERR_INVALID, "bad device ordinal");
+  HIP_TRY(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(DIRECT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  direct_ddp_handle_t h = new direct_ddp_handle_s();
+  h->dtype = cfg->dtype; h->device = cfg->device; h->max_batch = cfg->max_batch;
+  h->nmax = cfg->n_seg_max; h->pmax = cfg->p_max;
+  h->rsz = cfg->dtype == DIRECT_F64 ? 8 : 4;
+  const int ncm = 6 * cfg->p_max + 55;
+  h->ncs = (ncm + 3) / 4 * 4;
+  h->rpl = (ncm + 63) / 64;
+  h->fcap = 0;
+  const size_t B = cfg->max_batch, nm = cfg->n_seg_max, r = h->rsz;
+  direct_status_t st = DIRECT_OK;
+  auto A = [&](auto pp, size_t bytes) { if (st == DIRECT_OK) st = dalloc(h, pp, bytes); };
+  A(&h->x0, B * 9 * r); A(&h->xd, B * 9 * r); A(&h->T0, B * nm * r); A(&h->T_next, B * nm * r);
+  A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r);
+  A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B); A(&h->infeas_next, B);
+  for (int i = 0; i < 2; i++) {
+    A(&h->X[i], B * (nm + 1) * kXS * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
+  }
+  A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
+  A(&h->st, B * sizeof(TrajState));
+  A(&h->o.rtn, B * 4); A(&h->o.iter_used, B * 4); A(&h->o.fwd_passes, B * 4);
+  A(&h->o.infeas_out, B); A(&h->o.line_failed_out, B);
+  A(&h->o.cost, B * r); A(&h->o.costq, B * r); A(&h->o.jerk_cost, B * r); A(&h->o.terminal_norm2, B * r);
+  A(&h->o.opterr, B * r); A(&h->o.mu, B * r);
+  A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
+  A(&h->best_idx, 16); A(&h->best_cost, 16);
+  h->fieldbuf_bytes = B * nm * (size_t)std::max(ncm, 100) * r + B * 16 * r + B * 9 * r;
+  A(&h->fieldbuf, h->fieldbuf_bytes);
+  if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
+    st = fail(DIRECT_ERR_DEVICE, "hipEventCreate failed");
+  if (st != DIRECT_OK) {
+    direct_ddp_destroy(h);
+    return st;
+  }
+  *out = h;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_ddp_destroy(direct_ddp_handle_t h) {
+  if (!h) return DIRECT_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->filt) (void)hipFree(h->filt);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_ddp_set_stream(direct_ddp_handle_t h, void* hip_stream) {
+  if (!h) return fail(DIRECT_ERR_INVALID, "null handle");
+  h->stream = (hipStream_t)hip_stream;
+  return DIRECT_OK;
+}
+
+static direct_status_t check_params(const direct_ddp_params_t* p) {
+  if (!p) return fail(DIRECT_ERR_INVALID, "null params");
+  if (p->time_power != 1 && p->time_power != 2)
+    return fail(DIRECT_ERR_INVALID, "time_power must be 1 or 2 (computeq has no other branch, ddp_optimizer.cpp:1294-1305)");
+  if (p->iter_max < 0) return fail(DIRECT_ERR_INVALID, "iter_max < 0");
+  if (p->line_init) return fail(DIRECT_ERR_UNSUPPORTED, "line_init_flag is not implemented on the device path yet");
+  return DIRECT_OK;
+}
+
+// copy (or alias) the inputs into device memory and fill h->cur_in with device pointers
+static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in) {
+  if (!h || !in) return fail(DIRECT_ERR_INVALID, "null argument");
+  TRY(check_params(p));
+  if (in->batch <= 0 || in->batch > h->max_batch) return fail(DIRECT_ERR_INVALID, "batch exceeds the handle's max_batch");
+  if (in->n_seg_max != h->nmax || in->p_max != h->pmax)
+    return fail(DIRECT_ERR_INVALID, "n_seg_max / p_max differ from the handle's configuration");
+  if (!in->n_seg || !in->x0 || !in->xd || !in->T0 || !in->n_planes || !in->planes)
+    return fail(DIRECT_ERR_INVALID, "null input array");
+  if (!p->zero_init && !in->init_bez) return fail(DIRECT_ERR_INVALID, "init_bez required unless zero_init");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t B = in->batch, nm = h->nmax, r = h->rsz;
+  direct_ddp_batch_in_t d = *in;
+  if (in->mem == DIRECT_MEM_HOST) {
+    // validate sizes on the host before anything reaches the device
+    for (size_t b = 0; b < B; b++) {
+      if (in->n_seg[b] < 1 || in->n_seg[b] > (int)nm) return fail(DIRECT_ERR_INVALID, "n_seg out of range");
+      for (int k = 0; k < in->n_seg[b]; k++) {
+        int np = in->n_planes[b * nm + k];
+        if (np < 1 || np > h->pmax) return fail(DIRECT_ERR_INVALID, "n_planes out of range");
+      }
+    }
+    auto up = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream); };
+    HIP_TRY(up(h->n_seg, in->n_seg, B * 4)); d.n_seg = h->n_seg;
+    HIP_TRY(up(h->x0, in->x0, B * 9 * r)); d.x0 = h->x0;
+    HIP_TRY(up(h->xd, in->xd, B * 9 * r)); d.xd = h->xd;
+    HIP_TRY(up(h->T0, in->T0, B * nm * r)); d.T0 = h->T0;
+    HIP_TRY(up(h->n_planes, in->n_planes, B * nm * 4)); d.n_planes = h->n_planes;
+    HIP_TRY(up(h->planes, in->planes, B * nm * h->pmax * 4 * r)); d.planes = h->planes;
+    if (in->init_bez) { HIP_TRY(up(h->init_bez, in->init_bez, B * nm * 18 * r)); d.init_bez = h->init_bez; }
+    if (in->infeas_in) { HIP_TRY(up(h->infeas_in, in->infeas_in, B)); d.infeas_in = h->infeas_in; }
+  }
+  if (!in->infeas_in) {
+    HIP_TRY(hipMemsetAsync(h->infeas_in, p->infeas ? 1 : 0, B, h->stream));
+    d.infeas_in = h->infeas_in;
+  }
+  d.mem = DIRECT_MEM_DEVICE;
+  h->cur_in = d;
+  h->params = *p;
+  h->B = in->batch;
+  // filter capacity follows iter_max
+  if (p->iter_max + 4 > h->fcap) {
+    if (h->filt) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->filt)); h->filt = nullptr; }
+    h->fcap = p->iter_max + 4;
+    HIP_TRY(hipMalloc((void**)&h->filt, (size_t)h->max_batch * h->fcap * 2 * sizeof(double)));
+  }
+  return DIRECT_OK;
+}
+
+static direct_status_t launch_begin(direct_ddp_handle_t h) {
+  if (h->dtype == DIRECT_F64) launch_begin_t<double>(h);
+  else launch_begin_t<float>(h);
+  HIP_TRY(hipGetLastError());
+  h->begun = true;
+  return DIRECT_OK;
+}
+
+static direct_status_t launch_iterate(direct_ddp_handle_t h, int n, int mode) {
+  if (!h->begun) return fail(DIRECT_ERR_INVALID, "direct_ddp_begin has not been called");
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  if (h->dtype == DIRECT_F64) launch_iterate_t<double>(h, n, mode);
+  else launch_iterate_t<float>(h, n, mode);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  h->n_launches = 1;
+  h->timed = true;
+  return DIRECT_OK;
+}
+
+static direct_status_t launch_finish(direct_ddp_handle_t h, direct_ddp_batch_out_t* out) {
+  if (!h->begun) return fail(DIRECT_ERR_INVALID, "direct_ddp_begin has not been called");
+  if (!out) return fail(DIRECT_ERR_INVALID, "null out");
+  if (h->dtype == DIRECT_F64) launch_finish_t<double>(h, out);
+  else launch_finish_t<float>(h, out);
+  HIP_TRY(hipGetLastError());
+  if (out->mem == DIRECT_MEM_HOST) {
+    const size_t B = h->B, nm = h->nmax, r = h->rsz;
+    auto dn = [&](void* dst, const void* src, size_t bytes) {
+      return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+    };
+    HIP_TRY(dn(out->rtn, h->o.rtn, B * 4)); HIP_TRY(dn(out->iter_used, h->o.iter_used, B * 4));
+    HIP_TRY(dn(out->fwd_passes, h->o.fwd_passes, B * 4));
+    HIP_TRY(dn(out->infeas_out, h->o.infeas_out, B)); HIP_TRY(dn(out->line_failed_out, h->o.line_failed_out, B));
+    HIP_TRY(dn(out->cost, h->o.cost, B * r)); HIP_TRY(dn(out->costq, h->o.costq, B * r));
+    HIP_TRY(dn(out->jerk_cost, h->o.jerk_cost, B * r)); HIP_TRY(dn(out->terminal_norm2, h->o.terminal_norm2, B * r));
+    HIP_TRY(dn(out->opterr, h->o.opterr, B * r)); HIP_TRY(dn(out->mu, h->o.mu, B * r));
+    HIP_TRY(dn(out->bez, h->o.bez, B * nm * 18 * r)); HIP_TRY(dn(out->poly, h->o.poly, B * nm * 18 * r));
+    HIP_TRY(dn(out->T, h->o.T, B * nm * r));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return DIRECT_OK;
+}
+
+direct_status_t direct_ddp_begin(direct_ddp_handle_t h, const direct_ddp_params_t* params, const direct_ddp_batch_in_t* in) {
+  TRY(stage_inputs(h, params, in));
+  return launch_begin(h);
+}
+direct_status_t direct_ddp_backward_pass(direct_ddp_handle_t h) {
+  if (!h) return fail(DIRECT_ERR_INVALID, "null handle");
+  return launch_iterate(h, 1, 1);
+}
+direct_status_t direct_ddp_forward_pass(direct_ddp_handle_t h) {
+  if (!h) return fail(DIRECT_ERR_INVALID, "null handle");
+  return launch_iterate(h, 1, 2);
+}
+direct_status_t direct_ddp_iterate(direct_ddp_handle_t h, int32_t n_iters) {
+  if (!h) return fail(DIRECT_ERR_INVALID, "null handle");
+  return launch_iterate(h, n_iters, 0);
+}
+direct_status_t direct_ddp_finish(direct_ddp_handle_t h, direct_ddp_batch_out_t* out) {
+  if (!h) return fail(DIRECT_ERR_INVALID, "null handle");
+  return launch_finish(h, out);
+}
+
+direct_status_t direct_ddp_solve_batch(direct_ddp_handle_t h, const direct_ddp_params_t* params,
+                                       const direct_ddp_batch_in_t* in, direct_ddp_batch_out_t* out) {
+  if (!out) return fail(DIRECT_ERR_INVALID, "null out");
+  TRY(stage_inputs(h, params, in));
+  TRY(launch_begin(h));
+  TRY(launch_iterate(h, params->iter_max, 0));
+  return launch_finish(h, out);
+}
+
+direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_params_t* p0, const direct_ddp_params_t* p1,
+                                      const direct_ddp_batch_in_t* in, direct_ddp_batch_out_t* out0,
+                                      direct_ddp_batch_out_t* out1) {
+  if (!h || !out1) return fail(DIRECT_ERR_INVALID, "null argument");
+  TRY(check_params(p1));
+  // phase 0 (teach_repeat_planner.cpp:886-897): infeas = true for every problem
+  direct_ddp_batch_in_t in0 = *in;
+  in0.infeas_in = nullptr;
+  direct_ddp_params_t q0 = *p0;
+  q0.infeas = 1;
+  TRY(stage_inputs(h, &q0, &in0));
+  TRY(launch_begin(h));
+  TRY(launch_iterate(h, q0.iter_max, 0));
+  // results of phase 0 stay on the device (staging buffers of the handle)
+  direct_ddp_batch_out_t stage = {};
+  stage.mem = DIRECT_MEM_DEVICE;
+  stage.rtn = h->o.rtn; stage.iter_used = h->o.iter_used; stage.fwd_passes = h->o.fwd_passes;
+  stage.infeas_out = h->o.infeas_out; stage.line_failed_out = h->o.line_failed_out;
+  stage.cost = h->o.cost; stage.costq = h->o.costq; stage.jerk_cost = h->o.jerk_cost;
+  stage.terminal_norm2 = h->o.terminal_norm2; stage.opterr = h->o.opterr; stage.mu = h->o.mu;
+  stage.bez = h->o.bez; stage.poly = h->o.poly; stage.T = h->o.T;
+  TRY(launch_finish(h, &stage));
+  if (out0) {  // hand phase-0 results to the caller as well
+    const size_t B = h->B, nm = h->nmax, r = h->rsz;
+    hipMemcpyKind kind = out0->mem == DIRECT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    auto cp = [&](void* dst, const void* src, size_t bytes) { return dst ? hipMemcpyAsync(dst, src, bytes, kind, h->stream) : hipSuccess; };
+    HIP_TRY(cp(out0->rtn, h->o.rtn, B * 4)); HIP_TRY(cp(out0->iter_used, h->o.iter_used, B * 4));
+    HIP_TRY(cp(out0->fwd_passes, h->o.fwd_passes, B * 4)); HIP_TRY(cp(out0->infeas_out, h->o.infeas_out, B));
+    HIP_TRY(cp(out0->line_failed_out, h->o.line_failed_out, B));
+    HIP_TRY(cp(out0->cost, h->o.cost, B * r)); HIP_TRY(cp(out0->costq, h->o.costq, B * r));
+    HIP_TRY(cp(out0->jerk_cost, h->o.jerk_cost, B * r)); HIP_TRY(cp(out0->terminal_norm2, h->o.terminal_norm2, B * r));
+    HIP_TRY(cp(out0->opterr, h->o.opterr, B * r)); HIP_TRY(cp(out0->mu, h->o.mu, B * r));
+    HIP_TRY(cp(out0->bez, h->o.bez, B * nm * 18 * r)); HIP_TRY(cp(out0->poly, h->o.poly, B * nm * 18 * r));
+    HIP_TRY(cp(out0->T, h->o.T, B * nm * r));
+  }
+  // UpdateTime where rtn0 == 2, warm start from the phase-0 Bezier coefficients (TRP:911-918)
+  const int n = h->B * h->nmax;
+  if (h->dtype == DIRECT_F64)
+    hipLaunchKernelGGL(k_chain<double>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->B, h->nmax, h->o.rtn,
+                       (const double*)h->o.T, (const double*)h->cur_in.T0, h->o.infeas_out, (double*)h->T_next, h->infeas_next);
+  else
+    hipLaunchKernelGGL(k_chain<float>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->B, h->nmax, h->o.rtn,
+                       (const float*)h->o.T, (const float*)h->cur_in.T0, h->o.infeas_out, (float*)h->T_next, h->infeas_next);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->init_bez, h->o.bez, (size_t)h->B * h->nmax * 18 * h->rsz, hipMemcpyDeviceToDevice, h->stream));
+  direct_ddp_batch_in_t in1 = h->cur_in;  // device pointers
+  in1.T0 = h->T_next;
+  in1.init_bez = h->init_bez;
+  in1.infeas_in = h->infeas_next;
+  TRY(stage_inputs(h, p1, &in1));
+  TRY(launch_begin(h));
+  TRY(launch_iterate(h, p1->iter_max, 0));
+  return launch_finish(h, out1);
+}
+
+static size_t field_elems(direct_ddp_handle_t h, int field) {
+  const size_t B = h->B, nm = h->nmax, ncm = 6 * h->pmax + 55;
+  switch (field) {
+    case DIRECT_FIELD_X: return B * (nm + 1) * 9;
+    case DIRECT_FIELD_U: case DIRECT_FIELD_KU: return B * nm * 10;
+    case DIRECT_FIELD_KUU: return B * nm * 90;
+    case DIRECT_FIELD_S: case DIRECT_FIELD_Y: case DIRECT_FIELD_C: case DIRECT_FIELD_KS: case DIRECT_FIELD_KY: return B * nm * ncm;
+    case DIRECT_FIELD_SCALARS: return B * 16;
+    default: return 0;
+  }
+}
+
+direct_status_t direct_ddp_get_field(direct_ddp_handle_t h, int32_t field, void* dst) {
+  if (!h || !dst) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->begun) return fail(DIRECT_ERR_INVALID, "direct_ddp_begin has not been called");
+  size_t n = field_elems(h, field);
+  if (!n) return fail(DIRECT_ERR_INVALID, "unknown field");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemsetAsync(h->fieldbuf, 0, n * h->rsz, h->stream));
+  if (h->dtype == DIRECT_F64) launch_field_t<double>(h, field, 0);
+  else launch_field_t<float>(h, field, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dst, h->fieldbuf, n * h->rsz, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DIRECT_OK;
+}
+
+direct_status_t direct_ddp_set_field(direct_ddp_handle_t h, int32_t field, const void* src) {
+  if (!h || !src) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->begun) return fail(DIRECT_ERR_INVALID, "direct_ddp_begin has not been called");
+  if (field != DIRECT_FIELD_X && field != DIRECT_FIELD_U && field != DIRECT_FIELD_S && field != DIRECT_FIELD_Y)
+    return fail(DIRECT_ERR_INVALID, "only X, U, S, Y can be set");
+  size_t n = field_elems(h, field);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(h->fieldbuf, src, n * h->rsz, hipMemcpyHostToDevice, h->stream));
+  if (h->dtype == DIRECT_F64) launch_field_t<double>(h, field, 1);
+  else launch_field_t<float>(h, field, 1);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DIRECT_OK;
+}
+
+direct_status_t direct_ddp_last_kernel_ms(direct_ddp_handle_t h, double* ms, int32_t* n_launches) {
+  if (!h || !ms) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->timed) return fail(DIRECT_ERR_INVALID, "nothing has been timed yet");
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, h->ev0, h->ev1));
+  *ms = (double)t;
+  if (n_launches) *n_launches = h->n_launches;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_ddp_best_cost(direct_ddp_handle_t h, int32_t mem, const void* cost, const int32_t* rtn,
+                                     int32_t batch, int32_t* best_index, double* best_cost) {
+  if (!h || !cost || !rtn || !best_index || !best_cost || batch <= 0 || batch > h->max_batch)
+    return fail(DIRECT_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const void* dc = cost;
+  const int32_t* dr = rtn;
+  if (mem == DIRECT_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(h->o.cost, cost, (size_t)batch * h->rsz, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->o.rtn, rtn, (size_t)batch * 4, hipMemcpyHostToDevice, h->stream));
+    dc = h->o.cost;
+    dr = h->o.rtn;
+  }
+  if (h->dtype == DIRECT_F64)
+    hipLaunchKernelGGL(k_best<double>, dim3(1), dim3(256), 0, h->stream, (const double*)dc, dr, batch, h->best_idx, h->best_cost);
+  else
+    hipLaunchKernelGGL(k_best<float>, dim3(1), dim3(256), 0, h->stream, (const float*)dc, dr, batch, h->best_idx, h->best_cost);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(best_index, h->best_idx, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(best_cost, h->best_cost, 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DIRECT_OK;
+}
+
+// initTimeAllocation (teach_repeat_planner.cpp:583-639) with v0 = 0: host-side, double precision.
+direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const int32_t* n_seg, const double* start,
+                                       const double* goal, const double* seeds, double max_vel, double max_acc,
+                                       double* T_out) {
+  if (batch <= 0 || n_seg_max <= 0 || !n_seg || !start || !goal || !seeds || !T_out || max_vel <= 0 || max_acc <= 0)
+    return fail(DIRECT_ERR_INVALID, "bad argument");
+  const double acct = max_vel / max_acc, accd = max_acc * acct * acct / 2.0;
+  const double dcct = max_vel / max_acc, dccd = max_acc * dcct * dcct / 2.0;
+  for (int b = 0; b < batch; b++) {
+    const int N = n_seg[b];
+    if (N < 1 || N > n_seg_max) return fail(DIRECT_ERR_INVALID, "n_seg out of range");
+    for (int k = 0; k < n_seg_max; k++) {
+      double t = 0.0;
+      if (k < N) {
+        const double* p0 = (k == 0) ? start + (size_t)b * 3 : seeds + ((size_t)b * n_seg_max + k) * 3;
+        const double* p1 = (k == N - 1) ? goal + (size_t)b * 3 : seeds + ((size_t)b * n_seg_max + k + 1) * 3;
+        const double dx = p1[0] - p0[0], dy = p1[1] - p0[1], dz = p1[2] - p0[2];
+        const double D = sqrt(dx * dx + dy * dy + dz * dz);
+        if (D < accd + dccd) t = 2.0 * sqrt(max_acc * D) / max_acc;   // triangle profile: t2 + t3
+        else t = acct + (D - accd - dccd) / max_vel + dcct;          // trapezoid profile
+      }
+      T_out[(size_t)b * n_seg_max + k] = t;
+    }
+  }
+  return DIRECT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""Python binding of libdirect_ddp.so (the C-ABI of include/direct_ddp.h) for tests and bench.py.
+
+The product is the shared library; this module only loads it with ctypes and mirrors the calling
+protocol of the reference: `DdpSolver.solve` = ddpTrajOptimizer::polyCurveGeneration + getters
+(global_planner/include/global_planner/ddp_optimizer.h:267-340), `DdpSolver.plan` =
+fastTrajPlanning's two-phase chaining (global_planner/src/teach_repeat_planner.cpp:886-921).
+There is no CPU fallback: loading fails loudly when the library is missing and creating a solver
+fails when no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdirect_ddp.so")
+_LIB = None
+
+EXPORTS = (
+    "direct_ddp_abi_version", "direct_ddp_last_error", "direct_ddp_create", "direct_ddp_destroy",
+    "direct_ddp_set_stream", "direct_ddp_solve_batch", "direct_ddp_plan_batch", "direct_time_allocation",
+    "direct_ddp_begin", "direct_ddp_backward_pass", "direct_ddp_forward_pass", "direct_ddp_iterate",
+    "direct_ddp_finish", "direct_ddp_get_field", "direct_ddp_set_field", "direct_ddp_last_kernel_ms",
+    "direct_ddp_best_cost",
+)
+
+
+class DirectError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("direct_ddp status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib():
+    """Load libdirect_ddp.so (built by __graft_entry__.build()).  Raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.direct_ddp_abi_version.restype = C.c_int32
+        L.direct_ddp_last_error.restype = C.c_char_p
+        L.direct_ddp_create.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_ddp_destroy.argtypes = [C.c_void_p]
+        L.direct_ddp_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_ddp_solve_batch.argtypes = [C.c_void_p] * 4
+        L.direct_ddp_plan_batch.argtypes = [C.c_void_p] * 6
+        L.direct_ddp_begin.argtypes = [C.c_void_p] * 3
+        L.direct_ddp_backward_pass.argtypes = [C.c_void_p]
+        L.direct_ddp_forward_pass.argtypes = [C.c_void_p]
+        L.direct_ddp_iterate.argtypes = [C.c_void_p, C.c_int32]
+        L.direct_ddp_finish.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_ddp_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.direct_ddp_set_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.direct_ddp_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.direct_ddp_best_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_void_p]
+        L.direct_time_allocation.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _check(st):
+    if st != abi.DIRECT_OK:
+        raise DirectError(st, lib().direct_ddp_last_error().decode())
+
+
+def time_allocation(n_seg, start, goal, seeds, max_vel=2.0, max_acc=2.0):
+    """initTimeAllocation (teach_repeat_planner.cpp:583-639) through the C-ABI."""
+    n_seg = np.ascontiguousarray(n_seg, np.int32)
+    seeds = np.ascontiguousarray(seeds, np.float64)
+    start = np.ascontiguousarray(start, np.float64)
+    goal = np.ascontiguousarray(goal, np.float64)
+    T = np.zeros(seeds.shape[:2])
+    _check(lib().direct_time_allocation(n_seg.shape[0], seeds.shape[1], n_seg.ctypes.data, start.ctypes.data,
+                                        goal.ctypes.data, seeds.ctypes.data, max_vel, max_acc, T.ctypes.data))
+    return T
+
+
+class DdpSolver:
+    """One handle = one GPU; reusable across calls (the reference object is single-use, quirk Q9)."""
+
+    def __init__(self, max_batch, n_seg_max, p_max, dtype=np.float32, device=0):
+        self.np_dtype = np.dtype(dtype)
+        self.dtype = abi.F64 if self.np_dtype == np.float64 else abi.F32
+        self.max_batch, self.n_seg_max, self.p_max = int(max_batch), int(n_seg_max), int(p_max)
+        cfg = abi.Config(self.dtype, device, self.max_batch, self.n_seg_max, self.p_max, 0)
+        h = C.c_void_p()
+        _check(lib().direct_ddp_create(C.addressof(cfg), C.addressof(h)))
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().direct_ddp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(lib().direct_ddp_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def _host_batch(self, batch):
+        return batch if batch.dtype == self.np_dtype else batch.astype(self.np_dtype)
+
+    # -- host-memory interface ------------------------------------------------------------------
+    def solve(self, params, batch):
+        """polyCurveGeneration for every corridor of `batch` (abi.HostBatch) -> abi.HostResult."""
+        hb = self._host_batch(batch)
+        res = abi.HostResult(hb.batch, hb.n_seg_max, self.np_dtype)
+        cin, cout = hb.c_struct(), res.c_struct()
+        _check(lib().direct_ddp_solve_batch(self.h, C.addressof(params), C.addressof(cin), C.addressof(cout)))
+        return res
+
+    def plan(self, params0, params1, batch):
+        """Phase 0 -> UpdateTime -> phase 1 (teach_repeat_planner.cpp:886-921) -> (res0, res1)."""
+        hb = self._host_batch(batch)
+        r0 = abi.HostResult(hb.batch, hb.n_seg_max, self.np_dtype)
+        r1 = abi.HostResult(hb.batch, hb.n_seg_max, self.np_dtype)
+        cin, c0, c1 = hb.c_struct(), r0.c_struct(), r1.c_struct()
+        _check(lib().direct_ddp_plan_batch(self.h, C.addressof(params0), C.addressof(params1), C.addressof(cin),
+                                           C.addressof(c0), C.addressof(c1)))
+        return r0, r1
+
+    # -- stepwise interface (per-pass parity) -----------------------------------------------------
+    def begin(self, params, batch):
+        hb = self._host_batch(batch)
+        cin = hb.c_struct()
+        self._keep = (hb, cin, params)
+        self._shape_src = hb
+        _check(lib().direct_ddp_begin(self.h, C.addressof(params), C.addressof(cin)))
+
+    def backward(self):
+        _check(lib().direct_ddp_backward_pass(self.h))
+
+    def forward(self):
+        _check(lib().direct_ddp_forward_pass(self.h))
+
+    def iterate(self, n):
+        _check(lib().direct_ddp_iterate(self.h, int(n)))
+
+    def finish(self):
+        hb = self._shape_src
+        res = abi.HostResult(hb.batch, hb.n_seg_max, self.np_dtype)
+        cout = res.c_struct()
+        _check(lib().direct_ddp_finish(self.h, C.addressof(cout)))
+        return res
+
+    def field_shape(self, field):
+        b = self._shape_src
+        B, nm, ncm = b.batch, b.n_seg_max, b.nc_max
+        return {abi.FIELD_X: (B, nm + 1, 9), abi.FIELD_U: (B, nm, 10), abi.FIELD_S: (B, nm, ncm),
+                abi.FIELD_Y: (B, nm, ncm), abi.FIELD_C: (B, nm, ncm), abi.FIELD_KU: (B, nm, 10),
+                abi.FIELD_KUU: (B, nm, 10, 9), abi.FIELD_KS: (B, nm, ncm), abi.FIELD_KY: (B, nm, ncm),
+                abi.FIELD_SCALARS: (B, 16)}[field]
+
+    def get(self, field):
+        out = np.zeros(self.field_shape(field), self.np_dtype)
+        _check(lib().direct_ddp_get_field(self.h, field, out.ctypes.data))
+        return out
+
+    def set(self, field, arr):
+        a = np.ascontiguousarray(arr, self.np_dtype)
+        assert a.shape == self.field_shape(field)
+        _check(lib().direct_ddp_set_field(self.h, field, a.ctypes.data))
+
+    def scalars(self):
+        s = self.get(abi.FIELD_SCALARS)
+        return {n: s[:, i] for i, n in enumerate(abi.SCALAR_NAMES)}
+
+    def last_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int32()
+        _check(lib().direct_ddp_last_kernel_ms(self.h, C.addressof(ms), C.addressof(n)))
+        return ms.value, n.value
+
+    # -- device-memory interface (pointers are raw device addresses, e.g. torch .data_ptr()) ------
+    def solve_device(self, params, cin, cout):
+        """cin: abi.BatchIn, cout: abi.BatchOut, both with mem = MEM_DEVICE.  Asynchronous."""
+        _check(lib().direct_ddp_solve_batch(self.h, C.addressof(params), C.addressof(cin), C.addressof(cout)))
+
+    def plan_device(self, params0, params1, cin, cout0, cout1):
+        _check(lib().direct_ddp_plan_batch(self.h, C.addressof(params0), C.addressof(params1), C.addressof(cin),
+                                           None if cout0 is None else C.addressof(cout0), C.addressof(cout1)))
+
+    def best_cost(self, cost, rtn, mem=abi.MEM_HOST, batch=None):
+        """(index, cost) of the cheapest trajectory with rtn >= 0.  cost/rtn: numpy arrays or raw pointers."""
+        idx, val = C.c_int32(), C.c_double()
+        if mem == abi.MEM_HOST:
+            cost = np.ascontiguousarray(cost, self.np_dtype)
+            rtn = np.ascontiguousarray(rtn, np.int32)
+            batch = cost.shape[0]
+            pc, pr = cost.ctypes.data, rtn.ctypes.data
+        else:
+            pc, pr = cost, rtn
+        _check(lib().direct_ddp_best_cost(self.h, mem, C.c_void_p(pc), C.c_void_p(pr), int(batch),
+                                          C.addressof(idx), C.addressof(val)))
+        return idx.value, val.value

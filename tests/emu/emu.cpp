@@ -1,0 +1,145 @@
+// TEST-ONLY harness: compiles direct_amd/csrc/ddp_wave.h with DIRECT_EMULATE, i.e. every LANES
+// block becomes a 64-iteration loop, so the restructured (Kronecker / column-per-lane) algorithm
+// of the HIP kernels can be checked against the oracle on a machine without a GPU.  This is NOT a
+// CPU fallback: nothing under direct_amd/ builds, loads or calls it; the product library
+// (libdirect_ddp.so) contains only gfx950 code and fails with DIRECT_ERR_NO_DEVICE without a GPU.
+#define DIRECT_EMULATE 1
+#include "../../direct_amd/csrc/ddp_wave.h"
+#include "../../include/direct_ddp.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace direct;
+
+template <typename Real>
+struct Emu {
+  Batch<Real> B;
+  std::vector<Real> x0, xd, T0, planes, init_bez, X0, X1, S0, S1, Y0, Y1, KU, KS, KY;
+  std::vector<int32_t> n_seg, n_planes;
+  std::vector<uint8_t> infeas_in;
+  std::vector<double> filt;
+  std::vector<TrajState> st;
+  int rpl;
+};
+
+template <typename Real, int RPL, typename F>
+static void for_each_wave(Emu<Real>& E, F f) {
+  static WaveLds<Real, RPL> lds;
+  for (int b = 0; b < E.B.B; b++) {
+    Wave<Real, RPL> W(E.B, lds, b);
+    f(W);
+  }
+}
+
+template <typename Real, typename F>
+static void dispatch(Emu<Real>& E, F f) {
+  if (E.rpl <= 2) for_each_wave<Real, 2>(E, f);
+  else if (E.rpl == 3) for_each_wave<Real, 3>(E, f);
+  else for_each_wave<Real, 4>(E, f);
+}
+
+template <typename Real>
+static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in) {
+  Emu<Real>* E = new Emu<Real>();
+  int B = in->batch, nm = in->n_seg_max, pm = in->p_max;
+  int ncm = 6 * pm + 55;
+  E->rpl = (ncm + 63) / 64;
+  Batch<Real>& Bt = E->B;
+  memset(&Bt, 0, sizeof(Bt));
+  Bt.B = B; Bt.nmax = nm; Bt.pmax = pm; Bt.ncs = ncm; Bt.fcap = p->iter_max + 4;
+  auto cp = [](std::vector<Real>& v, const void* src, size_t n) {
+    v.assign((const Real*)src, (const Real*)src + n);
+  };
+  E->n_seg.assign(in->n_seg, in->n_seg + B);
+  E->n_planes.assign(in->n_planes, in->n_planes + (size_t)B * nm);
+  cp(E->x0, in->x0, (size_t)B * 9);
+  cp(E->xd, in->xd, (size_t)B * 9);
+  cp(E->T0, in->T0, (size_t)B * nm);
+  cp(E->planes, in->planes, (size_t)B * nm * pm * 4);
+  if (in->init_bez) cp(E->init_bez, in->init_bez, (size_t)B * nm * 18);
+  E->infeas_in.assign(B, (uint8_t)p->infeas);
+  if (in->infeas_in) E->infeas_in.assign(in->infeas_in, in->infeas_in + B);
+  size_t nx = (size_t)B * (nm + 1) * kXS, ns = (size_t)B * nm * ncm;
+  E->X0.assign(nx, 0); E->X1.assign(nx, 0);
+  E->S0.assign(ns, 0); E->S1.assign(ns, 0); E->Y0.assign(ns, 0); E->Y1.assign(ns, 0);
+  E->KU.assign((size_t)B * nm * 100, 0); E->KS.assign(ns, 0); E->KY.assign(ns, 0);
+  E->filt.assign((size_t)B * Bt.fcap * 2, 0.0);
+  E->st.assign(B, TrajState());
+  Bt.n_seg = E->n_seg.data(); Bt.x0 = E->x0.data(); Bt.xd = E->xd.data(); Bt.T0 = E->T0.data();
+  Bt.n_planes = E->n_planes.data(); Bt.planes = E->planes.data();
+  Bt.init_bez = in->init_bez ? E->init_bez.data() : nullptr;
+  Bt.infeas_in = E->infeas_in.data();
+  Bt.X[0] = E->X0.data(); Bt.X[1] = E->X1.data(); Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data();
+  Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
+  Bt.KY = E->KY.data(); Bt.filt = E->filt.data(); Bt.st = E->st.data();
+  SolveConst& k = Bt.k;
+  k.max_vel = p->max_vel; k.max_acc = p->max_acc; k.w_snap = p->w_snap; k.w_term = p->w_terminal;
+  k.w_time = p->w_time; k.reg_base = p->zero_init ? 1.6 : 4.0; k.shift = p->minvo ? 0.0 : 2.0e-4;
+  k.tol = 1.0e-7; k.iter_max = p->iter_max; k.time_power = p->time_power; k.zero_init = p->zero_init;
+  k.line_init = p->line_init; k.minvo = p->minvo; k.fixed_iters = p->fixed_iters; k.exact_dt = p->exact_dt;
+  dispatch(*E, [&](auto& W) {
+    W.init_tables();
+    memset(&W.st, 0, sizeof(W.st));
+    W.begin();
+    W.B.st[W.b] = W.st;
+  });
+  return E;
+}
+
+template <typename Real, typename F>
+static void with_state(Emu<Real>& E, F f) {
+  dispatch(E, [&](auto& W) {
+    W.init_tables();
+    W.st = W.B.st[W.b];
+    W.N = W.st.nseg;
+    f(W);
+    W.B.st[W.b] = W.st;
+  });
+}
+
+struct EmuHandle {
+  int dtype;
+  void* p;
+};
+
+extern "C" {
+void* emu_begin(int dtype, const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in) {
+  EmuHandle* h = new EmuHandle();
+  h->dtype = dtype;
+  h->p = dtype == DIRECT_F64 ? (void*)emu_begin_t<double>(p, in) : (void*)emu_begin_t<float>(p, in);
+  return h;
+}
+#define EMU_CALL(body)                                            \
+  EmuHandle* h = (EmuHandle*)hv;                                  \
+  if (h->dtype == DIRECT_F64) { auto& E = *(Emu<double>*)h->p; typedef double Real; (void)sizeof(Real); body; } \
+  else { auto& E = *(Emu<float>*)h->p; typedef float Real; (void)sizeof(Real); body; }
+
+void emu_backward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.bwd_sweep(); })) }
+void emu_forward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.fwd_pass(); })) }
+void emu_iterate(void* hv, int n) { EMU_CALL(with_state(E, [n](auto& W) { W.iterate(n); })) }
+void emu_get_field(void* hv, int field, void* dst) {
+  EMU_CALL(with_state(E, [&](auto& W) { get_field_wave(W, field, (Real*)dst); }))
+}
+void emu_set_field(void* hv, int field, const void* src) {
+  EMU_CALL(with_state(E, [&](auto& W) { set_field_wave(W, field, (const Real*)src); }))
+}
+void emu_finish(void* hv, direct_ddp_batch_out_t* out) {
+  EMU_CALL({
+    OutPtrs<Real> O;
+    O.rtn = out->rtn; O.iter_used = out->iter_used; O.fwd_passes = out->fwd_passes;
+    O.infeas_out = out->infeas_out; O.line_failed_out = out->line_failed_out;
+    O.cost = (Real*)out->cost; O.costq = (Real*)out->costq; O.jerk_cost = (Real*)out->jerk_cost;
+    O.terminal_norm2 = (Real*)out->terminal_norm2; O.opterr = (Real*)out->opterr; O.mu = (Real*)out->mu;
+    O.bez = (Real*)out->bez; O.poly = (Real*)out->poly; O.T = (Real*)out->T;
+    with_state(E, [&](auto& W) { finish_wave(W, O); });
+  })
+}
+void emu_end(void* hv) {
+  EmuHandle* h = (EmuHandle*)hv;
+  if (h->dtype == DIRECT_F64) delete (Emu<double>*)h->p;
+  else delete (Emu<float>*)h->p;
+  delete h;
+}
+}
