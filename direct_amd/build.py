@@ -1,0 +1,34 @@
+"""Builds libdirect_ddp.so (gfx950 only) in-tree with hipcc.  No torch dependency."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "direct_ddp.hip")
+DEPS = [SRC, os.path.join(_HERE, "csrc", "ddp_wave.h"), os.path.join(_HERE, "csrc", "ddp_tables.h"),
+        os.path.join(_HERE, "..", "include", "direct_ddp.h")]
+OUT = os.path.join(_HERE, "lib", "libdirect_ddp.so")
+
+# occupancy targets of the hot kernel (waves per SIMD): see DESIGN.md "Occupancy"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-DDDP_WAVES_F32=4", "-DDDP_WAVES_F64=2"]
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force=False, extra_flags=()):
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + [SRC, "-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -35,7 +35,10 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #else
 #include <hip/hip_runtime.h>
 #define DDP_DEV __device__ __forceinline__
-#define LANES for (int lane = (int)threadIdx.x, lanes_once_ = 1; lanes_once_; lanes_once_ = 0)
+// `lane` is laundered through an empty asm so that LICM cannot hoist the dozens of lane-derived
+// indices and loop-invariant LDS table reads of every phase out of the knot loop (that costs >128
+// VGPRs and with them the occupancy); re-deriving them per phase is a handful of integer ops.
+#define LANES for (int lane = direct::opaque_lane(), lanes_once_ = 1; lanes_once_; lanes_once_ = 0)
 #define PLV(T, name) T name
 #define PLA(T, name, n) T name[n]
 #define LV(name) name
@@ -49,6 +52,11 @@ namespace direct {
 constexpr int kPLim = 32;  // DIRECT_P_LIMIT
 
 #if !defined(DIRECT_EMULATE)
+__device__ __forceinline__ int opaque_lane() {
+  int l = (int)threadIdx.x;
+  asm volatile("" : "+v"(l));
+  return l;
+}
 __device__ __forceinline__ float readlane_real(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
@@ -151,16 +159,21 @@ constexpr int kXS = 20;  // knot record stride of X
 // ---- LDS (one per wave) ------------------------------------------------------------------------
 template <typename Real, int RPL>
 struct WaveLds {
-  Real WbE[90], WdE[90];  // base tables with Ek_inv folded in (fixed for the launch)
-  int pq[192];            // upper-triangle (p,q) of the 19x19 system, p | q << 8
+  TrajState st;
+  Real WbE[90], WdE[90];  // value / d-dT base tables with Ek_inv folded in (fixed for the launch)
+  Real Hc[18], Hpc[18];   // [F|G] and [F'|G'] coefficients; entry = coefficient * T^exponent
+  int He[18], Hpe[18];
+  Real Rc[9];             // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1)
+  int pq[192];            // upper-triangle (p,q) of the 18x18 block, p | q << 8
+  Real tp[8], tpn[8];     // powers of T (old / new iterate)
   Real z[kXS], zn[kXS], dz[kXS], xn[12], xnx[12];
   Real pl[4 * kPLim];
   Real We[90];
   Real val[48], dval[48], valn[48], G[48];
   Real drow[64 * RPL], grow[64 * RPL];
-  Real Sp[36], hp[18], dl[27], gm[27], Sd[48], last[4];
+  Real Sp[36], dl[27], Sd[48], hh[48], last[4];
   Real H[18], Hp[18], fT[12];
-  Real Ru[9], Rpu[9], Rppu[9], qs[4];
+  Real Ru[9], Rpu[9], Rppu[9], qp[12];
   Real V[81], Vx[12];
   Real VZ[176];
   Real Hzz[361], Hz[20];
@@ -178,26 +191,34 @@ DDP_DEV Real powi(Real T, int e) {  // T^e for 0 <= e <= 7 without a register-ar
 
 DDP_DEV int ctrl_off(int cr) { return cr < 6 ? 0 : (cr < 11 ? 1 : 2); }
 
-// H = [F | G] (DDP:862-871) and Hp = [F' | G'] (DDP:930-935), entry (c, i), i = 0..5
-template <typename Real>
-DDP_DEV void dyn_entry(Real T, int c, int i, Real& h, Real& hp) {
-  if (i < 3) {
-    int e = i - c;
-    h = (e < 0) ? (Real)0 : (e == 0 ? (Real)1 : (e == 1 ? T : (Real)0.5 * T * T));
-    hp = (e <= 0) ? (Real)0 : (e == 1 ? (Real)1 : T);
+// one constraint row, decoded: kind 0 = position (plane pi, control point vi/3), 1 / 2 = +/- velocity or
+// acceleration component val[vi], 3 = the T >= 0.3 row          (DDP:1181-1188, 1236-1238, 1274-1279)
+struct RowD {
+  int kind, vi, pi;
+};
+DDP_DEV RowD row_decode(int r, int P) {
+  RowD d;
+  int rr = r - 6 * P;
+  if (rr < 0) {
+    int j = (r >= P) + (r >= 2 * P) + (r >= 3 * P) + (r >= 4 * P) + (r >= 5 * P);
+    d.kind = 0;
+    d.vi = 3 * j;
+    d.pi = 4 * (r - j * P);
+  } else if (rr < 30) {
+    d.kind = rr < 15 ? 1 : 2;
+    d.vi = 18 + (rr < 15 ? rr : rr - 15);
+    d.pi = 0;
+  } else if (rr < 54) {
+    int r2 = rr - 30;
+    d.kind = r2 < 12 ? 1 : 2;
+    d.vi = 33 + (r2 < 12 ? r2 : r2 - 12);
+    d.pi = 0;
   } else {
-    int a = i - 3;
-    const Real g0 = (c == 0) ? (Real)1 : (c == 1 ? (Real)(3 + a) : (Real)((3 + a) * (2 + a)));
-    int e = 3 + a - c;
-    h = g0 * powi(T, e);
-    hp = g0 * (Real)e * powi(T, e - 1);
+    d.kind = 3;
+    d.vi = 0;
+    d.pi = 0;
   }
-}
-
-// jerk Gram matrix coefficients: R[a][a'] = Rc * T^(a+a'+1)  (DDP:991-999)
-DDP_DEV double gram_c(int a, int b) {
-  const double rc[3][3] = {{36, 72, 120}, {72, 192, 360}, {120, 360, 720}};
-  return rc[a][b];
+  return d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -206,11 +227,11 @@ struct Wave {
   typedef WaveLds<Real, RPL> Lds;
   const Batch<Real>& B;
   Lds& L;
+  TrajState& st;
   const int b;  // trajectory
   int N;        // segments
-  TrajState st;
 
-  DDP_DEV Wave(const Batch<Real>& batch, Lds& lds, int traj) : B(batch), L(lds), b(traj) {}
+  DDP_DEV Wave(const Batch<Real>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
 
   DDP_DEV Real* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * kXS; }
   DDP_DEV Real* Sp_(Real* base, int k) const { return base + ((size_t)b * B.nmax + k) * B.ncs; }
@@ -218,10 +239,31 @@ struct Wave {
   DDP_DEV int np_(int k) const { return B.n_planes[(size_t)b * B.nmax + k]; }
   DDP_DEV Real* KUp(int k) const { return B.KU + ((size_t)b * B.nmax + k) * 100; }
 
+  DDP_DEV void load_state() {
+    const TrajState* g = &B.st[b];
+    LANES {
+      const int* src = (const int*)g;
+      int* dst = (int*)&L.st;
+      for (int e = lane; e < (int)(sizeof(TrajState) / 4); e += 64) dst[e] = src[e];
+    }
+    WSYNC();
+    N = DDP_UNIFORM_I(L.st.nseg);
+  }
+  DDP_DEV void store_state() {
+    WSYNC();
+    TrajState* g = &B.st[b];
+    LANES {
+      const int* src = (const int*)&L.st;
+      int* dst = (int*)g;
+      for (int e = lane; e < (int)(sizeof(TrajState) / 4); e += 64) dst[e] = src[e];
+    }
+  }
+
   // one-time LDS tables
   DDP_DEV void init_tables() {
     const int mv = B.k.minvo ? 1 : 0;
     LANES {
+#pragma unroll 1
       for (int e = lane; e < 90; e += 64) {
         int cr = e / 6, i = e % 6;
         double eps = (i == 2) ? 0.5 : 1.0;  // Ek_inv = {1,1,1/2} (DDP:101-103), 1 for the u part
@@ -231,80 +273,113 @@ struct Wave {
         L.WbE[e] = (Real)(v * eps);
         L.WdE[e] = (Real)(d * eps);
       }
+#pragma unroll 1
       for (int e = lane; e < 192; e += 64) {
-        // e -> (p,q), p <= q < 19, row-major over the upper triangle
+        // e -> (p,q), p <= q < 18, row-major over the upper triangle (171 entries)
         int p = 0, rem = e;
-        while (p < 19 && rem >= 19 - p) {
-          rem -= 19 - p;
+        while (p < 18 && rem >= 18 - p) {
+          rem -= 18 - p;
           p++;
         }
-        L.pq[e] = (e < 190) ? (p | ((p + rem) << 8)) : 0;
+        L.pq[e] = (e < 171) ? (p | ((p + rem) << 8)) : 0;
+      }
+      if (lane < 18) {  // [F|G] (DDP:862-871) and [F'|G'] (DDP:930-935): coefficient and exponent of T
+        int c = lane / 6, i = lane % 6;
+        double hc, hpc;
+        int he, hpe;
+        if (i < 3) {
+          int e = i - c;
+          hc = (e < 0) ? 0.0 : (e == 2 ? 0.5 : 1.0);
+          he = e < 0 ? 0 : e;
+          hpc = (e <= 0) ? 0.0 : 1.0;
+          hpe = e <= 1 ? 0 : e - 1;
+        } else {
+          int a = i - 3, e = 3 + a - c;
+          double g0 = (c == 0) ? 1.0 : (c == 1 ? (double)(3 + a) : (double)((3 + a) * (2 + a)));
+          hc = g0;
+          he = e;
+          hpc = g0 * (double)e;
+          hpe = e - 1;
+        }
+        L.Hc[lane] = (Real)hc; L.He[lane] = he; L.Hpc[lane] = (Real)hpc; L.Hpe[lane] = hpe;
+      }
+      if (lane < 9) {  // DDP:991-999: Rc[a][a'] = c_a c_a' / (a+a'+1), c_a = (a+1)(a+2)(a+3)
+        int a = lane / 3, a2 = lane % 3;
+        double ca = (a + 1) * (a + 2) * (a + 3), cb = (a2 + 1) * (a2 + 2) * (a2 + 3);
+        L.Rc[lane] = (Real)(ca * cb / (double)(a + a2 + 1));
       }
     }
     WSYNC();
   }
 
   // ---- shared pieces ---------------------------------------------------------------------------
-  // constraint value of row r from control values `val` (DDP:1181-1188, 1236-1238, 1274-1279)
-  DDP_DEV Real row_c(const Real* val, int r, int P, Real T) const {
-    const Real sh = (Real)B.k.shift;
-    int rr = r - 6 * P;
-    if (rr < 0) {
-      int j = r / P, q = r - j * P;
-      const Real* n = &L.pl[4 * q];
-      return n[0] * val[3 * j] + n[1] * val[3 * j + 1] + n[2] * val[3 * j + 2] + n[3] - sh;
-    } else if (rr < 30) {
-      int q = rr < 15 ? rr : rr - 15;
-      Real v = val[18 + q];
-      return (rr < 15 ? v : -v) - (Real)B.k.max_vel - sh;
-    } else if (rr < 54) {
-      int r2 = rr - 30;
-      int q = r2 < 12 ? r2 : r2 - 12;
-      Real v = val[33 + q];
-      return (r2 < 12 ? v : -v) - (Real)B.k.max_acc - sh;
+  // value of row d over the control-value array A: n.A[cp] for position rows, +/-A[vi] otherwise
+  DDP_DEV Real row_lin(const Real* A, const RowD& d) const {
+    if (d.kind == 0) {
+      const Real* n = &L.pl[d.pi];
+      return n[0] * A[d.vi] + n[1] * A[d.vi + 1] + n[2] * A[d.vi + 2];
     }
-    return -T + (Real)0.3 - sh;
+    if (d.kind == 3) return (Real)0;
+    return d.kind == 1 ? A[d.vi] : -A[d.vi];
   }
-  // A_r . w  where w is given per control row as G[cr][d] and for the T_min row as wT
-  DDP_DEV Real row_dot(const Real* G, int r, int P, Real wT) const {
-    int rr = r - 6 * P;
-    if (rr < 0) {
-      int j = r / P, q = r - j * P;
-      const Real* n = &L.pl[4 * q];
-      return n[0] * G[3 * j] + n[1] * G[3 * j + 1] + n[2] * G[3 * j + 2];
-    } else if (rr < 30) {
-      int q = rr < 15 ? rr : rr - 15;
-      return rr < 15 ? G[18 + q] : -G[18 + q];
-    } else if (rr < 54) {
-      int r2 = rr - 30;
-      int q = r2 < 12 ? r2 : r2 - 12;
-      return r2 < 12 ? G[33 + q] : -G[33 + q];
-    }
-    return -wT;
+  // constant part of the constraint row: d_k, -vmax, -amax or +0.3, minus the 2e-4 shift (DDP:1279-1283)
+  DDP_DEV Real row_off(const RowD& d) const {
+    Real o;
+    if (d.kind == 0) o = L.pl[d.pi + 3];
+    else if (d.kind == 3) o = (Real)0.3;
+    else o = (d.vi < 33) ? -(Real)B.k.max_vel : -(Real)B.k.max_acc;
+    return o - (Real)B.k.shift;
+  }
+  // c_r = row_lin(val) + row_off - [T for the last row];  A_r . w = row_lin(G) - [wT for the last row]
+  DDP_DEV Real row_c(const Real* val, const RowD& d, Real T) const {
+    Real c = row_lin(val, d) + row_off(d);
+    return d.kind == 3 ? c - T : c;
+  }
+  DDP_DEV Real row_dot(const Real* G, const RowD& d, Real wT) const {
+    return d.kind == 3 ? -wT : row_lin(G, d);
   }
 
-  // dynamics x+ = (F(x)I) x + (G(x)I) u  (DDP:1062-1067) from a 19-word knot record in LDS
-  DDP_DEV Real next_x(const Real* zz, int a) const {
-    int c = a / 3, d = a % 3;
-    Real T = zz[18], acc = (Real)0;
+  // control values val[cr][d] = sum_i W[cr][i] T^(i-o) C_i[d] from a knot record zz with powers tpw
+  DDP_DEV Real ctrl_val(const Real* zz, const Real* tpw, int cr, int d) const {
+    const int o = ctrl_off(cr);
+    Real v = 0;
+#pragma unroll
     for (int i = 0; i < 6; i++) {
-      Real h, hp;
-      dyn_entry(T, c, i, h, hp);
-      acc += h * zz[3 * i + d];
+      int e = i - o;
+      v += L.WbE[cr * 6 + i] * tpw[e < 0 ? 0 : e] * zz[3 * i + d];
     }
+    return v;
+  }
+  // x+ component a of (F (x) I) x + (G (x) I) u  (DDP:1062-1067)
+  DDP_DEV Real next_x(const Real* zz, const Real* tpw, int a) const {
+    const int c = a / 3, d = a % 3;
+    Real acc = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc += L.Hc[c * 6 + i] * tpw[L.He[c * 6 + i]] * zz[3 * i + d];
     return acc;
   }
-  // running cost q (DDP:1294-1305) of a knot record
-  DDP_DEV Real run_cost(const Real* zz) const {
-    Real T = zz[18], acc = (Real)0;
-    for (int a = 0; a < 3; a++)
-      for (int a2 = 0; a2 < 3; a2++) {
-        Real r = (Real)gram_c(a, a2) * powi(T, a + a2 + 1);
-        acc += r * (zz[9 + 3 * a] * zz[9 + 3 * a2] + zz[10 + 3 * a] * zz[10 + 3 * a2] + zz[11 + 3 * a] * zz[11 + 3 * a2]);
-      }
+  // u_a[d] * (R u)_a[d]; the nine of them sum to u'Ru  (DDP:1294-1305)
+  DDP_DEV Real jerk_part(const Real* zz, const Real* tpw, int a9) const {
+    const int a = a9 / 3, d = a9 % 3;
+    Real acc = 0;
+#pragma unroll
+    for (int a2 = 0; a2 < 3; a2++) acc += L.Rc[a * 3 + a2] * tpw[a + a2 + 1] * zz[9 + 3 * a2 + d];
+    return acc * zz[9 + a9];
+  }
+  DDP_DEV double knot_cost(Real T) const {  // q from the nine partial products in L.qp
+    Real acc = 0;
+#pragma unroll
+    for (int a = 0; a < 9; a++) acc += L.qp[a];
     Real q = (Real)0.5 * (Real)B.k.w_snap * acc;
-    if (B.k.time_power == 2) return q + (Real)0.5 * T * (Real)B.k.w_time * T;
-    return q + (Real)0.5 * (Real)B.k.w_time * T;
+    if (B.k.time_power == 2) q += (Real)0.5 * T * (Real)B.k.w_time * T;
+    else q += (Real)0.5 * (Real)B.k.w_time * T;
+    return (double)q;
+  }
+  DDP_DEV double terminal_sq() {  // |x_N - x_d|^2 with x_N - x_d in L.z[0..8]
+    Real acc = 0;
+#pragma unroll
+    for (int a = 0; a < 9; a++) acc += L.z[a] * L.z[a];
+    return (double)acc;
   }
 
   // ---- evaluation sweep over one iterate buffer: costs, log / error sums, violation count.
@@ -314,6 +389,7 @@ struct Wave {
     PLV(Real, serr);
     PLV(int, nviol);
     LANES { LV(slog) = 0; LV(serr) = 0; LV(nviol) = 0; }
+    const int infeas = DDP_UNIFORM_I(st.infeas);
     double qsum = 0.0;
     int neg = 0;
     for (int k = 0; k < N; k++) {
@@ -326,25 +402,23 @@ struct Wave {
       WSYNC();
       const Real T = L.z[18];
       if (T < 0) neg = 1;
+      LANES { if (lane < 8) L.tp[lane] = powi(T, lane); }
+      WSYNC();
       LANES {
-        if (lane < 45) {
-          int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
-          Real v = 0;
-          for (int i = 0; i < 6; i++) v += L.WbE[cr * 6 + i] * powi(T, i - o) * L.z[3 * i + d];
-          L.val[lane] = v;
-        }
-        if (do_roll && lane >= 48 && lane < 57) L.xnx[lane - 48] = next_x(L.z, lane - 48);
-        if (lane == 63) L.qs[0] = run_cost(L.z);
+        if (lane < 45) L.val[lane] = ctrl_val(L.z, L.tp, lane / 3, lane % 3);
+        else if (lane < 54) { if (do_roll) L.xnx[lane - 45] = next_x(L.z, L.tp, lane - 45); }
+        else if (lane < 63) L.qp[lane - 54] = jerk_part(L.z, L.tp, lane - 54);
       }
       WSYNC();
-      qsum += (double)L.qs[0];
+      qsum += knot_cost(T);
       LANES {
         const Real* yk = Sp_(B.Y[buf], k);
         for (int i = 0; i < RPL; i++) {
           int r = lane + 64 * i;
           if (r < nc) {
-            Real c = row_c(L.val, r, P, T);
-            if (st.infeas) {
+            RowD rd = row_decode(r, P);
+            Real c = row_c(L.val, rd, T);
+            if (infeas) {
               Real y = yk[r];
               LV(slog) += log(y);
               LV(serr) += fabs(c + y);
@@ -358,13 +432,11 @@ struct Wave {
       }
       WSYNC();
     }
-    // terminal cost (DDP:1289-1292)
     LANES {
       if (lane < 9) L.z[lane] = Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane];
     }
     WSYNC();
-    double pterm = 0.0;
-    for (int a = 0; a < 9; a++) pterm += (double)(L.z[a] * L.z[a]);
+    const double pterm = terminal_sq();  // DDP:1289-1292
     WSYNC();
     st.costq = qsum;
     st.cost = qsum + 0.5 * B.k.w_term * pterm;
@@ -453,26 +525,26 @@ struct Wave {
 
   // ---- backward sweep (DDP:440-644).  Returns 1 on success, 0 when the LLT failed. ---------------
   DDP_DEV int bwd_sweep() {
-    // regulariser schedule (DDP:452-474)
-    if (st.fp_failed || st.bp_failed) {
-      st.reg += 1;
-    } else if (st.step == 0) {
-      st.reg -= 1;
-    } else if (st.step > 3) {
-      st.reg += 1;
+    {  // regulariser schedule (DDP:452-474)
+      int reg = st.reg;
+      if (st.fp_failed || st.bp_failed) reg += 1;
+      else if (st.step == 0) reg -= 1;
+      else if (st.step > 3) reg += 1;
+      st.reg = reg < 0 ? 0 : (reg > 24 ? 24 : reg);
     }
-    if (st.reg < 0) st.reg = 0;
-    if (st.reg > 24) st.reg = 24;
+    const int regi = DDP_UNIFORM_I(st.reg);
     double lam_d = 1.0;
-    for (int q = 0; q < st.reg; q++) lam_d *= B.k.reg_base;
+    for (int q = 0; q < regi; q++) lam_d *= B.k.reg_base;
     const Real lam = (Real)(lam_d - 1.0);  // DDP:529
-    const int buf = st.cur;
-    const int infeas = st.infeas;
+    const int buf = DDP_UNIFORM_I(st.cur);
+    const int infeas = DDP_UNIFORM_I(st.infeas);
     const Real mu = (Real)st.mu;
     const Real wsn = (Real)B.k.w_snap;
+    const Real sig = infeas ? (Real)1 : (Real)-1;
 
     // terminal derivatives (DDP:1318-1323)
     LANES {
+#pragma unroll 1
       for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Real)B.k.w_term : (Real)0;
       if (lane < 9) L.Vx[lane] = (Real)B.k.w_term * (Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane]);
     }
@@ -480,8 +552,9 @@ struct Wave {
     PLV(Real, e_mu);
     PLV(Real, e_c);
     LANES { LV(e_mu) = 0; LV(e_c) = 0; }
-    double qu_err = 0.0;
+    Real qu_err = 0;
 
+#pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
       const int P = np_(k);
       const int nc = 6 * P + 55;
@@ -501,59 +574,55 @@ struct Wave {
       }
       WSYNC();
       const Real T = L.z[18];
-      // ---- T1: scaled value table, dynamics tables, jerk-cost vectors
+      // ---- T1: powers of T, scaled value table, dynamics tables
       LANES {
+#pragma unroll 1
         for (int e = lane; e < 90; e += 64) {
           int cr = e / 6, i = e % 6;
           L.We[e] = L.WbE[e] * powi(T, i - ctrl_off(cr));
         }
         if (lane < 18) {
-          Real h, hp;
-          dyn_entry(T, lane / 6, lane % 6, h, hp);
-          L.H[lane] = h;
-          L.Hp[lane] = hp;
-        }
-        if (lane >= 32 && lane < 59) {  // Ru, R'u, R''u (DDP:1349-1355)
-          int t = (lane - 32) / 9, a9 = (lane - 32) % 9, a = a9 / 3, d = a9 % 3;
-          Real acc = 0;
-          for (int a2 = 0; a2 < 3; a2++) {
-            int e = a + a2 + 1 - t;
-            Real cf = (Real)gram_c(a, a2);
-            if (t >= 1) cf *= (Real)(a + a2 + 1);
-            if (t == 2) cf *= (Real)(a + a2);
-            Real pw = (e >= 0) ? powi(T, e) : (Real)0;
-            acc += cf * pw * L.z[9 + 3 * a2 + d];
-          }
-          if (t == 0) L.Ru[a9] = acc;
-          else if (t == 1) L.Rpu[a9] = acc;
-          else L.Rppu[a9] = acc;
+          L.H[lane] = L.Hc[lane] * powi(T, L.He[lane]);
+          L.Hp[lane] = L.Hpc[lane] * powi(T, L.Hpe[lane]);
+        } else if (lane < 26) {
+          L.tp[lane - 18] = powi(T, lane - 18);
         }
       }
       WSYNC();
-      // ---- T2: control values and their d/dT, fT, u'R'u, u'R''u
+      // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u
       LANES {
         if (lane < 45) {
           int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
           Real v = 0, dv = 0;
+#pragma unroll
           for (int i = 0; i < 6; i++) {
             Real zi = L.z[3 * i + d];
             v += L.We[cr * 6 + i] * zi;
             int e = i - o - 1;
-            Real pw = (e >= 0) ? powi(T, e) : (Real)0;
-            dv += L.WdE[cr * 6 + i] * pw * zi;
+            dv += L.WdE[cr * 6 + i] * L.tp[e < 0 ? 0 : e] * zi;  // WdE is 0 where e < 0
           }
           L.val[lane] = v;
           L.dval[lane] = dv;
-        } else if (lane < 54) {
-          int a = lane - 45, c = a / 3, d = a % 3;
+        }
+        if (lane < 27) {  // Ru, R'u, R''u (DDP:1349-1355)
+          int t = lane / 9, a9 = lane % 9, a = a9 / 3, d = a9 % 3;
           Real acc = 0;
+#pragma unroll
+          for (int a2 = 0; a2 < 3; a2++) {
+            int e = a + a2 + 1 - t;
+            Real cf = L.Rc[a * 3 + a2];
+            if (t >= 1) cf *= (Real)(a + a2 + 1);
+            if (t == 2) cf *= (Real)(a + a2);
+            acc += cf * L.tp[e < 0 ? 0 : e] * L.z[9 + 3 * a2 + d];  // cf is 0 where e < 0
+          }
+          Real* dst = (t == 0) ? L.Ru : (t == 1 ? L.Rpu : L.Rppu);
+          dst[a9] = acc;
+        } else if (lane < 36) {
+          int a = lane - 27, c = a / 3, d = a % 3;
+          Real acc = 0;
+#pragma unroll
           for (int i = 0; i < 6; i++) acc += L.Hp[c * 6 + i] * L.z[3 * i + d];
           L.fT[a] = acc;  // DDP:1332
-        } else if (lane < 56) {
-          const Real* v = (lane == 54) ? L.Rpu : L.Rppu;
-          Real acc = 0;
-          for (int a = 0; a < 9; a++) acc += L.z[9 + a] * v[a];
-          L.qs[lane - 54] = acc;
         }
       }
       WSYNC();
@@ -562,7 +631,8 @@ struct Wave {
         for (int i = 0; i < RPL; i++) {
           int r = lane + 64 * i;
           if (r < nc) {
-            Real c = row_c(L.val, r, P, T), s = LV(rs)[i], y = LV(ry)[i];
+            RowD rd = row_decode(r, P);
+            Real c = row_c(L.val, rd, T), s = LV(rs)[i], y = LV(ry)[i];
             Real D, g, rv;
             if (infeas) {  // DDP:535-539, 554
               Real rm = s * y - mu;
@@ -585,13 +655,16 @@ struct Wave {
             L.grow[r] = g;
           }
         }
+#pragma unroll 1
         for (int e = lane; e < 171; e += 64) {  // VZ[a][q]
           int a = e / 19, q = e % 19;
           Real acc = 0;
           if (q < 18) {
             int i = q / 3, d = q % 3;
+#pragma unroll
             for (int c = 0; c < 3; c++) acc += L.V[a * 9 + 3 * c + d] * L.H[c * 6 + i];
           } else {
+#pragma unroll
             for (int c = 0; c < 9; c++) acc += L.V[a * 9 + c] * L.fT[c];
           }
           L.VZ[e] = acc;
@@ -612,17 +685,18 @@ struct Wave {
           } else {
             j = (lane - 36) / 3;
             d0 = (lane - 36) % 3;
-            d1 = 3;  // reads n[3] replaced by 1 below
+            d1 = 3;
             w = L.grow;
           }
           Real acc = 0;
+#pragma unroll 2
           for (int q = 0; q < P; q++) {
             const Real* n = &L.pl[4 * q];
             Real f = (d1 == 3) ? (Real)1 : n[d1];
             acc += w[j * P + q] * n[d0] * f;
           }
           if (lane < 36) L.Sp[lane] = acc;
-          else L.hp[lane - 36] = acc;
+          else L.hh[lane - 36] = acc;
         }
         if (lane < 27) {  // velocity / acceleration rows: +/- pairs
           int rp, rm;
@@ -634,7 +708,7 @@ struct Wave {
             rm = rp + 12;
           }
           L.dl[lane] = L.drow[rp] + L.drow[rm];
-          L.gm[lane] = L.grow[rp] - L.grow[rm];
+          L.hh[18 + lane] = L.grow[rp] - L.grow[rm];
         }
         if (lane == 63) {
           L.last[0] = L.drow[nc - 1];
@@ -661,57 +735,74 @@ struct Wave {
       }
       WSYNC();
       // ---- H: assemble the 19x19 system  Hzz = Z'VZ + quu -/+ A'DA,  Hz = qz + Z'Vx + A'g
-      const Real sig = infeas ? (Real)1 : (Real)-1;
       LANES {
-        for (int e = lane; e < 190; e += 64) {
-          int p = L.pq[e] & 255, q = L.pq[e] >> 8;
-          Real ada = 0, zvz = 0, quu = 0;
-          if (q < 18) {
-            int i = p / 3, d = p % 3, i2 = q / 3, d2 = q % 3;
-            int se = (d <= d2) ? (d * 3 - (d * (d - 1)) / 2 + (d2 - d)) : (d2 * 3 - (d2 * (d2 - 1)) / 2 + (d - d2));
-            for (int cr = 0; cr < 6; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.Sp[cr * 6 + se];
-            if (d == d2)
-              for (int cr = 6; cr < 15; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.dl[(cr - 6) * 3 + d];
-            for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + q];
-            if (i >= 3 && d == d2) quu = wsn * (Real)gram_c(i - 3, i2 - 3) * powi(T, i + i2 - 5);
-          } else if (p < 18) {
-            int i = p / 3, d = p % 3;
-            for (int cr = 0; cr < 15; cr++) ada += L.We[cr * 6 + i] * L.Sd[cr * 3 + d];
-            for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
-            if (i >= 3) quu = wsn * L.Rpu[p - 9];
-          } else {
-            for (int t = 0; t < 45; t++) ada += L.dval[t] * L.Sd[t];
-            ada += L.last[0];
-            for (int a = 0; a < 9; a++) zvz += L.fT[a] * L.VZ[a * 19 + 18];
-            quu = ((B.k.time_power == 2) ? (Real)B.k.w_time : (Real)0) + (Real)0.5 * wsn * L.qs[1];
+#pragma unroll 1
+        for (int e = lane; e < 171; e += 64) {  // the 18x18 block, p <= q
+          const int p = L.pq[e] & 255, q = L.pq[e] >> 8;
+          const int i = p / 3, d = p % 3, i2 = q / 3, d2 = q % 3;
+          const int se = d * 3 - (d * (d - 1)) / 2 + (d2 - d);  // d <= d2 when i == i2; S is symmetric
+          const int se2 = d2 * 3 - (d2 * (d2 - 1)) / 2 + (d - d2);
+          const int sidx = (d <= d2) ? se : se2;
+          Real ada = 0, zvz = 0;
+#pragma unroll
+          for (int cr = 0; cr < 6; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.Sp[cr * 6 + sidx];
+          if (d == d2) {
+#pragma unroll 3
+            for (int cr = 6; cr < 15; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.dl[(cr - 6) * 3 + d];
           }
-          Real v = zvz + quu + sig * ada;
+#pragma unroll
+          for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + q];
+          Real quu = 0;
+          if (i >= 3 && d == d2) quu = wsn * L.Rc[(i - 3) * 3 + (i2 - 3)] * L.tp[i + i2 - 5];
+          const Real v = zvz + quu + sig * ada;
           L.Hzz[p * 19 + q] = v;
           L.Hzz[q * 19 + p] = v;
         }
-        if (lane < 19) {
-          int p = lane;
-          Real ag = 0, zv = 0, qz = 0;
-          if (p < 18) {
-            int i = p / 3, d = p % 3;
-            for (int cr = 0; cr < 6; cr++) ag += L.We[cr * 6 + i] * L.hp[cr * 3 + d];
-            for (int cr = 6; cr < 15; cr++) ag += L.We[cr * 6 + i] * L.gm[(cr - 6) * 3 + d];
-            for (int c = 0; c < 3; c++) zv += L.H[c * 6 + i] * L.Vx[3 * c + d];
-            if (i >= 3) qz = wsn * L.Ru[p - 9];
+        if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
+          const int p = lane < 18 ? lane : lane - 18;
+          const int i = p / 3, d = p % 3;
+          const Real* vec = lane < 18 ? L.Sd : L.hh;
+          Real acc = 0;
+#pragma unroll 5
+          for (int cr = 0; cr < 15; cr++) acc += L.We[cr * 6 + i] * vec[cr * 3 + d];
+          if (lane < 18) {
+            Real zvz = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
+            const Real v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Real)0) + sig * acc;
+            L.Hzz[p * 19 + 18] = v;
+            L.Hzz[18 * 19 + p] = v;
           } else {
-            for (int t = 0; t < 18; t++) ag += L.dval[t] * L.hp[t];
-            for (int t = 18; t < 45; t++) ag += L.dval[t] * L.gm[t - 18];
-            ag -= L.last[1];
-            for (int a = 0; a < 9; a++) zv += L.fT[a] * L.Vx[a];
-            qz = ((B.k.time_power == 2) ? (Real)B.k.w_time * T : (Real)0.5 * (Real)B.k.w_time) + (Real)0.5 * wsn * L.qs[0];
+            Real zv = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) zv += L.H[c * 6 + i] * L.Vx[3 * c + d];
+            L.Hz[p] = ((i >= 3) ? wsn * L.Ru[p - 9] : (Real)0) + zv + acc;
           }
-          L.Hz[p] = qz + zv + ag;
+        } else if (lane < 38) {  // (T,T) entry (lane 36) and Hz[T] (lane 37)
+          const Real* vec = lane == 36 ? L.Sd : L.hh;
+          const Real* rv = lane == 36 ? L.Rppu : L.Rpu;
+          Real acc = 0, zv = 0, uru = 0;
+#pragma unroll 5
+          for (int t = 0; t < 45; t++) acc += L.dval[t] * vec[t];
+#pragma unroll 3
+          for (int a = 0; a < 9; a++) {
+            zv += L.fT[a] * (lane == 36 ? L.VZ[a * 19 + 18] : L.Vx[a]);
+            uru += L.z[9 + a] * rv[a];
+          }
+          if (lane == 36) {
+            const Real quu = ((B.k.time_power == 2) ? (Real)B.k.w_time : (Real)0) + (Real)0.5 * wsn * uru;
+            L.Hzz[18 * 19 + 18] = zv + quu + sig * (acc + L.last[0]);
+          } else {
+            const Real qz = ((B.k.time_power == 2) ? (Real)B.k.w_time * T : (Real)0.5 * (Real)B.k.w_time) + (Real)0.5 * wsn * uru;
+            L.Hz[18] = qz + zv + (acc - L.last[1]);
+          }
         }
       }
       WSYNC();
       // ---- C: LLT of Huu + lam I and the 10 right-hand sides, one column per lane
       PLA(Real, m, 10);
       LANES {
+#pragma unroll
         for (int a = 0; a < 10; a++) {
           Real v = 0;
           if (lane < 10) v = L.Hzz[(9 + a) * 19 + 9 + lane] + ((a == lane) ? lam : (Real)0);
@@ -757,10 +848,11 @@ struct Wave {
       }
       LANES {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
         if (lane >= 10 && lane < 20) {
-          int col = lane - 10;
+          const int col = lane - 10;
+#pragma unroll
           for (int a = 0; a < 10; a++) {
-            if (col == 0) L.KU[a] = -LV(m)[a];
-            else L.KU[10 + a * 9 + (col - 1)] = -LV(m)[a];
+            const int idx = (col == 0) ? a : 10 + a * 9 + (col - 1);
+            L.KU[idx] = -LV(m)[a];
           }
         }
       }
@@ -770,32 +862,33 @@ struct Wave {
         if (lane < 45) {
           int cr = lane / 3, d = lane % 3;
           Real acc = L.dval[lane] * L.KU[9];
+#pragma unroll
           for (int i = 3; i < 6; i++) acc += L.We[cr * 6 + i] * L.KU[(i - 3) * 3 + d];
           L.G[lane] = acc;
         }
+#pragma unroll 1
         for (int e = lane; e < 190; e += 64) {
+          // W1 = Hxu Ku (81) | W2 = Huu Ku (90) | t10 = Huu ku (10) | hk = Hxu ku (9): all 10-term dots
+          int hrow, koff, kstr;
+          Real* dst;
+          if (e < 81) { hrow = e / 9; koff = 10 + e % 9; kstr = 9; dst = &L.W1[e]; }
+          else if (e < 171) { hrow = 9 + (e - 81) / 9; koff = 10 + (e - 81) % 9; kstr = 9; dst = &L.W2[e - 81]; }
+          else if (e < 181) { hrow = 9 + (e - 171); koff = 0; kstr = 1; dst = &L.t10[e - 171]; }
+          else { hrow = e - 181; koff = 0; kstr = 1; dst = &L.hk[e - 181]; }
+          const Real* hp = &L.Hzz[hrow * 19 + 9];
           Real acc = 0;
-          if (e < 81) {  // W1 = Hxu * Ku
-            int a = e / 9, c2 = e % 9;
-            for (int c = 0; c < 10; c++) acc += L.Hzz[a * 19 + 9 + c] * L.KU[10 + c * 9 + c2];
-            L.W1[e] = acc;
-          } else if (e < 171) {  // W2 = Huu * Ku
-            int a = (e - 81) / 9, c2 = (e - 81) % 9;
-            for (int c = 0; c < 10; c++) acc += L.Hzz[(9 + a) * 19 + 9 + c] * L.KU[10 + c * 9 + c2];
-            L.W2[e - 81] = acc;
-          } else if (e < 181) {  // t10 = Huu * ku
-            int a = e - 171;
-            for (int c = 0; c < 10; c++) acc += L.Hzz[(9 + a) * 19 + 9 + c] * L.KU[c];
-            L.t10[a] = acc;
-          } else {  // hk = Hxu * ku
-            int a = e - 181;
-            for (int c = 0; c < 10; c++) acc += L.Hzz[a * 19 + 9 + c] * L.KU[c];
-            L.hk[a] = acc;
-          }
+#pragma unroll 5
+          for (int c = 0; c < 10; c++) acc += hp[c] * L.KU[koff + c * kstr];
+          *dst = acc;
         }
       }
       WSYNC();
-      for (int a = 0; a < 10; a++) qu_err = fmax(qu_err, fabs((double)L.Hz[9 + a]));  // DDP:633 (quirk Q10)
+      {  // DDP:633 (quirk Q10): Qu after the condensation correction
+        Real m0 = 0;
+#pragma unroll
+        for (int a = 0; a < 10; a++) m0 = fmax(m0, fabs(L.Hz[9 + a]));
+        qu_err = fmax(qu_err, m0);
+      }
       // ---- R2: slack / dual gains per row; V recursion; gains to HBM
       LANES {
         Real* ksg = Sp_(B.KS, k);
@@ -804,7 +897,8 @@ struct Wave {
         for (int i = 0; i < RPL; i++) {
           int r = lane + 64 * i;
           if (r < nc) {
-            Real cuku = row_dot(L.G, r, P, kuT);
+            RowD rd = row_decode(r, P);
+            Real cuku = row_dot(L.G, rd, kuT);
             Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
             if (infeas) {  // DDP:568, 571
               Real y = LV(ry)[i];
@@ -815,34 +909,31 @@ struct Wave {
             }
           }
         }
+#pragma unroll 1
         for (int e = lane; e < 100; e += 64) KUp(k)[e] = L.KU[e];
-        Real vnew = 0, vnew2 = 0;
-        int a = 0, c2 = 0;
-        if (lane < 45) {  // Vxx (DDP:627-628), pairs a <= c2
-          int rem = lane;
+        if (lane < 45) {  // Vxx (DDP:627-628), pairs a <= c2.  V is dead since phase R1: overwrite in place
+          int a = 0, rem = lane;
           while (rem >= 9 - a) {
             rem -= 9 - a;
             a++;
           }
-          c2 = a + rem;
+          const int c2 = a + rem;
           Real m1 = L.Hzz[a * 19 + c2] + L.W1[a * 9 + c2] + L.W1[c2 * 9 + a];
           Real m2 = m1;
+#pragma unroll 5
           for (int c = 0; c < 10; c++) {
             m1 += L.KU[10 + c * 9 + a] * L.W2[c * 9 + c2];
             m2 += L.KU[10 + c * 9 + c2] * L.W2[c * 9 + a];
           }
-          vnew = (Real)0.5 * (m1 + m2);
-        } else if (lane < 54) {  // Vx (DDP:626)
-          int aa = lane - 45;
-          vnew2 = L.Hz[aa] + L.hk[aa];
-          for (int c = 0; c < 10; c++) vnew2 += L.KU[10 + c * 9 + aa] * (L.Hz[9 + c] + L.t10[c]);
-        }
-        // V / Vx are dead since phase H of this knot: safe to overwrite without another sync
-        if (lane < 45) {
+          const Real vnew = (Real)0.5 * (m1 + m2);
           L.V[a * 9 + c2] = vnew;
           L.V[c2 * 9 + a] = vnew;
-        } else if (lane < 54) {
-          L.Vx[lane - 45] = vnew2;
+        } else if (lane < 54) {  // Vx (DDP:626); Vx is dead since phase H
+          const int aa = lane - 45;
+          Real v2 = L.Hz[aa] + L.hk[aa];
+#pragma unroll 5
+          for (int c = 0; c < 10; c++) v2 += L.KU[10 + c * 9 + aa] * (L.Hz[9 + c] + L.t10[c]);
+          L.Vx[aa] = v2;
         }
       }
       WSYNC();
@@ -850,20 +941,23 @@ struct Wave {
     double mu_err = WAVE_MAX_D(e_mu);
     double c_err = infeas ? WAVE_MAX_D(e_c) : 0.0;
     st.bp_failed = 0;
-    st.opterr = fmax(fmax(qu_err, c_err), mu_err);  // DDP:641
+    st.opterr = fmax(fmax((double)qu_err, c_err), mu_err);  // DDP:641
     return 1;
   }
 
   // ---- forward pass (DDP:647-778) ---------------------------------------------------------------
   DDP_DEV void fwd_pass() {
-    const int cur = st.cur, nxt = 1 - st.cur;
-    const int infeas = st.infeas;
-    const double tau_d = fmax(0.99, 1.0 - st.mu);
+    const int cur = DDP_UNIFORM_I(st.cur), nxt = 1 - cur;
+    const int infeas = DDP_UNIFORM_I(st.infeas);
+    const double mu_d = st.mu;
+    const double tau_d = fmax(0.99, 1.0 - mu_d);
     const Real omt = (Real)(1.0 - tau_d);
+    const int nfilter = DDP_UNIFORM_I(st.nfilter);
     double* filt = B.filt + (size_t)b * B.fcap * 2;
     int accepted = 0, step = 0;
     double cost = 0, costq = 0, logcost = 0, err = 0, sumlog = 0, errsum = 0, stepsize = 0;
-    int viol = 0, neg = 0;
+    int viol = 0, neg = 0, nkeep = 0;
+#pragma unroll 1
     for (step = 0; step < 11; step++) {
       stepsize = 1.0;
       for (int q = 0; q < step; q++) stepsize *= 0.5;  // DDP:670
@@ -879,6 +973,7 @@ struct Wave {
       double qsum = 0.0;
       int failed = 0;
       neg = 0;
+#pragma unroll 1
       for (int k = 0; k < N; k++) {
         const int P = np_(k);
         const int nc = 6 * P + 55;
@@ -888,6 +983,7 @@ struct Wave {
         PLA(Real, rky, RPL);
         LANES {
           if (lane < 19) L.z[lane] = Xp(cur, k)[lane];
+#pragma unroll 1
           for (int e = lane; e < 100; e += 64) L.KU[e] = KUp(k)[e];
           for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
           for (int i = 0; i < RPL; i++) {
@@ -900,48 +996,58 @@ struct Wave {
           }
         }
         WSYNC();
-        // ---- D: dx, Ku dx, u+ (DDP:689 / 695)
+        // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the old and the new T
         LANES {
           if (lane < 9) {
-            Real dx = L.xn[lane] - L.z[lane];
-            L.dz[lane] = dx;
+            L.dz[lane] = L.xn[lane] - L.z[lane];
             L.zn[lane] = L.xn[lane];
           } else if (lane < 19) {
             int a = lane - 9;
             Real acc = 0;
+#pragma unroll 3
             for (int c = 0; c < 9; c++) acc += L.KU[10 + a * 9 + c] * (L.xn[c] - L.z[c]);
             L.dz[lane] = acc;
-            L.zn[lane] = L.z[lane] + alpha * L.KU[a] + acc;
+            Real un = L.z[lane] + alpha * L.KU[a] + acc;
+            L.zn[lane] = un;
+            if (lane == 18) {
+              Real pw = 1;
+              for (int q = 0; q < 8; q++) { L.tpn[q] = pw; pw *= un; }
+            }
+          } else if (lane == 19) {
+            Real To_ = L.z[18], pw = 1;
+            for (int q = 0; q < 8; q++) { L.tp[q] = pw; pw *= To_; }
           }
         }
         WSYNC();
         const Real To = L.z[18], Tn = L.zn[18];
         if (Tn < 0) neg = 1;
-        // ---- T: control values at the old and the new iterate, A*[dx; Ku dx]
+        // ---- T: control values at the old and the new iterate, A*[dx; Ku dx], x+, jerk cost
         LANES {
           if (lane < 45) {
             int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
             Real vo = 0, dvo = 0, vn = 0, gf = 0;
+#pragma unroll
             for (int i = 0; i < 6; i++) {
+              int e = i - o;
+              int e0 = e < 0 ? 0 : e, e1 = e < 1 ? 0 : e - 1;
               Real wb = L.WbE[cr * 6 + i];
-              Real w = wb * powi(To, i - o);
+              Real w = wb * L.tp[e0];
               vo += w * L.z[3 * i + d];
               gf += w * L.dz[3 * i + d];
-              int e = i - o - 1;
-              dvo += L.WdE[cr * 6 + i] * ((e >= 0) ? powi(To, e) : (Real)0) * L.z[3 * i + d];
-              vn += wb * powi(Tn, i - o) * L.zn[3 * i + d];
+              dvo += L.WdE[cr * 6 + i] * L.tp[e1] * L.z[3 * i + d];
+              vn += wb * L.tpn[e0] * L.zn[3 * i + d];
             }
             L.val[lane] = vo;
             L.valn[lane] = vn;
             L.G[lane] = gf + dvo * L.dz[18];
           } else if (lane < 54) {
-            L.xnx[lane - 45] = next_x(L.zn, lane - 45);
-          } else if (lane == 54) {
-            L.qs[0] = run_cost(L.zn);
+            L.xnx[lane - 45] = next_x(L.zn, L.tpn, lane - 45);
+          } else if (lane < 63) {
+            L.qp[lane - 54] = jerk_part(L.zn, L.tpn, lane - 54);
           }
         }
         WSYNC();
-        qsum += (double)L.qs[0];
+        qsum += knot_cost(Tn);
         // ---- R: rows: s+, y+, c+, fraction-to-boundary tests
         PLV(int, bad);
         LANES {
@@ -952,8 +1058,9 @@ struct Wave {
           for (int i = 0; i < RPL; i++) {
             int r = lane + 64 * i;
             if (r < nc) {
-              Real az = row_dot(L.G, r, P, dzT);
-              Real cn = row_c(L.valn, r, P, Tn);
+              RowD rd = row_decode(r, P);
+              Real az = row_dot(L.G, rd, dzT);
+              Real cn = row_c(L.valn, rd, Tn);
               Real s = LV(rs)[i];
               Real snew;
               if (infeas) {  // DDP:680-687
@@ -965,7 +1072,7 @@ struct Wave {
                 LV(slog) += log(ynew);
                 LV(serr) += fabs(cn + ynew);
               } else {  // DDP:694-703
-                Real co = row_c(L.val, r, P, To);
+                Real co = row_c(L.val, rd, To);
                 snew = s + alpha * LV(rks)[i] - (s / co) * az;
                 if (cn > omt * co || snew < omt * s) LV(bad) = 1;
                 LV(slog) += log(-cn);
@@ -989,19 +1096,18 @@ struct Wave {
         }
       }
       WSYNC();
-      double pterm = 0.0;
-      for (int a = 0; a < 9; a++) pterm += (double)(L.z[a] * L.z[a]);
+      const double pterm = terminal_sq();
       WSYNC();
       costq = qsum;
       cost = qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
       sumlog = WAVE_SUM_D(slog);
       errsum = WAVE_SUM_D(serr);
       viol = WAVE_SUM_I(nviol);
-      logcost = cost - st.mu * sumlog;  // DDP:718-732
+      logcost = cost - mu_d * sumlog;  // DDP:718-732
       err = infeas ? fmax(B.k.tol, errsum) : 0.0;
       // filter (DDP:737-757)
-      int nkeep = 0, rejected = 0;
-      for (int i = 0; i < st.nfilter; i++) {
+      int rejected = 0;
+      for (int i = 0; i < nfilter; i++) {
         double f0 = filt[2 * i], f1 = filt[2 * i + 1];
         if (logcost >= f0 && err >= f1) {
           rejected = 1;
@@ -1009,7 +1115,8 @@ struct Wave {
         }
       }
       if (rejected) continue;
-      for (int i = 0; i < st.nfilter; i++) {
+      nkeep = 0;
+      for (int i = 0; i < nfilter; i++) {
         double f0 = filt[2 * i], f1 = filt[2 * i + 1];
         if (logcost > f0 || err > f1) {  // wave-uniform stores (nkeep <= i)
           filt[2 * nkeep] = f0;
@@ -1019,7 +1126,6 @@ struct Wave {
       }
       filt[2 * nkeep] = logcost;
       filt[2 * nkeep + 1] = err;
-      st.nfilter = nkeep + 1;
       accepted = 1;
       break;
     }
@@ -1027,6 +1133,7 @@ struct Wave {
       st.fp_failed = 1;
       st.stepsize = 0.0;
     } else {  // DDP:763-776
+      st.nfilter = nkeep + 1;
       st.cost = cost;
       st.costq = costq;
       st.logcost = logcost;
@@ -1076,20 +1183,17 @@ struct Wave {
         st.done = 1;
         return;
       }
+      const double d = st.cost - prev_cost;
       if (!B.k.line_init) {
-        double d = st.cost - prev_cost;
         if (d * d < prev_cost * 1.0e-2 && st.opterr < 5.0e1) {
           st.rtn = 1;
           st.done = 1;
           return;
         }
-      } else {
-        double d = st.cost - prev_cost;
-        if (d * d < prev_cost * 0.01) {
-          st.line_failed = 0;
-          st.done = 1;
-          return;
-        }
+      } else if (d * d < prev_cost * 0.01) {
+        st.line_failed = 0;
+        st.done = 1;
+        return;
       }
     }
     if (st.bp_no_upd > 20) {  // DDP:392-396
@@ -1108,7 +1212,9 @@ struct Wave {
   }
 
   DDP_DEV void iterate(int n_iters) {
-    for (int it = 0; it < n_iters && !st.done; it++) {
+#pragma unroll 1
+    for (int it = 0; it < n_iters; it++) {
+      if (DDP_UNIFORM_I(st.done)) break;
       if (st.iter >= B.k.iter_max) {
         st.done = 1;
         break;
@@ -1142,7 +1248,7 @@ DDP_DEV void finish_wave(Wave<Real, RPL>& W, const OutPtrs<Real>& O) {
       Real T = zz[18], acc = 0;  // finalroll, DDP:1624-1634
       for (int a = 0; a < 3; a++)
         for (int a2 = 0; a2 < 3; a2++) {
-          Real r = (Real)gram_c(a, a2) * powi(T, a + a2 + 1);
+          Real r = W.L.Rc[a * 3 + a2] * powi(T, a + a2 + 1);
           acc += r * (zz[9 + 3 * a] * zz[9 + 3 * a2] + zz[10 + 3 * a] * zz[10 + 3 * a2] + zz[11 + 3 * a] * zz[11 + 3 * a2]);
         }
       LV(jc) += acc;
@@ -1201,10 +1307,14 @@ DDP_DEV void get_field_wave(Wave<Real, RPL>& W, int field, Real* dst) {
   if (field == 9) {
     const TrajState& s = W.st;
     Real* o = dst + (size_t)b * 16;
-    o[0] = (Real)s.cost; o[1] = (Real)s.costq; o[2] = (Real)s.logcost; o[3] = (Real)s.err;
-    o[4] = (Real)s.mu; o[5] = (Real)s.reg; o[6] = (Real)s.opterr; o[7] = (Real)s.stepsize;
-    o[8] = (Real)s.step; o[9] = (Real)s.fp_failed; o[10] = (Real)s.bp_failed; o[11] = (Real)s.rtn;
-    o[12] = (Real)s.iter; o[13] = (Real)s.done; o[14] = (Real)s.nfilter; o[15] = (Real)s.infeas;
+    LANES {
+      if (lane == 0) {
+        o[0] = (Real)s.cost; o[1] = (Real)s.costq; o[2] = (Real)s.logcost; o[3] = (Real)s.err;
+        o[4] = (Real)s.mu; o[5] = (Real)s.reg; o[6] = (Real)s.opterr; o[7] = (Real)s.stepsize;
+        o[8] = (Real)s.step; o[9] = (Real)s.fp_failed; o[10] = (Real)s.bp_failed; o[11] = (Real)s.rtn;
+        o[12] = (Real)s.iter; o[13] = (Real)s.done; o[14] = (Real)s.nfilter; o[15] = (Real)s.infeas;
+      }
+    }
     return;
   }
   if (field == 0) {
@@ -1229,17 +1339,12 @@ DDP_DEV void get_field_wave(Wave<Real, RPL>& W, int field, Real* dst) {
       }
       WSYNC();
       const Real T = W.L.z[18];
-      LANES {
-        if (lane < 45) {
-          int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
-          Real v = 0;
-          for (int i = 0; i < 6; i++) v += W.L.WbE[cr * 6 + i] * powi(T, i - o) * W.L.z[3 * i + d];
-          W.L.val[lane] = v;
-        }
-      }
+      LANES { if (lane < 8) W.L.tp[lane] = powi(T, lane); }
+      WSYNC();
+      LANES { if (lane < 45) W.L.val[lane] = W.ctrl_val(W.L.z, W.L.tp, lane / 3, lane % 3); }
       WSYNC();
       LANES {
-        for (int r = lane; r < nc; r += 64) dst[rowbase + r] = W.row_c(W.L.val, r, P, T);
+        for (int r = lane; r < nc; r += 64) dst[rowbase + r] = W.row_c(W.L.val, row_decode(r, P), T);
       }
       WSYNC();
     } else {

@@ -17,49 +17,65 @@
 using namespace direct;
 
 // ---- kernels ---------------------------------------------------------------------------------------
+#ifndef DDP_WAVES_F32
+#define DDP_WAVES_F32 1
+#endif
+#ifndef DDP_WAVES_F64
+#define DDP_WAVES_F64 1
+#endif
+template <typename Real>
+struct MinWaves { static constexpr int v = DDP_WAVES_F32; };
+template <>
+struct MinWaves<double> { static constexpr int v = DDP_WAVES_F64; };
+
 template <typename Real, int RPL>
 __global__ __launch_bounds__(64) void k_begin(Batch<Real> B) {
   __shared__ WaveLds<Real, RPL> lds;
-  const int b = blockIdx.x;
-  Wave<Real, RPL> W(B, lds, b);
+  Wave<Real, RPL> W(B, lds, blockIdx.x);
   W.init_tables();
   W.begin();
-  if (threadIdx.x == 0) B.st[b] = W.st;
+  W.store_state();
 }
 
-// mode 0: n outer iterations; 1: one backwardpass(); 2: one forwardpass()
+// the hot kernel: n trips of the outer loop (ddp_optimizer.cpp:295-412) per trajectory
 template <typename Real, int RPL>
-__global__ __launch_bounds__(64) void k_iterate(Batch<Real> B, int n_iters, int mode) {
+__global__ __launch_bounds__(64, MinWaves<Real>::v) void k_iterate(Batch<Real> B, int n_iters) {
   __shared__ WaveLds<Real, RPL> lds;
-  const int b = blockIdx.x;
-  Wave<Real, RPL> W(B, lds, b);
-  W.st = B.st[b];
-  if (W.st.done) return;
-  W.N = W.st.nseg;
+  Wave<Real, RPL> W(B, lds, blockIdx.x);
+  W.load_state();
+  if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
-  if (mode == 0) W.iterate(n_iters);
-  else if (mode == 1) W.bwd_sweep();
+  W.iterate(n_iters);
+  W.store_state();
+}
+
+// stepwise interface: mode 1 = one backwardpass(), 2 = one forwardpass()
+template <typename Real, int RPL>
+__global__ __launch_bounds__(64) void k_pass(Batch<Real> B, int mode) {
+  __shared__ WaveLds<Real, RPL> lds;
+  Wave<Real, RPL> W(B, lds, blockIdx.x);
+  W.load_state();
+  if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
+  W.init_tables();
+  if (mode == 1) W.bwd_sweep();
   else W.fwd_pass();
-  if (threadIdx.x == 0) B.st[b] = W.st;
+  W.store_state();
 }
 
 template <typename Real, int RPL>
 __global__ __launch_bounds__(64) void k_finish(Batch<Real> B, OutPtrs<Real> O) {
   __shared__ WaveLds<Real, RPL> lds;
-  const int b = blockIdx.x;
-  Wave<Real, RPL> W(B, lds, b);
-  W.st = B.st[b];
-  W.N = W.st.nseg;
+  Wave<Real, RPL> W(B, lds, blockIdx.x);
+  W.load_state();
+  W.init_tables();
   finish_wave(W, O);
 }
 
 template <typename Real, int RPL>
 __global__ __launch_bounds__(64) void k_field(Batch<Real> B, int field, Real* buf, int set) {
   __shared__ WaveLds<Real, RPL> lds;
-  const int b = blockIdx.x;
-  Wave<Real, RPL> W(B, lds, b);
-  W.st = B.st[b];
-  W.N = W.st.nseg;
+  Wave<Real, RPL> W(B, lds, blockIdx.x);
+  W.load_state();
   W.init_tables();
   if (set) set_field_wave(W, field, (const Real*)buf);
   else get_field_wave(W, field, buf);
@@ -210,7 +226,8 @@ static void launch_begin_t(direct_ddp_handle_t h) {
 template <typename Real>
 static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
   auto Bt = make_batch<Real>(h, h->cur_in, h->params);
-  RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n, mode);
+  if (mode == 0) RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n);
+  else RPL_LAUNCH(h, k_pass, Real, h->B, Bt, mode);
 }
 template <typename Real>
 static void launch_field_t(direct_ddp_handle_t h, int field, int set) {

@@ -15,7 +15,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdirect_ddp.so")
+LIB_PATH = os.environ.get("DIRECT_DDP_LIB", os.path.join(_HERE, "lib", "libdirect_ddp.so"))
 _LIB = None
 
 EXPORTS = (

@@ -83,7 +83,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
     W.init_tables();
     memset(&W.st, 0, sizeof(W.st));
     W.begin();
-    W.B.st[W.b] = W.st;
+    W.store_state();
   });
   return E;
 }
@@ -91,11 +91,10 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
 template <typename Real, typename F>
 static void with_state(Emu<Real>& E, F f) {
   dispatch(E, [&](auto& W) {
+    W.load_state();
     W.init_tables();
-    W.st = W.B.st[W.b];
-    W.N = W.st.nseg;
     f(W);
-    W.B.st[W.b] = W.st;
+    W.store_state();
   });
 }
 

@@ -1,0 +1,92 @@
+"""The C-ABI library: loads, exports every symbol include/direct_ddp.h declares, ctypes mirrors have
+the C sizes, and without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from direct_amd import abi, problems, solver
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "direct_ddp.h")
+
+
+def declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(direct_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = solver.lib()
+    names = declared_functions()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), "libdirect_ddp.so does not export %s" % n
+    assert set(names) == set(solver.EXPORTS)
+    assert lib.direct_ddp_abi_version() == 1
+
+
+def test_struct_sizes_match_the_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu\\n",'
+                   'sizeof(direct_ddp_params_t),sizeof(direct_ddp_batch_in_t),sizeof(direct_ddp_batch_out_t),'
+                   'sizeof(direct_ddp_config_t));return 0;}\n' % HEADER)
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(abi.Params), C.sizeof(abi.BatchIn), C.sizeof(abi.BatchOut), C.sizeof(abi.Config)]
+
+
+def _has_gpu():
+    try:
+        out = subprocess.run(["/opt/rocm/bin/rocminfo"], capture_output=True, text=True, timeout=30).stdout
+        return "gfx950" in out
+    except Exception:
+        return False
+
+
+def test_no_cpu_fallback_without_device(built):
+    if _has_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(solver.DirectError) as e:
+        solver.DdpSolver(4, 5, 6, np.float32)
+    assert e.value.status == abi.DIRECT_ERR_NO_DEVICE
+
+
+def test_product_package_does_not_import_the_oracle():
+    """direct_amd/ must never touch oracle/ or the emulator (they are test infrastructure)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "direct_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("oracle/ or", "") or f == "abi.py", (dirpath, f)
+                assert "DIRECT_EMULATE" not in txt or f == "ddp_wave.h", (dirpath, f)
+
+
+def test_create_rejects_bad_configs(built):
+    lib = solver.lib()
+    h = C.c_void_p()
+    for cfg, want in ((abi.Config(5, 0, 4, 4, 6, 0), abi.DIRECT_ERR_INVALID),
+                      (abi.Config(abi.F32, 0, 0, 4, 6, 0), abi.DIRECT_ERR_INVALID),
+                      (abi.Config(abi.F32, 0, 4, 4, 99, 0), abi.DIRECT_ERR_UNSUPPORTED)):
+        assert lib.direct_ddp_create(C.addressof(cfg), C.addressof(h)) == want
+        assert len(lib.direct_ddp_last_error()) > 0
+
+
+def test_time_allocation_through_the_abi(built):
+    """initTimeAllocation (teach_repeat_planner.cpp:583-639) is host code in the library."""
+    batch = problems.make_batch("free", 5, 9, seed=4)
+    T = solver.time_allocation(batch.n_seg, batch.x0[:, :3], batch.xd[:, :3], batch.seeds)
+    assert np.allclose(T, batch.T0, rtol=1e-14)
+
+
+def test_algorithmic_words_formula():
+    """257 + 5 nc + 8 P words per knot-iteration (feasible), P = 6 -> 760."""
+    b = problems.make_batch("free", 2, 10, seed=1)
+    assert problems.algorithmic_words(b.n_planes, b.n_seg) == 2 * 10 * 760
+    assert problems.algorithmic_words(b.n_planes, b.n_seg, infeasible=True) == 2 * 10 * (257 + 910 + 48)

@@ -1,0 +1,91 @@
+"""The kernel SOURCE (direct_amd/csrc/ddp_wave.h) compiled by the test-only lane-loop emulator
+(tests/emu/emu.cpp: every 64-lane phase becomes a loop) against the oracle and the golden vectors.
+This checks the restructured mathematics of the HIP kernels -- Kronecker-form constraint rows,
+3x3 accumulators, column-per-lane LLT -- on a machine without a GPU.  It is not a product path."""
+import numpy as np
+import pytest
+
+from direct_amd import abi, problems
+from oracle import refapi
+from tests import helpers
+from tests.emu import emuapi
+
+
+@pytest.mark.parametrize("name", helpers.CASES)
+def test_emulated_kernels_match_golden_fp64(name):
+    g, batch = helpers.load_case(name)
+    p0, p1 = helpers.case_params(name)
+    e0 = emuapi.solve_batch(p0, batch)
+    helpers.check_result(e0, g, "p0_", 1e-9, T_tol=1e-8)
+    e1 = emuapi.solve_batch(p1, helpers.phase1_batch(g, batch))
+    helpers.check_result(e1, g, "p1_", 1e-8, T_tol=1e-6)
+
+
+@pytest.mark.parametrize("kind,N", [("free", 5), ("corridor", 8)])
+def test_emulated_passes_match_oracle(kind, N):
+    """One backward sweep and one forward pass from identical state: gains and iterates."""
+    batch = problems.make_batch(kind, 2, N, seed=21)
+    p0 = abi.phase0_params()
+    e = emuapi.EmuSolver(p0, batch)
+    r = [refapi.Stepper(p0, batch, i) for i in range(2)]
+    e.backward()
+    for q in r:
+        q.backward()
+    for f in (abi.FIELD_KU, abi.FIELD_KUU, abi.FIELD_KS, abi.FIELD_KY):
+        for i in range(2):
+            assert helpers.rel(e.get(f)[i], r[i].get(f)) < 1e-10
+    e.forward()
+    for q in r:
+        q.forward()
+    for f in (abi.FIELD_X, abi.FIELD_U, abi.FIELD_S, abi.FIELD_Y, abi.FIELD_C):
+        for i in range(2):
+            assert helpers.rel(e.get(f)[i], r[i].get(f)) < 1e-10
+    sc = e.scalars()
+    for i in range(2):
+        rs = r[i].scalars()
+        assert sc["step"][i] == rs["step"] and sc["fp_failed"][i] == rs["fp_failed"]
+        assert abs(sc["logcost"][i] / rs["logcost"] - 1) < 1e-12
+
+
+def test_emulated_fp32_within_stated_tolerance():
+    """fp32 arithmetic (fp64 scalar accumulators): converged cost within 5e-3 of the fp64 oracle on
+    short corridors; iteration counts may differ (SURVEY.md 8c tolerances)."""
+    g, batch = helpers.load_case("corridor_n8")
+    p0, p1 = helpers.case_params("corridor_n8")
+    e1 = emuapi.solve_batch(p1, helpers.phase1_batch(g, batch), np.float32)
+    assert (e1.rtn == g["p1_rtn"].astype(int)).all()
+    assert np.abs(e1.cost / g["p1_cost"] - 1).max() < 5e-3
+    assert helpers.rel(e1.T, g["p1_T"]) < 2e-2
+
+
+def test_ragged_batch_and_mixed_plane_counts():
+    """n_seg differs per problem (ragged), planes per polytope differ per knot."""
+    a = problems.make_batch("corridor", 2, 9, seed=31)
+    n_seg = np.array([9, 5], np.int32)
+    xd = a.xd.copy()
+    xd[1, :3] = a.seeds[1, 5]          # goal of the short problem = its 6th seed
+    T0 = problems.time_allocation(n_seg, a.x0[:, :3], xd[:, :3], a.seeds)
+    batch = abi.HostBatch(n_seg, a.x0, xd, T0, a.n_planes, a.planes, seeds=a.seeds)
+    p0 = abi.phase0_params()
+    r, _ = refapi.solve_batch(p0, batch)
+    e = emuapi.solve_batch(p0, batch)
+    assert (e.rtn == r.rtn).all() and (e.iter_used == r.iter_used).all()
+    assert np.abs(e.cost / r.cost - 1).max() < 1e-9
+    assert helpers.rel(e.T[1, :5], r.T[1, :5]) < 1e-8 and (e.T[1, 5:] == 0).all()
+
+
+def test_fixed_iteration_mode_and_resume():
+    """fixed_iters disables the early exits; iterate(a) + iterate(b) == iterate(a+b)."""
+    g, batch = helpers.load_case("free_n5")
+    b1 = helpers.phase1_batch(g, batch)
+    p = abi.phase1_params(iter_max=6, fixed_iters=1)
+    one = emuapi.EmuSolver(p, b1)
+    one.iterate(6)
+    two = emuapi.EmuSolver(p, b1)
+    two.iterate(2)
+    two.iterate(4)
+    ra, rb = one.finish(), two.finish()
+    assert (ra.fwd_passes == 6).all() and (rb.fwd_passes == 6).all()
+    assert np.array_equal(ra.bez, rb.bez) and np.array_equal(ra.cost, rb.cost)
+    r, _ = refapi.solve_batch(p, b1)
+    assert np.abs(ra.cost / r.cost - 1).max() < 1e-9

@@ -1,0 +1,163 @@
+"""BASELINE-size batches (B = 4096, N = 100): the oracle cannot be run on all of them in seconds,
+so parity is established (a) exactly against the oracle on a random SAMPLE of the batch and (b)
+through size-independent properties of the whole batch: determinism, sharding invariance,
+dynamics / continuity of the returned polynomials, feasibility and duration bounds at exit,
+Bezier <-> monomial consistency of the two output formats, monotone objective."""
+import numpy as np
+import pytest
+
+from direct_amd import abi, problems, solver
+from oracle import refapi
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+B, N = 4096, 100
+
+
+@pytest.fixture(scope="module")
+def free_batch():
+    return problems.make_batch("free", B, N, seed=1000)
+
+
+@pytest.fixture(scope="module")
+def corridor_batch():
+    return problems.make_batch("corridor", B, N, seed=1000)
+
+
+def poly_eval(poly, T, order):
+    """value of the order-th derivative of every segment's quintic at t = T; poly [.., 18] = c0xyz..c5xyz"""
+    C = poly.reshape(poly.shape[:-1] + (6, 3))
+    out = np.zeros(poly.shape[:-1] + (3,))
+    for i in range(order, 6):
+        f = 1.0
+        for q in range(order):
+            f *= (i - q)
+        out += f * C[..., i, :] * T[..., None] ** (i - order)
+    return out
+
+
+def check_properties(batch, res, fp_tol):
+    n = batch.n_seg_max
+    ok = res.rtn >= 0
+    assert ok.mean() > 0.9
+    # continuity of position / velocity / acceleration across segments = the dynamics roll-out
+    for order in range(3):
+        end = poly_eval(res.poly[:, :-1], res.T[:, :-1], order)
+        coef = {0: 1.0, 1: 1.0, 2: 2.0}[order]
+        start = coef * res.poly[:, 1:].reshape(B, n - 1, 6, 3)[:, :, order, :]
+        scale = np.abs(start).max() + 1.0
+        assert np.abs(end - start)[ok].max() < fp_tol * scale
+    # the trajectory starts at x0
+    assert np.abs(res.poly[:, 0, :3] - batch.x0[:, :3]).max() < fp_tol * 20
+    # both output formats describe the same curve: Bezier control point 0 / 5 (time-scaled) = p(0) / p(T)
+    bez = res.bez.reshape(B, n, 3, 6)
+    p0 = res.poly[..., :3]
+    pT = poly_eval(res.poly, res.T, 0)
+    assert np.abs(bez[..., 0] * res.T[..., None] - p0)[ok].max() < fp_tol * 50
+    assert np.abs(bez[..., 5] * res.T[..., None] - pT)[ok].max() < fp_tol * 50
+    # durations respect T >= 0.3 (up to the fraction-to-boundary margin) and costs are finite
+    assert res.T[ok].min() > 0.29
+    assert np.isfinite(res.cost[ok]).all() and (res.cost[ok] > 0).all()
+
+
+def test_free_space_full_batch_fp32(built, free_batch):
+    s = solver.DdpSolver(B, N, free_batch.p_max, np.float32)
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    g0, g1 = s.plan(p0, p1, free_batch)
+    assert (g0.rtn == 2).all()            # zero init is feasible in free space: phase 0 exits at once
+    check_properties(free_batch, g1, 2e-4)
+    # determinism: a second run is bit-identical
+    h0, h1 = s.plan(p0, p1, free_batch)
+    assert np.array_equal(g1.bez, h1.bez) and np.array_equal(g1.rtn, h1.rtn) and np.array_equal(g1.cost, h1.cost)
+    # sharding invariance: solving a slice alone gives bit-identical results to solving it in the batch
+    sub = free_batch.select(np.arange(512, 768))
+    s0, s1 = s.plan(p0, p1, sub)
+    assert np.array_equal(s1.bez, g1.bez[512:768]) and np.array_equal(s1.iter_used, g1.iter_used[512:768])
+    # sample parity against the fp64 oracle
+    idx = np.array([0, 777, 2048, 4095])
+    r0, r1 = refapi.plan_batch(p0, p1, free_batch.select(idx))
+    conv = (r1.rtn == 1) & (g1.rtn[idx] == 1)
+    assert conv.any()
+    assert np.abs(g1.cost[idx] / r1.cost - 1)[conv].max() < 1e-2
+    # the final objective improved on the warm start for every converged problem
+    assert (g1.cost[g1.rtn == 1] < 1e4).all()
+    s.close()
+
+
+def test_corridor_full_batch_fp32(built, corridor_batch):
+    s = solver.DdpSolver(B, N, corridor_batch.p_max, np.float32)
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    g0, g1 = s.plan(p0, p1, corridor_batch)
+    found = g0.rtn == 2
+    assert found.mean() > 0.8
+    # phase 0 found a feasible trajectory: every (shifted) constraint is below 2e-4 for those problems
+    s.begin(p0, corridor_batch)
+    s.iterate(p0.iter_max)
+    c = s.get(abi.FIELD_C)
+    nc = 6 * corridor_batch.n_planes + 55
+    mask = np.arange(c.shape[2])[None, None, :] < nc[:, :, None]
+    cmax = np.where(mask, c, -np.inf).max(axis=(1, 2))
+    assert (cmax[found] < 2e-4).all()
+    check_properties(corridor_batch, g1, 5e-4)
+    s.close()
+
+
+def test_fixed_iteration_benchmark_mode_counts(built, free_batch):
+    """The benchmark workload: every problem executes exactly iter_max forward passes."""
+    s = solver.DdpSolver(B, N, free_batch.p_max, np.float32)
+    g0 = s.solve(abi.phase0_params(), free_batch)
+    b1 = free_batch.with_init(g0.bez, T0=np.where((g0.rtn == 2)[:, None], g0.T, free_batch.T0), infeas_in=g0.infeas_out)
+    g1 = s.solve(abi.phase1_params(iter_max=20, fixed_iters=1), b1)
+    assert (g1.fwd_passes == 20).all() and (g1.iter_used == 20).all()
+    ms, n = s.last_kernel_ms()
+    assert ms > 0 and n == 1
+    s.close()
+
+
+def test_fp64_sample_of_full_size_problems(built, corridor_batch):
+    """N = 100 corridors in fp64: exact agreement with the oracle on a sample of the config-3 batch."""
+    idx = np.array([3, 1500, 4000])
+    sub = corridor_batch.select(idx)
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    r0, r1 = refapi.plan_batch(p0, p1, sub)
+    s = solver.DdpSolver(3, N, sub.p_max, np.float64)
+    g0, g1 = s.plan(p0, p1, sub)
+    assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
+    assert (g1.rtn == r1.rtn).all()
+    same = g1.iter_used == r1.iter_used
+    assert same.all()
+    assert np.abs(g1.cost / r1.cost - 1).max() < 1e-7
+    assert helpers.rel(g1.T, r1.T) < 1e-5
+    s.close()
+
+
+def test_device_memory_interface_matches_host_interface(built, free_batch):
+    """Inputs and outputs resident in HBM (torch tensors as plain device pointers)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    import ctypes as C
+    sub = free_batch.select(np.arange(256)).astype(np.float32)
+    p0 = abi.phase0_params()
+    s = solver.DdpSolver(256, N, sub.p_max, np.float32)
+    want = s.solve(p0, sub)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(getattr(sub, k)).to(dev) for k in ("n_seg", "x0", "xd", "T0", "n_planes", "planes")}
+    cin = abi.BatchIn()
+    cin.batch, cin.n_seg_max, cin.p_max, cin.mem = 256, N, sub.p_max, abi.MEM_DEVICE
+    for k, v in t.items():
+        setattr(cin, k, v.data_ptr())
+    o = dict(rtn=torch.zeros(256, dtype=torch.int32, device=dev), cost=torch.zeros(256, device=dev),
+             bez=torch.zeros(256, N, 18, device=dev), T=torch.zeros(256, N, device=dev),
+             fwd_passes=torch.zeros(256, dtype=torch.int32, device=dev))
+    cout = abi.BatchOut()
+    cout.mem = abi.MEM_DEVICE
+    for k, v in o.items():
+        setattr(cout, k, v.data_ptr())
+    s.set_stream(torch.cuda.current_stream().cuda_stream)
+    s.solve_device(p0, cin, cout)
+    torch.cuda.synchronize()
+    assert np.array_equal(o["rtn"].cpu().numpy(), want.rtn)
+    assert np.array_equal(o["bez"].cpu().numpy(), want.bez)
+    assert np.array_equal(o["T"].cpu().numpy(), want.T)
+    s.close()

@@ -1,0 +1,158 @@
+"""Parity of the HIP path (through the C-ABI of include/direct_ddp.h) against the oracle and the
+golden vectors.  Tolerances: fp64 per-pass <= 1e-10 rel, whole solve identical
+rtn / iteration counts and cost <= 1e-8 rel; fp32 per-pass <= 1e-3 rel on gains, whole solve cost
+<= 5e-3 rel (discrete branches may differ, so iteration counts are not compared)."""
+import numpy as np
+import pytest
+
+from direct_amd import abi, problems, solver
+from oracle import refapi
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def make_solver(batch, dtype):
+    return solver.DdpSolver(batch.batch, batch.n_seg_max, batch.p_max, dtype)
+
+
+@pytest.mark.parametrize("kind,N", [("free", 5), ("corridor", 8), ("corridor", 20)])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 1e-3)])
+def test_one_backward_and_forward_pass(built, kind, N, dtype, tol):
+    batch = problems.make_batch(kind, 3, N, seed=7)
+    p0 = abi.phase0_params()
+    s = make_solver(batch, dtype)
+    s.begin(p0, batch)
+    r = [refapi.Stepper(p0, batch, i) for i in range(3)]
+    ncm = r[0].ncmax
+    assert max(helpers.rel(s.get(abi.FIELD_X)[i], r[i].get(abi.FIELD_X)) for i in range(3)) < tol * 1e-2
+    assert max(helpers.rel(s.get(abi.FIELD_C)[i][:, :ncm], r[i].get(abi.FIELD_C)) for i in range(3)) < tol * 1e-2
+    s.backward()
+    for q in r:
+        q.backward()
+    for f in (abi.FIELD_KU, abi.FIELD_KUU, abi.FIELD_KS, abi.FIELD_KY):
+        assert max(helpers.rel(s.get(f)[i], r[i].get(f)) for i in range(3)) < tol, f
+    sc = s.scalars()
+    for i in range(3):
+        assert abs(sc["opterr"][i] / r[i].scalars()["opterr"] - 1) < tol
+        assert sc["bp_failed"][i] == 0
+    s.forward()
+    for q in r:
+        q.forward()
+    sc = s.scalars()
+    for i in range(3):
+        rs = r[i].scalars()
+        assert sc["step"][i] == rs["step"] and sc["fp_failed"][i] == rs["fp_failed"]
+        assert abs(sc["cost"][i] / rs["cost"] - 1) < tol
+    for f in (abi.FIELD_X, abi.FIELD_U, abi.FIELD_S, abi.FIELD_Y):
+        assert max(helpers.rel(s.get(f)[i], r[i].get(f)) for i in range(3)) < tol, f
+    s.close()
+
+
+@pytest.mark.parametrize("name", helpers.CASES)
+def test_whole_solve_matches_golden_fp64(built, name):
+    g, batch = helpers.load_case(name)
+    p0, p1 = helpers.case_params(name)
+    s = make_solver(batch, np.float64)
+    helpers.check_result(s.solve(p0, batch), g, "p0_", 1e-9, T_tol=1e-8)
+    helpers.check_result(s.solve(p1, helpers.phase1_batch(g, batch)), g, "p1_", 1e-8, T_tol=1e-6)
+    # the fused two-phase entry point (teach_repeat_planner.cpp:886-921) gives the same answer
+    g0, g1 = s.plan(p0, p1, batch)
+    helpers.check_result(g0, g, "p0_", 1e-9, T_tol=1e-8)
+    helpers.check_result(g1, g, "p1_", 1e-8, T_tol=1e-6)
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["free_n5", "corridor_n8", "corridor_n8_minvo", "free_n6_tp1"])
+def test_whole_solve_fp32_tolerance(built, name):
+    g, batch = helpers.load_case(name)
+    p0, p1 = helpers.case_params(name)
+    s = make_solver(batch, np.float32)
+    f0 = s.solve(p0, batch)
+    assert (f0.rtn == g["p0_rtn"].astype(int)).all()
+    assert np.abs(f0.cost / g["p0_cost"] - 1).max() < 5e-3
+    f1 = s.solve(p1, helpers.phase1_batch(g, batch))
+    assert (f1.rtn >= 0).all()
+    assert np.abs(f1.cost / g["p1_cost"] - 1).max() < 5e-3, np.abs(f1.cost / g["p1_cost"] - 1).max()
+    assert helpers.rel(f1.T, g["p1_T"]) < 3e-2
+    s.close()
+
+
+def test_random_batch_against_oracle_fp64(built):
+    """64 corridors, N = 12, both phases: identical exits and iteration counts, cost 1e-8."""
+    batch = problems.make_batch("corridor", 64, 12, seed=123)
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    r0, r1 = refapi.plan_batch(p0, p1, batch)
+    s = make_solver(batch, np.float64)
+    g0, g1 = s.plan(p0, p1, batch)
+    assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
+    assert (g1.rtn == r1.rtn).all() and (g1.iter_used == r1.iter_used).all()
+    assert np.abs(g1.cost / r1.cost - 1).max() < 1e-8
+    assert helpers.rel(g1.bez, r1.bez) < 1e-6 and helpers.rel(g1.T, r1.T) < 1e-6
+    assert helpers.rel(g1.terminal_norm2, r1.terminal_norm2) < 1e-6
+    s.close()
+
+
+def test_ragged_batch_and_handle_reuse(built):
+    a = problems.make_batch("corridor", 2, 9, seed=31)
+    n_seg = np.array([9, 5], np.int32)
+    xd = a.xd.copy()
+    xd[1, :3] = a.seeds[1, 5]
+    T0 = problems.time_allocation(n_seg, a.x0[:, :3], xd[:, :3], a.seeds)
+    batch = abi.HostBatch(n_seg, a.x0, xd, T0, a.n_planes, a.planes, seeds=a.seeds)
+    p0 = abi.phase0_params()
+    r, _ = refapi.solve_batch(p0, batch)
+    s = make_solver(batch, np.float64)
+    for _ in range(2):  # the handle is reusable (the reference object is single-use, quirk Q9)
+        e = s.solve(p0, batch)
+        assert (e.rtn == r.rtn).all() and (e.iter_used == r.iter_used).all()
+        assert np.abs(e.cost / r.cost - 1).max() < 1e-9
+        assert helpers.rel(e.T[1, :5], r.T[1, :5]) < 1e-8
+    s.close()
+
+
+def test_many_planes_rpl3_and_rpl4(built):
+    """P up to 20 (nc = 175, 3 rows per lane) and 30 (nc = 235, 4 rows per lane)."""
+    for pmax in (20, 30):
+        batch = problems.make_batch("corridor", 4, 6, seed=5, p_max=pmax)
+        assert batch.n_planes.max() > 12
+        p0 = abi.phase0_params()
+        r, _ = refapi.solve_batch(p0, batch)
+        s = make_solver(batch, np.float64)
+        e = s.solve(p0, batch)
+        assert (e.rtn == r.rtn).all() and (e.iter_used == r.iter_used).all()
+        assert np.abs(e.cost / r.cost - 1).max() < 1e-8
+        s.close()
+
+
+def test_error_paths(built):
+    batch = problems.make_batch("free", 4, 5, seed=1)
+    s = make_solver(batch, np.float32)
+    with pytest.raises(solver.DirectError) as e:
+        s.solve(abi.phase0_params(time_power=3), batch)
+    assert e.value.status == abi.DIRECT_ERR_INVALID
+    with pytest.raises(solver.DirectError) as e:
+        s.solve(abi.phase0_params(line_init=1), batch)
+    assert e.value.status == abi.DIRECT_ERR_UNSUPPORTED
+    with pytest.raises(solver.DirectError) as e:
+        s.solve(abi.phase1_params(), batch)          # warm start without init_bez
+    assert e.value.status == abi.DIRECT_ERR_INVALID
+    big = problems.make_batch("free", 8, 5, seed=1)
+    with pytest.raises(solver.DirectError):
+        s.solve(abi.phase0_params(), big)            # batch > max_batch
+    bad = problems.make_batch("free", 4, 5, seed=1)
+    bad.n_planes[0, 0] = 99
+    with pytest.raises(solver.DirectError):
+        s.solve(abi.phase0_params(), bad)
+    s.close()
+
+
+def test_best_cost_reduction(built):
+    rng = np.random.default_rng(0)
+    cost = rng.uniform(1, 100, 1000).astype(np.float32)
+    rtn = rng.integers(-4, 3, 1000).astype(np.int32)
+    s = solver.DdpSolver(1000, 4, 6, np.float32)
+    i, c = s.best_cost(cost, rtn)
+    want = np.where(rtn >= 0, cost, np.inf)
+    assert i == int(np.argmin(want)) and abs(c - float(want.min())) < 1e-6
+    s.close()

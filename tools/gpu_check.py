@@ -60,7 +60,12 @@ def timing(kind, B, N, dtype, iters=20):
     s.close()
 
 if __name__ == "__main__":
-    print("abi", solver.lib().direct_ddp_abi_version(), flush=True)
+    print("abi", solver.lib().direct_ddp_abi_version(), solver.LIB_PATH, flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "timing":
+        timing("free", 4096, 100, np.float32)
+        timing("corridor", 4096, 100, np.float32)
+        timing("free", 4096, 100, np.float64)
+        sys.exit(0)
     for dt in (np.float64, np.float32):
         per_pass("free", 5, dt)
         per_pass("corridor", 8, dt)
