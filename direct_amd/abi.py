@@ -51,7 +51,7 @@ class BatchIn(C.Structure):
         ("batch", C.c_int32), ("n_seg_max", C.c_int32), ("p_max", C.c_int32), ("mem", C.c_int32),
         ("n_seg", C.c_void_p), ("x0", C.c_void_p), ("xd", C.c_void_p), ("T0", C.c_void_p),
         ("n_planes", C.c_void_p), ("planes", C.c_void_p), ("seeds", C.c_void_p),
-        ("init_bez", C.c_void_p), ("infeas_in", C.c_void_p),
+        ("init_bez", C.c_void_p), ("infeas_in", C.c_void_p), ("init_poly", C.c_void_p),
     ]
 
 
@@ -103,7 +103,7 @@ class HostBatch:
     """Host-side (numpy) batch of corridors in the flat layout of include/direct_ddp.h."""
 
     def __init__(self, n_seg, x0, xd, T0, n_planes, planes, seeds=None, init_bez=None,
-                 infeas_in=None, dtype=np.float64):
+                 infeas_in=None, dtype=np.float64, init_poly=None):
         self.dtype = np.dtype(dtype)
         self.n_seg = np.ascontiguousarray(n_seg, dtype=np.int32)
         self.batch = int(self.n_seg.shape[0])
@@ -118,6 +118,7 @@ class HostBatch:
         self.seeds = None if seeds is None else np.ascontiguousarray(seeds, dtype=self.dtype)
         self.init_bez = None if init_bez is None else np.ascontiguousarray(init_bez, dtype=self.dtype)
         self.infeas_in = None if infeas_in is None else np.ascontiguousarray(infeas_in, dtype=np.uint8)
+        self.init_poly = None if init_poly is None else np.ascontiguousarray(init_poly, dtype=self.dtype)
 
     @property
     def nc_max(self):
@@ -125,18 +126,18 @@ class HostBatch:
 
     def astype(self, dtype):
         return HostBatch(self.n_seg, self.x0, self.xd, self.T0, self.n_planes, self.planes,
-                         self.seeds, self.init_bez, self.infeas_in, dtype=dtype)
+                         self.seeds, self.init_bez, self.infeas_in, dtype=dtype, init_poly=self.init_poly)
 
     def select(self, idx):
         idx = np.atleast_1d(np.asarray(idx))
         f = lambda a: None if a is None else a[idx]
         return HostBatch(self.n_seg[idx], self.x0[idx], self.xd[idx], self.T0[idx],
                          self.n_planes[idx], self.planes[idx], f(self.seeds), f(self.init_bez),
-                         f(self.infeas_in), dtype=self.dtype)
+                         f(self.infeas_in), dtype=self.dtype, init_poly=f(self.init_poly))
 
-    def with_init(self, init_bez, T0=None, infeas_in=None):
+    def with_init(self, init_bez, T0=None, infeas_in=None, init_poly=None):
         return HostBatch(self.n_seg, self.x0, self.xd, self.T0 if T0 is None else T0, self.n_planes,
-                         self.planes, self.seeds, init_bez, infeas_in, dtype=self.dtype)
+                         self.planes, self.seeds, init_bez, infeas_in, dtype=self.dtype, init_poly=init_poly)
 
     def c_struct(self):
         s = BatchIn()
@@ -145,6 +146,7 @@ class HostBatch:
         s.x0, s.xd, s.T0 = _ptr(self.x0), _ptr(self.xd), _ptr(self.T0)
         s.n_planes, s.planes = _ptr(self.n_planes), _ptr(self.planes)
         s.seeds, s.init_bez, s.infeas_in = _ptr(self.seeds), _ptr(self.init_bez), _ptr(self.infeas_in)
+        s.init_poly = _ptr(self.init_poly)
         return s
 
 

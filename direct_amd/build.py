@@ -11,7 +11,7 @@ OUT = os.path.join(_HERE, "lib", "libdirect_ddp.so")
 
 # occupancy targets of the hot kernel (waves per SIMD): see DESIGN.md "Occupancy"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-DDDP_WAVES_F32=4", "-DDDP_WAVES_F64=2"]
+         "-DDDP_WAVES_F32=2", "-DDDP_WAVES_F64=2"]
 
 
 def hipcc():

@@ -142,8 +142,9 @@ struct Batch {
   const int32_t* n_planes;
   const Real* planes;
   const Real* init_bez;
+  const Real* init_poly;
   const uint8_t* infeas_in;
-  Real* X[2];   // [B][nmax+1][20]: x_k (9), u_k (10), pad
+  Real* X[2];   // [B][nmax+1][kXS]: x_k (9), u_k (10), position low words (3), pad
   Real* S[2];   // [B][nmax][ncs]
   Real* Y[2];   // [B][nmax][ncs]
   Real* KU;     // [B][nmax][100]: ku (10), Ku (10x9 row-major)
@@ -154,7 +155,8 @@ struct Batch {
   SolveConst k;
 };
 
-constexpr int kXS = 20;  // knot record stride of X
+constexpr int kXS = 24;  // knot record stride of X: x (9), u (10), low parts of the position (3), pad (2)
+typedef double Acc;      // accumulator type of the condensed system (see WaveLds)
 
 // ---- LDS (one per wave) ------------------------------------------------------------------------
 template <typename Real, int RPL>
@@ -171,14 +173,23 @@ struct WaveLds {
   Real We[90];
   Real val[48], dval[48], valn[48], G[48];
   Real drow[64 * RPL], grow[64 * RPL];
-  Real Sp[36], dl[27], Sd[48], hh[48], last[4];
-  Real H[18], Hp[18], fT[12];
-  Real Ru[9], Rpu[9], Rppu[9], qp[12];
-  Real V[81], Vx[12];
-  Real VZ[176];
-  Real Hzz[361], Hz[20];
-  Real KU[100];
-  Real W1[81], W2[90], t10[10], hk[10];
+  Real H[18], Hp[18], qp[12];
+  Real KUr[100];  // gains of the knot as stored in HBM (forward pass)
+  // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
+  // even when Real = float: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in fp32
+  // over ~100 knots (the fp32 solver stalls at 2-3x the fp64 cost, DESIGN.md "Precision").
+  Acc Sp[36], dl[27], Sd[48], hh[48], last[4];
+  Acc fT[12], Ru[9], Rpu[9], Rppu[9];
+  Acc V[81], Vx[12];
+  Acc Hzz[361], Hz[20];
+  Acc KU[100];
+  union {
+    Acc VZ[176];  // Vxx * Z: dead after phase H
+    struct {
+      Acc W1[81], W2[90];  // Hxu Ku, Huu Ku: born in phase G
+    };
+  };
+  Acc t10[10], hk[10];
 };
 
 template <typename Real>
@@ -222,22 +233,37 @@ DDP_DEV RowD row_decode(int r, int P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename Real, int RPL>
+// Real = arithmetic type of the per-row / roll-out work, St = storage type of everything in HBM
+// (the dtype of the C-ABI), Acc (double) = type of the condensed system.
+template <typename Real, typename St, int RPL>
 struct Wave {
   typedef WaveLds<Real, RPL> Lds;
-  const Batch<Real>& B;
+  const Batch<St>& B;
   Lds& L;
   TrajState& st;
   const int b;  // trajectory
   int N;        // segments
 
-  DDP_DEV Wave(const Batch<Real>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
+  DDP_DEV Wave(const Batch<St>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
 
-  DDP_DEV Real* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * kXS; }
-  DDP_DEV Real* Sp_(Real* base, int k) const { return base + ((size_t)b * B.nmax + k) * B.ncs; }
-  DDP_DEV const Real* planes_(int k) const { return B.planes + ((size_t)b * B.nmax + k) * B.pmax * 4; }
+  DDP_DEV St* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * kXS; }
+  DDP_DEV St* Sp_(St* base, int k) const { return base + ((size_t)b * B.nmax + k) * B.ncs; }
+  DDP_DEV const St* planes_(int k) const { return B.planes + ((size_t)b * B.nmax + k) * B.pmax * 4; }
   DDP_DEV int np_(int k) const { return B.n_planes[(size_t)b * B.nmax + k]; }
-  DDP_DEV Real* KUp(int k) const { return B.KU + ((size_t)b * B.nmax + k) * 100; }
+  DDP_DEV St* KUp(int k) const { return B.KU + ((size_t)b * B.nmax + k) * 100; }
+  // Knot-record access.  Positions reach hundreds of metres while a barrier step must resolve
+  // ~1e-7 of the log-cost, so with float storage the three position words are kept as an unevaluated
+  // hi + lo pair (words a and 19 + a); every other entry is O(1) and a single word suffices.
+  DDP_DEV Real ldx(const St* rec, int a) const {
+    Real v = (Real)rec[a];
+    if (sizeof(St) < sizeof(double) && a < 3) v += (Real)rec[19 + a];
+    return v;
+  }
+  DDP_DEV void stx(St* rec, int a, Real v) const {
+    const St hi = (St)v;
+    rec[a] = hi;
+    if (sizeof(St) < sizeof(double) && a < 3) rec[19 + a] = (St)(v - (Real)hi);
+  }
 
   DDP_DEV void load_state() {
     const TrajState* g = &B.st[b];
@@ -396,7 +422,7 @@ struct Wave {
       const int P = np_(k);
       const int nc = 6 * P + 55;
       LANES {
-        if (lane < 19) L.z[lane] = Xp(buf, k)[lane];
+        if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
         for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
       }
       WSYNC();
@@ -412,7 +438,7 @@ struct Wave {
       WSYNC();
       qsum += knot_cost(T);
       LANES {
-        const Real* yk = Sp_(B.Y[buf], k);
+        const St* yk = Sp_(B.Y[buf], k);
         for (int i = 0; i < RPL; i++) {
           int r = lane + 64 * i;
           if (r < nc) {
@@ -428,12 +454,12 @@ struct Wave {
             if (c >= (Real)2.0e-4) LV(nviol)++;
           }
         }
-        if (do_roll && lane < 9) Xp(buf, k + 1)[lane] = L.xnx[lane];
+        if (do_roll && lane < 9) stx(Xp(buf, k + 1), lane, L.xnx[lane]);
       }
       WSYNC();
     }
     LANES {
-      if (lane < 9) L.z[lane] = Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane];
+      if (lane < 9) L.z[lane] = ldx(Xp(buf, N), lane) - (Real)B.xd[(size_t)b * 9 + lane];
     }
     WSYNC();
     const double pterm = terminal_sq();  // DDP:1289-1292
@@ -472,25 +498,28 @@ struct Wave {
     st.infeas = B.infeas_in ? (int)B.infeas_in[b] : 0;
     st.infeas_ref = st.infeas;
     st.line_failed = 1;
-    const Real* T0 = B.T0 + (size_t)b * B.nmax;
+    const St* T0 = B.T0 + (size_t)b * B.nmax;
     LANES {
-      if (lane < 9) Xp(0, 0)[lane] = B.x0[(size_t)b * 9 + lane];
+      if (lane < 9) stx(Xp(0, 0), lane, (Real)B.x0[(size_t)b * 9 + lane]);
       // u: zero init (DDP:126-127) or the tail of the Bezier->poly row (DDP:167-193)
       for (int k = lane; k < N; k += 64) {
-        Real* u = Xp(0, k) + 9;
+        St* u = Xp(0, k) + 9;
         Real T = T0[k];
-        if (B.k.zero_init || B.init_bez == nullptr) {
-          for (int a = 0; a < 9; a++) u[a] = 0;
+        if (B.k.zero_init || (B.init_bez == nullptr && B.init_poly == nullptr)) {
+          for (int a = 0; a < 9; a++) u[a] = (St)0;
+        } else if (B.init_poly != nullptr) {  // extension: monomial warm start, u = [c3; c4; c5]
+          const St* row = B.init_poly + ((size_t)b * B.nmax + k) * 18;
+          for (int a = 0; a < 9; a++) u[a] = row[9 + a];
         } else {
-          const Real* row = B.init_bez + ((size_t)b * B.nmax + k) * 18;  // [x0..x5,y0..y5,z0..z5]
+          const St* row = B.init_bez + ((size_t)b * B.nmax + k) * 18;  // [x0..x5,y0..y5,z0..z5]
           for (int i = 3; i < 6; i++)
             for (int d = 0; d < 3; d++) {
               Real acc = 0;
-              for (int l = 0; l < 6; l++) acc += (Real)kBez2Mono[l][i] * (T * row[d * 6 + l]);
-              u[(i - 3) * 3 + d] = acc / powi(T, i);
+              for (int l = 0; l < 6; l++) acc += (Real)kBez2Mono[l][i] * (T * (Real)row[d * 6 + l]);
+              u[(i - 3) * 3 + d] = (St)(acc / powi(T, i));
             }
         }
-        u[9] = T;
+        u[9] = (St)T;
       }
     }
     for (int k = 0; k < N; k++) {  // s = 0.1, y = 0.01 (DDP:150-151)
@@ -499,8 +528,8 @@ struct Wave {
         for (int i = 0; i < RPL; i++) {
           int r = lane + 64 * i;
           if (r < nc) {
-            Sp_(B.S[0], k)[r] = (Real)0.1;
-            Sp_(B.Y[0], k)[r] = (Real)0.01;
+            Sp_(B.S[0], k)[r] = (St)0.1;
+            Sp_(B.Y[0], k)[r] = (St)0.01;
           }
         }
       }
@@ -535,24 +564,24 @@ struct Wave {
     const int regi = DDP_UNIFORM_I(st.reg);
     double lam_d = 1.0;
     for (int q = 0; q < regi; q++) lam_d *= B.k.reg_base;
-    const Real lam = (Real)(lam_d - 1.0);  // DDP:529
+    const Acc lam = (Acc)(lam_d - 1.0);  // DDP:529
     const int buf = DDP_UNIFORM_I(st.cur);
     const int infeas = DDP_UNIFORM_I(st.infeas);
     const Real mu = (Real)st.mu;
     const Real wsn = (Real)B.k.w_snap;
-    const Real sig = infeas ? (Real)1 : (Real)-1;
+    const Acc sig = infeas ? (Acc)1 : (Acc)-1;
 
     // terminal derivatives (DDP:1318-1323)
     LANES {
 #pragma unroll 1
-      for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Real)B.k.w_term : (Real)0;
-      if (lane < 9) L.Vx[lane] = (Real)B.k.w_term * (Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane]);
+      for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Acc)B.k.w_term : (Acc)0;
+      if (lane < 9) L.Vx[lane] = (Acc)B.k.w_term * (Acc)(ldx(Xp(buf, N), lane) - (Real)B.xd[(size_t)b * 9 + lane]);
     }
     WSYNC();
     PLV(Real, e_mu);
     PLV(Real, e_c);
     LANES { LV(e_mu) = 0; LV(e_c) = 0; }
-    Real qu_err = 0;
+    Acc qu_err = 0;
 
 #pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
@@ -564,7 +593,7 @@ struct Wave {
       PLA(Real, rr, RPL);  // r (feasible) or rhat (infeasible)
       // ---- L: load the knot
       LANES {
-        if (lane < 19) L.z[lane] = Xp(buf, k)[lane];
+        if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
         for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
         for (int i = 0; i < RPL; i++) {
           int r = lane + 64 * i;
@@ -606,7 +635,7 @@ struct Wave {
         }
         if (lane < 27) {  // Ru, R'u, R''u (DDP:1349-1355)
           int t = lane / 9, a9 = lane % 9, a = a9 / 3, d = a9 % 3;
-          Real acc = 0;
+          Acc acc = 0;
 #pragma unroll
           for (int a2 = 0; a2 < 3; a2++) {
             int e = a + a2 + 1 - t;
@@ -615,11 +644,11 @@ struct Wave {
             if (t == 2) cf *= (Real)(a + a2);
             acc += cf * L.tp[e < 0 ? 0 : e] * L.z[9 + 3 * a2 + d];  // cf is 0 where e < 0
           }
-          Real* dst = (t == 0) ? L.Ru : (t == 1 ? L.Rpu : L.Rppu);
+          Acc* dst = (t == 0) ? L.Ru : (t == 1 ? L.Rpu : L.Rppu);
           dst[a9] = acc;
         } else if (lane < 36) {
           int a = lane - 27, c = a / 3, d = a % 3;
-          Real acc = 0;
+          Acc acc = 0;
 #pragma unroll
           for (int i = 0; i < 6; i++) acc += L.Hp[c * 6 + i] * L.z[3 * i + d];
           L.fT[a] = acc;  // DDP:1332
@@ -658,7 +687,7 @@ struct Wave {
 #pragma unroll 1
         for (int e = lane; e < 171; e += 64) {  // VZ[a][q]
           int a = e / 19, q = e % 19;
-          Real acc = 0;
+          Acc acc = 0;
           if (q < 18) {
             int i = q / 3, d = q % 3;
 #pragma unroll
@@ -688,7 +717,7 @@ struct Wave {
             d1 = 3;
             w = L.grow;
           }
-          Real acc = 0;
+          Acc acc = 0;
 #pragma unroll 2
           for (int q = 0; q < P; q++) {
             const Real* n = &L.pl[4 * q];
@@ -707,8 +736,8 @@ struct Wave {
             rp = 6 * P + 30 + (lane - 15);
             rm = rp + 12;
           }
-          L.dl[lane] = L.drow[rp] + L.drow[rm];
-          L.hh[18 + lane] = L.grow[rp] - L.grow[rm];
+          L.dl[lane] = (Acc)L.drow[rp] + (Acc)L.drow[rm];
+          L.hh[18 + lane] = (Acc)L.grow[rp] - (Acc)L.grow[rm];
         }
         if (lane == 63) {
           L.last[0] = L.drow[nc - 1];
@@ -720,9 +749,9 @@ struct Wave {
       LANES {
         if (lane < 45) {
           int cr = lane / 3, d = lane % 3;
-          Real acc;
+          Acc acc;
           if (cr < 6) {
-            const Real* S = &L.Sp[cr * 6];  // xx,xy,xz,yy,yz,zz
+            const Acc* S = &L.Sp[cr * 6];  // xx,xy,xz,yy,yz,zz
             const Real* dv = &L.dval[cr * 3];
             if (d == 0) acc = S[0] * dv[0] + S[1] * dv[1] + S[2] * dv[2];
             else if (d == 1) acc = S[1] * dv[0] + S[3] * dv[1] + S[4] * dv[2];
@@ -743,7 +772,7 @@ struct Wave {
           const int se = d * 3 - (d * (d - 1)) / 2 + (d2 - d);  // d <= d2 when i == i2; S is symmetric
           const int se2 = d2 * 3 - (d2 * (d2 - 1)) / 2 + (d - d2);
           const int sidx = (d <= d2) ? se : se2;
-          Real ada = 0, zvz = 0;
+          Acc ada = 0, zvz = 0;
 #pragma unroll
           for (int cr = 0; cr < 6; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.Sp[cr * 6 + sidx];
           if (d == d2) {
@@ -752,36 +781,36 @@ struct Wave {
           }
 #pragma unroll
           for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + q];
-          Real quu = 0;
+          Acc quu = 0;
           if (i >= 3 && d == d2) quu = wsn * L.Rc[(i - 3) * 3 + (i2 - 3)] * L.tp[i + i2 - 5];
-          const Real v = zvz + quu + sig * ada;
+          const Acc v = zvz + quu + sig * ada;
           L.Hzz[p * 19 + q] = v;
           L.Hzz[q * 19 + p] = v;
         }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
           const int p = lane < 18 ? lane : lane - 18;
           const int i = p / 3, d = p % 3;
-          const Real* vec = lane < 18 ? L.Sd : L.hh;
-          Real acc = 0;
+          const Acc* vec = lane < 18 ? L.Sd : L.hh;
+          Acc acc = 0;
 #pragma unroll 5
           for (int cr = 0; cr < 15; cr++) acc += L.We[cr * 6 + i] * vec[cr * 3 + d];
           if (lane < 18) {
-            Real zvz = 0;
+            Acc zvz = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
-            const Real v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Real)0) + sig * acc;
+            const Acc v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Acc)0) + sig * acc;
             L.Hzz[p * 19 + 18] = v;
             L.Hzz[18 * 19 + p] = v;
           } else {
-            Real zv = 0;
+            Acc zv = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) zv += L.H[c * 6 + i] * L.Vx[3 * c + d];
-            L.Hz[p] = ((i >= 3) ? wsn * L.Ru[p - 9] : (Real)0) + zv + acc;
+            L.Hz[p] = ((i >= 3) ? wsn * L.Ru[p - 9] : (Acc)0) + zv + acc;
           }
         } else if (lane < 38) {  // (T,T) entry (lane 36) and Hz[T] (lane 37)
-          const Real* vec = lane == 36 ? L.Sd : L.hh;
-          const Real* rv = lane == 36 ? L.Rppu : L.Rpu;
-          Real acc = 0, zv = 0, uru = 0;
+          const Acc* vec = lane == 36 ? L.Sd : L.hh;
+          const Acc* rv = lane == 36 ? L.Rppu : L.Rpu;
+          Acc acc = 0, zv = 0, uru = 0;
 #pragma unroll 5
           for (int t = 0; t < 45; t++) acc += L.dval[t] * vec[t];
 #pragma unroll 3
@@ -790,22 +819,22 @@ struct Wave {
             uru += L.z[9 + a] * rv[a];
           }
           if (lane == 36) {
-            const Real quu = ((B.k.time_power == 2) ? (Real)B.k.w_time : (Real)0) + (Real)0.5 * wsn * uru;
+            const Acc quu = ((B.k.time_power == 2) ? (Acc)B.k.w_time : (Acc)0) + (Acc)0.5 * wsn * uru;
             L.Hzz[18 * 19 + 18] = zv + quu + sig * (acc + L.last[0]);
           } else {
-            const Real qz = ((B.k.time_power == 2) ? (Real)B.k.w_time * T : (Real)0.5 * (Real)B.k.w_time) + (Real)0.5 * wsn * uru;
+            const Acc qz = ((B.k.time_power == 2) ? (Acc)B.k.w_time * T : (Acc)0.5 * (Acc)B.k.w_time) + (Acc)0.5 * wsn * uru;
             L.Hz[18] = qz + zv + (acc - L.last[1]);
           }
         }
       }
       WSYNC();
       // ---- C: LLT of Huu + lam I and the 10 right-hand sides, one column per lane
-      PLA(Real, m, 10);
+      PLA(Acc, m, 10);
       LANES {
 #pragma unroll
         for (int a = 0; a < 10; a++) {
-          Real v = 0;
-          if (lane < 10) v = L.Hzz[(9 + a) * 19 + 9 + lane] + ((a == lane) ? lam : (Real)0);
+          Acc v = 0;
+          if (lane < 10) v = L.Hzz[(9 + a) * 19 + 9 + lane] + ((a == lane) ? lam : (Acc)0);
           else if (lane == 10) v = L.Hz[9 + a];
           else if (lane < 20) v = L.Hzz[(9 + a) * 19 + (lane - 11)];
           LV(m)[a] = v;
@@ -814,14 +843,14 @@ struct Wave {
       int ok = 1;
 #pragma unroll
       for (int kk = 0; kk < 10; kk++) {
-        Real piv = RDLANE(m, kk, kk);
-        if (piv <= (Real)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
-        Real rinv = (Real)1 / sqrt(piv);
-        Real l[10];
+        Acc piv = RDLANE(m, kk, kk);
+        if (piv <= (Acc)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
+        Acc rinv = (Acc)1 / sqrt(piv);
+        Acc l[10];
 #pragma unroll
         for (int i = kk + 1; i < 10; i++) l[i] = RDLANE(m, i, kk) * rinv;
         LANES {
-          Real mk = LV(m)[kk] * rinv;
+          Acc mk = LV(m)[kk] * rinv;
           LV(m)[kk] = mk;
 #pragma unroll
           for (int i = kk + 1; i < 10; i++) LV(m)[i] -= l[i] * mk;
@@ -835,12 +864,12 @@ struct Wave {
       }
 #pragma unroll
       for (int i = 9; i >= 0; i--) {
-        Real dinv = (Real)1 / RDLANE(m, i, i);
-        Real uij[10];
+        Acc dinv = (Acc)1 / RDLANE(m, i, i);
+        Acc uij[10];
 #pragma unroll
         for (int j = i + 1; j < 10; j++) uij[j] = RDLANE(m, i, j);
         LANES {
-          Real acc = LV(m)[i];
+          Acc acc = LV(m)[i];
 #pragma unroll
           for (int j = i + 1; j < 10; j++) acc -= uij[j] * LV(m)[j];
           if (lane >= 10) LV(m)[i] = acc * dinv;
@@ -861,22 +890,22 @@ struct Wave {
       LANES {
         if (lane < 45) {
           int cr = lane / 3, d = lane % 3;
-          Real acc = L.dval[lane] * L.KU[9];
+          Acc acc = L.dval[lane] * L.KU[9];
 #pragma unroll
           for (int i = 3; i < 6; i++) acc += L.We[cr * 6 + i] * L.KU[(i - 3) * 3 + d];
-          L.G[lane] = acc;
+          L.G[lane] = (Real)acc;
         }
 #pragma unroll 1
         for (int e = lane; e < 190; e += 64) {
           // W1 = Hxu Ku (81) | W2 = Huu Ku (90) | t10 = Huu ku (10) | hk = Hxu ku (9): all 10-term dots
           int hrow, koff, kstr;
-          Real* dst;
+          Acc* dst;
           if (e < 81) { hrow = e / 9; koff = 10 + e % 9; kstr = 9; dst = &L.W1[e]; }
           else if (e < 171) { hrow = 9 + (e - 81) / 9; koff = 10 + (e - 81) % 9; kstr = 9; dst = &L.W2[e - 81]; }
           else if (e < 181) { hrow = 9 + (e - 171); koff = 0; kstr = 1; dst = &L.t10[e - 171]; }
           else { hrow = e - 181; koff = 0; kstr = 1; dst = &L.hk[e - 181]; }
-          const Real* hp = &L.Hzz[hrow * 19 + 9];
-          Real acc = 0;
+          const Acc* hp = &L.Hzz[hrow * 19 + 9];
+          Acc acc = 0;
 #pragma unroll 5
           for (int c = 0; c < 10; c++) acc += hp[c] * L.KU[koff + c * kstr];
           *dst = acc;
@@ -884,16 +913,16 @@ struct Wave {
       }
       WSYNC();
       {  // DDP:633 (quirk Q10): Qu after the condensation correction
-        Real m0 = 0;
+        Acc m0 = 0;
 #pragma unroll
         for (int a = 0; a < 10; a++) m0 = fmax(m0, fabs(L.Hz[9 + a]));
         qu_err = fmax(qu_err, m0);
       }
       // ---- R2: slack / dual gains per row; V recursion; gains to HBM
       LANES {
-        Real* ksg = Sp_(B.KS, k);
-        Real* kyg = Sp_(B.KY, k);
-        const Real kuT = L.KU[9];
+        St* ksg = Sp_(B.KS, k);
+        St* kyg = Sp_(B.KY, k);
+        const Real kuT = (Real)L.KU[9];
         for (int i = 0; i < RPL; i++) {
           int r = lane + 64 * i;
           if (r < nc) {
@@ -902,15 +931,15 @@ struct Wave {
             Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
             if (infeas) {  // DDP:568, 571
               Real y = LV(ry)[i];
-              ksg[r] = (rv + s * cuku) / y;
-              kyg[r] = -(c + y) - cuku;
+              ksg[r] = (St)((rv + s * cuku) / y);
+              kyg[r] = (St)(-(c + y) - cuku);
             } else {  // DDP:611
-              ksg[r] = -((rv + s * cuku) / c);
+              ksg[r] = (St)(-((rv + s * cuku) / c));
             }
           }
         }
 #pragma unroll 1
-        for (int e = lane; e < 100; e += 64) KUp(k)[e] = L.KU[e];
+        for (int e = lane; e < 100; e += 64) KUp(k)[e] = (St)L.KU[e];
         if (lane < 45) {  // Vxx (DDP:627-628), pairs a <= c2.  V is dead since phase R1: overwrite in place
           int a = 0, rem = lane;
           while (rem >= 9 - a) {
@@ -918,19 +947,19 @@ struct Wave {
             a++;
           }
           const int c2 = a + rem;
-          Real m1 = L.Hzz[a * 19 + c2] + L.W1[a * 9 + c2] + L.W1[c2 * 9 + a];
-          Real m2 = m1;
+          Acc m1 = L.Hzz[a * 19 + c2] + L.W1[a * 9 + c2] + L.W1[c2 * 9 + a];
+          Acc m2 = m1;
 #pragma unroll 5
           for (int c = 0; c < 10; c++) {
             m1 += L.KU[10 + c * 9 + a] * L.W2[c * 9 + c2];
             m2 += L.KU[10 + c * 9 + c2] * L.W2[c * 9 + a];
           }
-          const Real vnew = (Real)0.5 * (m1 + m2);
+          const Acc vnew = (Acc)0.5 * (m1 + m2);
           L.V[a * 9 + c2] = vnew;
           L.V[c2 * 9 + a] = vnew;
         } else if (lane < 54) {  // Vx (DDP:626); Vx is dead since phase H
           const int aa = lane - 45;
-          Real v2 = L.Hz[aa] + L.hk[aa];
+          Acc v2 = L.Hz[aa] + L.hk[aa];
 #pragma unroll 5
           for (int c = 0; c < 10; c++) v2 += L.KU[10 + c * 9 + aa] * (L.Hz[9 + c] + L.t10[c]);
           L.Vx[aa] = v2;
@@ -967,7 +996,7 @@ struct Wave {
       PLV(int, nviol);
       LANES {
         LV(slog) = 0; LV(serr) = 0; LV(nviol) = 0;
-        if (lane < 9) L.xn[lane] = Xp(cur, 0)[lane];
+        if (lane < 9) L.xn[lane] = ldx(Xp(cur, 0), lane);
       }
       WSYNC();
       double qsum = 0.0;
@@ -982,9 +1011,9 @@ struct Wave {
         PLA(Real, rks, RPL);
         PLA(Real, rky, RPL);
         LANES {
-          if (lane < 19) L.z[lane] = Xp(cur, k)[lane];
+          if (lane < 19) L.z[lane] = ldx(Xp(cur, k), lane);
 #pragma unroll 1
-          for (int e = lane; e < 100; e += 64) L.KU[e] = KUp(k)[e];
+          for (int e = lane; e < 100; e += 64) L.KUr[e] = KUp(k)[e];
           for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
           for (int i = 0; i < RPL; i++) {
             int r = lane + 64 * i;
@@ -1005,9 +1034,11 @@ struct Wave {
             int a = lane - 9;
             Real acc = 0;
 #pragma unroll 3
-            for (int c = 0; c < 9; c++) acc += L.KU[10 + a * 9 + c] * (L.xn[c] - L.z[c]);
+            for (int c = 0; c < 9; c++) acc += L.KUr[10 + a * 9 + c] * (L.xn[c] - L.z[c]);
             L.dz[lane] = acc;
-            Real un = L.z[lane] + alpha * L.KU[a] + acc;
+            // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
+            // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
+            Real un = (Real)(St)(L.z[lane] + alpha * L.KUr[a] + acc);
             L.zn[lane] = un;
             if (lane == 18) {
               Real pw = 1;
@@ -1052,8 +1083,8 @@ struct Wave {
         PLV(int, bad);
         LANES {
           LV(bad) = 0;
-          Real* sn = Sp_(B.S[nxt], k);
-          Real* yn = Sp_(B.Y[nxt], k);
+          St* sn = Sp_(B.S[nxt], k);
+          St* yn = Sp_(B.Y[nxt], k);
           const Real dzT = L.dz[18];
           for (int i = 0; i < RPL; i++) {
             int r = lane + 64 * i;
@@ -1065,23 +1096,23 @@ struct Wave {
               Real snew;
               if (infeas) {  // DDP:680-687
                 Real y = LV(ry)[i];
-                Real ynew = y + alpha * LV(rky)[i] - az;
-                snew = s + alpha * LV(rks)[i] + (s / y) * az;
+                Real ynew = (Real)(St)(y + alpha * LV(rky)[i] - az);
+                snew = (Real)(St)(s + alpha * LV(rks)[i] + (s / y) * az);
                 if (ynew < omt * y || snew < omt * s) LV(bad) = 1;
-                yn[r] = ynew;
+                yn[r] = (St)ynew;
                 LV(slog) += log(ynew);
                 LV(serr) += fabs(cn + ynew);
               } else {  // DDP:694-703
                 Real co = row_c(L.val, rd, To);
-                snew = s + alpha * LV(rks)[i] - (s / co) * az;
+                snew = (Real)(St)(s + alpha * LV(rks)[i] - (s / co) * az);
                 if (cn > omt * co || snew < omt * s) LV(bad) = 1;
                 LV(slog) += log(-cn);
               }
-              sn[r] = snew;
+              sn[r] = (St)snew;
               if (cn >= (Real)2.0e-4) LV(nviol)++;
             }
           }
-          if (lane < 19) Xp(nxt, k)[lane] = L.zn[lane];
+          if (lane < 19) stx(Xp(nxt, k), lane, L.zn[lane]);
           if (lane < 9) L.xn[lane] = L.xnx[lane];
         }
         failed = WAVE_ANY(bad);
@@ -1091,7 +1122,7 @@ struct Wave {
       if (failed) continue;
       LANES {
         if (lane < 9) {
-          Xp(nxt, N)[lane] = L.xn[lane];
+          stx(Xp(nxt, N), lane, L.xn[lane]);
           L.z[lane] = L.xn[lane] - B.xd[(size_t)b * 9 + lane];
         }
       }
@@ -1236,15 +1267,17 @@ struct OutPtrs {
   Real *cost, *costq, *jerk_cost, *terminal_norm2, *opterr, *mu, *bez, *poly, *T;
 };
 
-template <typename Real, int RPL>
-DDP_DEV void finish_wave(Wave<Real, RPL>& W, const OutPtrs<Real>& O) {
-  const Batch<Real>& B = W.B;
+template <typename Real, typename St, int RPL>
+DDP_DEV void finish_wave(Wave<Real, St, RPL>& W, const OutPtrs<St>& O) {
+  const Batch<St>& B = W.B;
   const int b = W.b, N = W.N, buf = W.st.cur;
   PLV(Real, jc);
   LANES {
     LV(jc) = 0;
     for (int k = lane; k < N; k += 64) {
-      const Real* zz = W.Xp(buf, k);
+      const St* zs = W.Xp(buf, k);
+      Real zz[19];
+      for (int a = 0; a < 19; a++) zz[a] = W.ldx(zs, a);
       Real T = zz[18], acc = 0;  // finalroll, DDP:1624-1634
       for (int a = 0; a < 3; a++)
         for (int a2 = 0; a2 < 3; a2++) {
@@ -1257,15 +1290,15 @@ DDP_DEV void finish_wave(Wave<Real, RPL>& W, const OutPtrs<Real>& O) {
       for (int a = 0; a < 9; a++) poly[9 + a] = zz[9 + a];
       size_t row = ((size_t)b * B.nmax + k) * 18;
       if (O.poly)
-        for (int a = 0; a < 18; a++) O.poly[row + a] = poly[a];
-      if (O.T) O.T[(size_t)b * B.nmax + k] = T;
+        for (int a = 0; a < 18; a++) O.poly[row + a] = (St)poly[a];
+      if (O.T) O.T[(size_t)b * B.nmax + k] = (St)T;
       if (O.bez) {  // poly2bezFunc + layout swap, DDP:799-812, 430-436
         Real invT = (Real)1 / T;
         for (int j = 0; j < 6; j++)
           for (int d = 0; d < 3; d++) {
             Real acc2 = 0;
             for (int i = 0; i < 6; i++) acc2 += (invT * poly[3 * i + d]) * powi(T, i) * (Real)kMono2Bez[i][j];
-            O.bez[row + d * 6 + j] = acc2;
+            O.bez[row + d * 6 + j] = (St)acc2;
           }
       }
     }
@@ -1275,7 +1308,7 @@ DDP_DEV void finish_wave(Wave<Real, RPL>& W, const OutPtrs<Real>& O) {
   LANES {
     LV(tn) = 0;
     if (lane < 9) {
-      Real d = W.Xp(buf, N)[lane] - B.xd[(size_t)b * 9 + lane];
+      Real d = W.ldx(W.Xp(buf, N), lane) - (Real)B.xd[(size_t)b * 9 + lane];
       LV(tn) = d * d;
     }
   }
@@ -1288,38 +1321,38 @@ DDP_DEV void finish_wave(Wave<Real, RPL>& W, const OutPtrs<Real>& O) {
       if (O.fwd_passes) O.fwd_passes[b] = s.fwd_passes;
       if (O.infeas_out) O.infeas_out[b] = (uint8_t)s.infeas_ref;
       if (O.line_failed_out) O.line_failed_out[b] = (uint8_t)s.line_failed;
-      if (O.cost) O.cost[b] = (Real)s.cost;
-      if (O.costq) O.costq[b] = (Real)s.costq;
-      if (O.jerk_cost) O.jerk_cost[b] = (Real)jsum;
-      if (O.terminal_norm2) O.terminal_norm2[b] = (Real)tsum;
-      if (O.opterr) O.opterr[b] = (Real)s.opterr;
-      if (O.mu) O.mu[b] = (Real)s.mu;
+      if (O.cost) O.cost[b] = (St)s.cost;
+      if (O.costq) O.costq[b] = (St)s.costq;
+      if (O.jerk_cost) O.jerk_cost[b] = (St)jsum;
+      if (O.terminal_norm2) O.terminal_norm2[b] = (St)tsum;
+      if (O.opterr) O.opterr[b] = (St)s.opterr;
+      if (O.mu) O.mu[b] = (St)s.mu;
     }
   }
 }
 
 // ---- stepwise interface helpers: dense read-out / injection of solver fields --------------------
 // Field ids and layouts: include/direct_ddp.h (direct_field_t); nc_max = 6*pmax + 55.
-template <typename Real, int RPL>
-DDP_DEV void get_field_wave(Wave<Real, RPL>& W, int field, Real* dst) {
-  const Batch<Real>& B = W.B;
+template <typename Real, typename St, int RPL>
+DDP_DEV void get_field_wave(Wave<Real, St, RPL>& W, int field, St* dst) {
+  const Batch<St>& B = W.B;
   const int b = W.b, N = W.N, buf = W.st.cur, ncm = 6 * B.pmax + 55;
   if (field == 9) {
     const TrajState& s = W.st;
-    Real* o = dst + (size_t)b * 16;
+    St* o = dst + (size_t)b * 16;
     LANES {
       if (lane == 0) {
-        o[0] = (Real)s.cost; o[1] = (Real)s.costq; o[2] = (Real)s.logcost; o[3] = (Real)s.err;
-        o[4] = (Real)s.mu; o[5] = (Real)s.reg; o[6] = (Real)s.opterr; o[7] = (Real)s.stepsize;
-        o[8] = (Real)s.step; o[9] = (Real)s.fp_failed; o[10] = (Real)s.bp_failed; o[11] = (Real)s.rtn;
-        o[12] = (Real)s.iter; o[13] = (Real)s.done; o[14] = (Real)s.nfilter; o[15] = (Real)s.infeas;
+        o[0] = (St)s.cost; o[1] = (St)s.costq; o[2] = (St)s.logcost; o[3] = (St)s.err;
+        o[4] = (St)s.mu; o[5] = (St)s.reg; o[6] = (St)s.opterr; o[7] = (St)s.stepsize;
+        o[8] = (St)s.step; o[9] = (St)s.fp_failed; o[10] = (St)s.bp_failed; o[11] = (St)s.rtn;
+        o[12] = (St)s.iter; o[13] = (St)s.done; o[14] = (St)s.nfilter; o[15] = (St)s.infeas;
       }
     }
     return;
   }
   if (field == 0) {
     LANES {
-      for (int e = lane; e < (N + 1) * 9; e += 64) dst[(size_t)b * (B.nmax + 1) * 9 + e] = W.Xp(buf, e / 9)[e % 9];
+      for (int e = lane; e < (N + 1) * 9; e += 64) dst[(size_t)b * (B.nmax + 1) * 9 + e] = (St)W.ldx(W.Xp(buf, e / 9), e % 9);
     }
     return;
   }
@@ -1334,7 +1367,7 @@ DDP_DEV void get_field_wave(Wave<Real, RPL>& W, int field, Real* dst) {
       LANES { for (int e = lane; e < 90; e += 64) dst[((size_t)b * B.nmax + k) * 90 + e] = W.KUp(k)[10 + e]; }
     } else if (field == 4) {
       LANES {
-        if (lane < 19) W.L.z[lane] = W.Xp(buf, k)[lane];
+        if (lane < 19) W.L.z[lane] = W.ldx(W.Xp(buf, k), lane);
         for (int e = lane; e < 4 * P; e += 64) W.L.pl[e] = W.planes_(k)[e];
       }
       WSYNC();
@@ -1344,24 +1377,24 @@ DDP_DEV void get_field_wave(Wave<Real, RPL>& W, int field, Real* dst) {
       LANES { if (lane < 45) W.L.val[lane] = W.ctrl_val(W.L.z, W.L.tp, lane / 3, lane % 3); }
       WSYNC();
       LANES {
-        for (int r = lane; r < nc; r += 64) dst[rowbase + r] = W.row_c(W.L.val, row_decode(r, P), T);
+        for (int r = lane; r < nc; r += 64) dst[rowbase + r] = (St)W.row_c(W.L.val, row_decode(r, P), T);
       }
       WSYNC();
     } else {
-      const Real* src = (field == 2) ? W.Sp_(B.S[buf], k) : (field == 3) ? W.Sp_(B.Y[buf], k)
+      const St* src = (field == 2) ? W.Sp_(B.S[buf], k) : (field == 3) ? W.Sp_(B.Y[buf], k)
                         : (field == 7) ? W.Sp_(B.KS, k) : W.Sp_(B.KY, k);
       LANES { for (int r = lane; r < nc; r += 64) dst[rowbase + r] = src[r]; }
     }
   }
 }
 
-template <typename Real, int RPL>
-DDP_DEV void set_field_wave(Wave<Real, RPL>& W, int field, const Real* src) {
-  const Batch<Real>& B = W.B;
+template <typename Real, typename St, int RPL>
+DDP_DEV void set_field_wave(Wave<Real, St, RPL>& W, int field, const St* src) {
+  const Batch<St>& B = W.B;
   const int b = W.b, N = W.N, buf = W.st.cur, ncm = 6 * B.pmax + 55;
   if (field == 0) {
     LANES {
-      for (int e = lane; e < (N + 1) * 9; e += 64) W.Xp(buf, e / 9)[e % 9] = src[(size_t)b * (B.nmax + 1) * 9 + e];
+      for (int e = lane; e < (N + 1) * 9; e += 64) W.stx(W.Xp(buf, e / 9), e % 9, (Real)src[(size_t)b * (B.nmax + 1) * 9 + e]);
     }
     return;
   }
@@ -1371,7 +1404,7 @@ DDP_DEV void set_field_wave(Wave<Real, RPL>& W, int field, const Real* src) {
     if (field == 1) {
       LANES { if (lane < 10) W.Xp(buf, k)[9 + lane] = src[((size_t)b * B.nmax + k) * 10 + lane]; }
     } else if (field == 2 || field == 3) {
-      Real* d = (field == 2) ? W.Sp_(B.S[buf], k) : W.Sp_(B.Y[buf], k);
+      St* d = (field == 2) ? W.Sp_(B.S[buf], k) : W.Sp_(B.Y[buf], k);
       LANES { for (int r = lane; r < nc; r += 64) d[r] = src[rowbase + r]; }
     }
   }

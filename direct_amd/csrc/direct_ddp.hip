@@ -23,25 +23,28 @@ using namespace direct;
 #ifndef DDP_WAVES_F64
 #define DDP_WAVES_F64 1
 #endif
-template <typename Real>
+// Arithmetic is double for both storage types (DESIGN.md "Precision"): St = float halves the HBM
+// traffic, it does not change the arithmetic.
+typedef double Cmp;
+template <typename St>
 struct MinWaves { static constexpr int v = DDP_WAVES_F32; };
 template <>
 struct MinWaves<double> { static constexpr int v = DDP_WAVES_F64; };
 
-template <typename Real, int RPL>
-__global__ __launch_bounds__(64) void k_begin(Batch<Real> B) {
-  __shared__ WaveLds<Real, RPL> lds;
-  Wave<Real, RPL> W(B, lds, blockIdx.x);
+template <typename St, int RPL>
+__global__ __launch_bounds__(64) void k_begin(Batch<St> B) {
+  __shared__ WaveLds<Cmp, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.init_tables();
   W.begin();
   W.store_state();
 }
 
 // the hot kernel: n trips of the outer loop (ddp_optimizer.cpp:295-412) per trajectory
-template <typename Real, int RPL>
-__global__ __launch_bounds__(64, MinWaves<Real>::v) void k_iterate(Batch<Real> B, int n_iters) {
-  __shared__ WaveLds<Real, RPL> lds;
-  Wave<Real, RPL> W(B, lds, blockIdx.x);
+template <typename St, int RPL>
+__global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate(Batch<St> B, int n_iters) {
+  __shared__ WaveLds<Cmp, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
@@ -50,10 +53,10 @@ __global__ __launch_bounds__(64, MinWaves<Real>::v) void k_iterate(Batch<Real> B
 }
 
 // stepwise interface: mode 1 = one backwardpass(), 2 = one forwardpass()
-template <typename Real, int RPL>
-__global__ __launch_bounds__(64) void k_pass(Batch<Real> B, int mode) {
-  __shared__ WaveLds<Real, RPL> lds;
-  Wave<Real, RPL> W(B, lds, blockIdx.x);
+template <typename St, int RPL>
+__global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
+  __shared__ WaveLds<Cmp, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
@@ -62,22 +65,22 @@ __global__ __launch_bounds__(64) void k_pass(Batch<Real> B, int mode) {
   W.store_state();
 }
 
-template <typename Real, int RPL>
-__global__ __launch_bounds__(64) void k_finish(Batch<Real> B, OutPtrs<Real> O) {
-  __shared__ WaveLds<Real, RPL> lds;
-  Wave<Real, RPL> W(B, lds, blockIdx.x);
+template <typename St, int RPL>
+__global__ __launch_bounds__(64) void k_finish(Batch<St> B, OutPtrs<St> O) {
+  __shared__ WaveLds<Cmp, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   W.init_tables();
   finish_wave(W, O);
 }
 
-template <typename Real, int RPL>
-__global__ __launch_bounds__(64) void k_field(Batch<Real> B, int field, Real* buf, int set) {
-  __shared__ WaveLds<Real, RPL> lds;
-  Wave<Real, RPL> W(B, lds, blockIdx.x);
+template <typename St, int RPL>
+__global__ __launch_bounds__(64) void k_field(Batch<St> B, int field, St* buf, int set) {
+  __shared__ WaveLds<Cmp, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   W.init_tables();
-  if (set) set_field_wave(W, field, (const Real*)buf);
+  if (set) set_field_wave(W, field, (const St*)buf);
   else get_field_wave(W, field, buf);
 }
 
@@ -149,6 +152,7 @@ struct direct_ddp_handle_s {
   bool timed = false;
   // device buffers
   void *x0 = nullptr, *xd = nullptr, *T0 = nullptr, *planes = nullptr, *init_bez = nullptr, *T_next = nullptr;
+  void* init_poly = nullptr;
   int32_t *n_seg = nullptr, *n_planes = nullptr;
   uint8_t *infeas_in = nullptr, *infeas_next = nullptr;
   void *X[2] = {nullptr, nullptr}, *S[2] = {nullptr, nullptr}, *Y[2] = {nullptr, nullptr};
@@ -195,6 +199,7 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   B.B = in.batch; B.nmax = h->nmax; B.pmax = h->pmax; B.ncs = h->ncs; B.fcap = h->fcap;
   B.n_seg = in.n_seg; B.x0 = (const Real*)in.x0; B.xd = (const Real*)in.xd; B.T0 = (const Real*)in.T0;
   B.n_planes = in.n_planes; B.planes = (const Real*)in.planes; B.init_bez = (const Real*)in.init_bez;
+  B.init_poly = (const Real*)in.init_poly;
   B.infeas_in = in.infeas_in;
   for (int i = 0; i < 2; i++) {
     B.X[i] = (Real*)h->X[i]; B.S[i] = (Real*)h->S[i]; B.Y[i] = (Real*)h->Y[i];
@@ -286,7 +291,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   direct_status_t st = DIRECT_OK;
   auto A = [&](auto pp, size_t bytes) { if (st == DIRECT_OK) st = dalloc(h, pp, bytes); };
   A(&h->x0, B * 9 * r); A(&h->xd, B * 9 * r); A(&h->T0, B * nm * r); A(&h->T_next, B * nm * r);
-  A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r);
+  A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r); A(&h->init_poly, B * nm * 18 * r);
   A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B); A(&h->infeas_next, B);
   for (int i = 0; i < 2; i++) {
     A(&h->X[i], B * (nm + 1) * kXS * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
@@ -347,7 +352,8 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
     return fail(DIRECT_ERR_INVALID, "n_seg_max / p_max differ from the handle's configuration");
   if (!in->n_seg || !in->x0 || !in->xd || !in->T0 || !in->n_planes || !in->planes)
     return fail(DIRECT_ERR_INVALID, "null input array");
-  if (!p->zero_init && !in->init_bez) return fail(DIRECT_ERR_INVALID, "init_bez required unless zero_init");
+  if (!p->zero_init && !in->init_bez && !in->init_poly)
+    return fail(DIRECT_ERR_INVALID, "init_bez (or init_poly) required unless zero_init");
   HIP_TRY(hipSetDevice(h->device));
   const size_t B = in->batch, nm = h->nmax, r = h->rsz;
   direct_ddp_batch_in_t d = *in;
@@ -368,6 +374,7 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
     HIP_TRY(up(h->n_planes, in->n_planes, B * nm * 4)); d.n_planes = h->n_planes;
     HIP_TRY(up(h->planes, in->planes, B * nm * h->pmax * 4 * r)); d.planes = h->planes;
     if (in->init_bez) { HIP_TRY(up(h->init_bez, in->init_bez, B * nm * 18 * r)); d.init_bez = h->init_bez; }
+    if (in->init_poly) { HIP_TRY(up(h->init_poly, in->init_poly, B * nm * 18 * r)); d.init_poly = h->init_poly; }
     if (in->infeas_in) { HIP_TRY(up(h->infeas_in, in->infeas_in, B)); d.infeas_in = h->infeas_in; }
   }
   if (!in->infeas_in) {
@@ -505,10 +512,13 @@ direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_pa
     hipLaunchKernelGGL(k_chain<float>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->B, h->nmax, h->o.rtn,
                        (const float*)h->o.T, (const float*)h->cur_in.T0, h->o.infeas_out, (float*)h->T_next, h->infeas_next);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h->init_bez, h->o.bez, (size_t)h->B * h->nmax * 18 * h->rsz, hipMemcpyDeviceToDevice, h->stream));
+  // TRP:918 hands over Bezier control points; the same trajectory is handed over here as its monomial
+  // coefficients (getPolyCoeff), which is exact in double and well conditioned in float
+  HIP_TRY(hipMemcpyAsync(h->init_poly, h->o.poly, (size_t)h->B * h->nmax * 18 * h->rsz, hipMemcpyDeviceToDevice, h->stream));
   direct_ddp_batch_in_t in1 = h->cur_in;  // device pointers
   in1.T0 = h->T_next;
-  in1.init_bez = h->init_bez;
+  in1.init_bez = nullptr;
+  in1.init_poly = h->init_poly;
   in1.infeas_in = h->infeas_next;
   TRY(stage_inputs(h, p1, &in1));
   TRY(launch_begin(h));

@@ -24,6 +24,7 @@
  *   seeds[b][k][3]              Polytope.seed_coord (line-init only, may be NULL)
  *   init_bez[b][k][18]          initbezCoeff row [x0..x5,y0..y5,z0..z5], time-scaled
  *                               (ddp_optimizer.cpp:167); ignored when zero_init
+ *   init_poly[b][k][18]         optional replacement of init_bez: getPolyCoeff() rows
  *   k runs over 0..n_seg[b]-1; strides use n_seg_max and p_max.
  */
 #ifndef DIRECT_DDP_H_
@@ -91,6 +92,11 @@ typedef struct {
   const void* seeds;         /* [batch][n_seg_max][3] Real or NULL */
   const void* init_bez;      /* [batch][n_seg_max][18] Real or NULL */
   const uint8_t* infeas_in;  /* [batch] or NULL (then params.infeas) */
+  /* Extension (no reference counterpart): warm start as monomial coefficients in the getPolyCoeff()
+   * layout [c0xyz..c5xyz] per segment; when non-NULL it replaces init_bez.  World-frame Bezier
+   * control points are an ill-conditioned hand-off in fp32 (c3..c5 are 5th-order differences of
+   * numbers of magnitude |position|/T), so phase chaining in float should use this. */
+  const void* init_poly;     /* [batch][n_seg_max][18] Real or NULL */
 } direct_ddp_batch_in_t;
 
 /* What the getters of ddp_optimizer.h:299-340 return, per problem.  Any pointer may be NULL. */

@@ -117,8 +117,8 @@ typedef struct {
   int iter, rtn, fwd_passes, line_failed, infeas_ref;
   int bp_no_upd_count, no_upd_count;
   double prev_cost, prev_costq;
-  /* scratch for forwardpass */
-  double *xn, *un, *cn, *sn, *yn, *qn;
+  /* scratch for forwardpass / backwardpass */
+  double *xn, *un, *cn, *sn, *yn, *qn, *bw_scratch;
   /* optional per-iteration trace: cost, costq, logcost, err, mu, reg, step, opterr, stepsize, fp_failed */
   double* trace;
   int trace_cap;
@@ -580,12 +580,12 @@ static void backwardpass(ref_t* r) {
   memcpy(Vx, r->px, sizeof Vx);
   memcpy(Vxx, r->pxx, sizeof Vxx);
   int ncm = r->ncmax;
-  double* SDcu = (double*)malloc(sizeof(double) * (size_t)ncm * 10);
-  double* SDcx = (double*)malloc(sizeof(double) * (size_t)ncm * 9);
-  double* rr = (double*)malloc(sizeof(double) * (size_t)ncm * 4);
+  double* SDcu = r->bw_scratch; /* preallocated in ref_begin: [ncm*10 | ncm*9 | ncm*4 | ncm*9 | ncm] */
+  double* SDcx = SDcu + (size_t)ncm * 10;
+  double* rr = SDcx + (size_t)ncm * 9;
   double *rhat = rr + ncm, *dinv = rr + 2 * ncm, *tv2 = rr + 3 * ncm;
-  double* cxpcuKu = (double*)malloc(sizeof(double) * (size_t)ncm * 9);
-  double* cuiku = (double*)malloc(sizeof(double) * (size_t)ncm);
+  double* cxpcuKu = rr + (size_t)ncm * 4;
+  double* cuiku = cxpcuKu + (size_t)ncm * 9;
 
   for (int i = N - 1; i >= 0; i--) {
     int nc = r->nc[i];
@@ -774,11 +774,7 @@ static void backwardpass(ref_t* r) {
   r->dV[0] = dV[0];
   r->dV[1] = dV[1];
 done:
-  free(SDcu);
-  free(SDcx);
-  free(rr);
-  free(cxpcuKu);
-  free(cuiku);
+  return;
 }
 
 /* DDP:647-778 forwardpass */
@@ -1004,7 +1000,7 @@ static double* dalloc(size_t n) {
 
 typedef struct {
   int N, pmax;
-  const double *x0, *xd, *T0, *planes, *seeds, *init_bez;
+  const double *x0, *xd, *T0, *planes, *seeds, *init_bez, *init_poly;
   const int* n_planes;
   int infeas;
 } ref_problem_t;
@@ -1016,7 +1012,7 @@ static void ref_free(ref_t* r) {
   free(r->fx); free(r->fu); free(r->qu); free(r->quu); free(r->cx); free(r->cu);
   free(r->filter);
   free(r->ku); free(r->Ku); free(r->ks); free(r->ky); free(r->Ks); free(r->Ky);
-  free(r->xn); free(r->un); free(r->cn); free(r->sn); free(r->yn); free(r->qn);
+  free(r->xn); free(r->un); free(r->cn); free(r->sn); free(r->yn); free(r->qn); free(r->bw_scratch);
   free(r->trace);
   free(r);
 }
@@ -1078,6 +1074,7 @@ static ref_t* ref_begin(const ref_problem_t* pb, const direct_ddp_params_t* pr, 
   r->sn = dalloc((size_t)N * ncm);
   r->yn = dalloc((size_t)N * ncm);
   r->qn = dalloc((size_t)N);
+  r->bw_scratch = dalloc((size_t)ncm * 33);
   r->filter_cap = 2 * (pr->iter_max + 8);
   r->filter = dalloc((size_t)2 * r->filter_cap);
   r->trace_cap = trace_cap;
@@ -1094,7 +1091,10 @@ static ref_t* ref_begin(const ref_problem_t* pb, const direct_ddp_params_t* pr, 
   }
   /* DDP:167-193: initial u from the Bezier warm start */
   if (!pr->zero_init) {
-    if (!pr->line_init) {
+    if (!pr->line_init && pb->init_poly) { /* C-ABI extension: monomial warm start (no reference counterpart) */
+      for (int i = 0; i < N; i++)
+        for (int a = 0; a < 9; a++) r->u[(size_t)i * 10 + a] = pb->init_poly[(size_t)i * 18 + 9 + a];
+    } else if (!pr->line_init) {
       for (int i = 0; i < N; i++) {
         double il[18], poly[18];
         const double* row = pb->init_bez + (size_t)i * 18;
@@ -1312,6 +1312,7 @@ static void fill_problem(ref_problem_t* pb, const direct_ddp_batch_in_t* in, int
   pb->planes = (const double*)in->planes + (size_t)b * nm * in->p_max * 4;
   pb->seeds = in->seeds ? (const double*)in->seeds + (size_t)b * nm * 3 : NULL;
   pb->init_bez = in->init_bez ? (const double*)in->init_bez + (size_t)b * nm * 18 : NULL;
+  pb->init_poly = in->init_poly ? (const double*)in->init_poly + (size_t)b * nm * 18 : NULL;
   pb->infeas = in->infeas_in ? in->infeas_in[b] : pr->infeas;
 }
 
@@ -1383,6 +1384,7 @@ int direct_ref_plan_batch(const direct_ddp_params_t* p0, const direct_ddp_params
     ref_problem_t pb1 = pb;
     if (rtn0 == 2) pb1.T0 = T0n; /* UpdateTime, TRP:911-915 */
     pb1.init_bez = bez0;         /* TRP:918 */
+    pb1.init_poly = NULL;
     pb1.infeas = infeas;
     ref_t* r1 = ref_begin(&pb1, p1, 0);
     ref_run(r1);

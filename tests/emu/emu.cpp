@@ -13,10 +13,11 @@
 
 using namespace direct;
 
-template <typename Real>
+template <typename Real>   // Real = storage type here; the compute type is chosen per call
 struct Emu {
   Batch<Real> B;
-  std::vector<Real> x0, xd, T0, planes, init_bez, X0, X1, S0, S1, Y0, Y1, KU, KS, KY;
+  int compute64 = 0;
+  std::vector<Real> x0, xd, T0, planes, init_bez, init_poly, X0, X1, S0, S1, Y0, Y1, KU, KS, KY;
   std::vector<int32_t> n_seg, n_planes;
   std::vector<uint8_t> infeas_in;
   std::vector<double> filt;
@@ -24,25 +25,31 @@ struct Emu {
   int rpl;
 };
 
-template <typename Real, int RPL, typename F>
+template <typename Cmp, typename Real, int RPL, typename F>
 static void for_each_wave(Emu<Real>& E, F f) {
-  static WaveLds<Real, RPL> lds;
+  static WaveLds<Cmp, RPL> lds;
   for (int b = 0; b < E.B.B; b++) {
-    Wave<Real, RPL> W(E.B, lds, b);
+    Wave<Cmp, Real, RPL> W(E.B, lds, b);
     f(W);
   }
 }
 
+template <typename Cmp, typename Real, typename F>
+static void dispatch_c(Emu<Real>& E, F f) {
+  if (E.rpl <= 2) for_each_wave<Cmp, Real, 2>(E, f);
+  else if (E.rpl == 3) for_each_wave<Cmp, Real, 3>(E, f);
+  else for_each_wave<Cmp, Real, 4>(E, f);
+}
 template <typename Real, typename F>
 static void dispatch(Emu<Real>& E, F f) {
-  if (E.rpl <= 2) for_each_wave<Real, 2>(E, f);
-  else if (E.rpl == 3) for_each_wave<Real, 3>(E, f);
-  else for_each_wave<Real, 4>(E, f);
+  if (E.compute64) dispatch_c<double, Real>(E, f);
+  else dispatch_c<Real, Real>(E, f);
 }
 
 template <typename Real>
-static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in) {
+static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in, int compute64) {
   Emu<Real>* E = new Emu<Real>();
+  E->compute64 = compute64;
   int B = in->batch, nm = in->n_seg_max, pm = in->p_max;
   int ncm = 6 * pm + 55;
   E->rpl = (ncm + 63) / 64;
@@ -59,6 +66,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   cp(E->T0, in->T0, (size_t)B * nm);
   cp(E->planes, in->planes, (size_t)B * nm * pm * 4);
   if (in->init_bez) cp(E->init_bez, in->init_bez, (size_t)B * nm * 18);
+  if (in->init_poly) cp(E->init_poly, in->init_poly, (size_t)B * nm * 18);
   E->infeas_in.assign(B, (uint8_t)p->infeas);
   if (in->infeas_in) E->infeas_in.assign(in->infeas_in, in->infeas_in + B);
   size_t nx = (size_t)B * (nm + 1) * kXS, ns = (size_t)B * nm * ncm;
@@ -70,6 +78,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   Bt.n_seg = E->n_seg.data(); Bt.x0 = E->x0.data(); Bt.xd = E->xd.data(); Bt.T0 = E->T0.data();
   Bt.n_planes = E->n_planes.data(); Bt.planes = E->planes.data();
   Bt.init_bez = in->init_bez ? E->init_bez.data() : nullptr;
+  Bt.init_poly = in->init_poly ? E->init_poly.data() : nullptr;
   Bt.infeas_in = E->infeas_in.data();
   Bt.X[0] = E->X0.data(); Bt.X[1] = E->X1.data(); Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data();
   Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
@@ -106,8 +115,8 @@ struct EmuHandle {
 extern "C" {
 void* emu_begin(int dtype, const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in) {
   EmuHandle* h = new EmuHandle();
-  h->dtype = dtype;
-  h->p = dtype == DIRECT_F64 ? (void*)emu_begin_t<double>(p, in) : (void*)emu_begin_t<float>(p, in);
+  h->dtype = dtype == DIRECT_F64 ? DIRECT_F64 : DIRECT_F32;   // dtype 2: fp32 storage, fp64 arithmetic
+  h->p = dtype == DIRECT_F64 ? (void*)emu_begin_t<double>(p, in, 1) : (void*)emu_begin_t<float>(p, in, dtype == 2);
   return h;
 }
 #define EMU_CALL(body)                                            \

@@ -39,12 +39,12 @@ def lib():
 
 
 class EmuSolver:
-    def __init__(self, params, batch, dtype=np.float64):
+    def __init__(self, params, batch, dtype=np.float64, compute64=False):
         self.np_dtype = np.dtype(dtype)
         self.batch = batch if batch.dtype == self.np_dtype else batch.astype(self.np_dtype)
         self._cin = self.batch.c_struct()
         self.params = params
-        code = abi.F64 if self.np_dtype == np.float64 else abi.F32
+        code = abi.F64 if self.np_dtype == np.float64 else (2 if compute64 else abi.F32)
         self.h = lib().emu_begin(code, C.addressof(params), C.addressof(self._cin))
 
     def close(self):
@@ -93,8 +93,8 @@ class EmuSolver:
         return res
 
 
-def solve_batch(params, batch, dtype=np.float64):
-    s = EmuSolver(params, batch, dtype)
+def solve_batch(params, batch, dtype=np.float64, compute64=False):
+    s = EmuSolver(params, batch, dtype, compute64)
     s.iterate(params.iter_max)
     res = s.finish()
     s.close()

@@ -1,7 +1,9 @@
 """Parity of the HIP path (through the C-ABI of include/direct_ddp.h) against the oracle and the
-golden vectors.  Tolerances: fp64 per-pass <= 1e-10 rel, whole solve identical
-rtn / iteration counts and cost <= 1e-8 rel; fp32 per-pass <= 1e-3 rel on gains, whole solve cost
-<= 5e-3 rel (discrete branches may differ, so iteration counts are not compared)."""
+golden vectors.  Tolerances: DIRECT_F64: per-pass <= 1e-10 rel, whole solve identical rtn / iteration
+counts and cost <= 1e-8 rel (1e-6 on a 64-problem batch).  DIRECT_F32 = float STORAGE with double
+arithmetic (DESIGN.md "Precision"): the oracle is given the same float-rounded inputs; per-pass
+<= 2e-5 rel (storage rounding of s, y, gains), whole solve cost <= 2e-2 rel at natural exits, which
+are stagnation tests (ddp_optimizer.cpp:374) and may fire an iteration apart."""
 import numpy as np
 import pytest
 
@@ -17,16 +19,16 @@ def make_solver(batch, dtype):
 
 
 @pytest.mark.parametrize("kind,N", [("free", 5), ("corridor", 8), ("corridor", 20)])
-@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 1e-3)])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 2e-5)])
 def test_one_backward_and_forward_pass(built, kind, N, dtype, tol):
-    batch = problems.make_batch(kind, 3, N, seed=7)
+    batch = problems.make_batch(kind, 3, N, seed=7).astype(dtype).astype(np.float64)  # same inputs for both
     p0 = abi.phase0_params()
     s = make_solver(batch, dtype)
     s.begin(p0, batch)
     r = [refapi.Stepper(p0, batch, i) for i in range(3)]
     ncm = r[0].ncmax
-    assert max(helpers.rel(s.get(abi.FIELD_X)[i], r[i].get(abi.FIELD_X)) for i in range(3)) < tol * 1e-2
-    assert max(helpers.rel(s.get(abi.FIELD_C)[i][:, :ncm], r[i].get(abi.FIELD_C)) for i in range(3)) < tol * 1e-2
+    assert max(helpers.rel(s.get(abi.FIELD_X)[i], r[i].get(abi.FIELD_X)) for i in range(3)) < max(tol * 1e-2, 1e-7 * (dtype == np.float32))
+    assert max(helpers.rel(s.get(abi.FIELD_C)[i][:, :ncm], r[i].get(abi.FIELD_C)) for i in range(3)) < max(tol * 1e-2, 1e-6 * (dtype == np.float32))
     s.backward()
     for q in r:
         q.backward()
@@ -70,11 +72,15 @@ def test_whole_solve_fp32_tolerance(built, name):
     s = make_solver(batch, np.float32)
     f0 = s.solve(p0, batch)
     assert (f0.rtn == g["p0_rtn"].astype(int)).all()
-    assert np.abs(f0.cost / g["p0_cost"] - 1).max() < 5e-3
-    f1 = s.solve(p1, helpers.phase1_batch(g, batch))
-    assert (f1.rtn >= 0).all()
-    assert np.abs(f1.cost / g["p1_cost"] - 1).max() < 5e-3, np.abs(f1.cost / g["p1_cost"] - 1).max()
-    assert helpers.rel(f1.T, g["p1_T"]) < 3e-2
+    assert (f0.iter_used == g["p0_iter_used"].astype(int)).all()
+    assert np.abs(f0.cost / g["p0_cost"] - 1).max() < 1e-4
+    b1 = helpers.phase1_batch(g, batch)
+    f1 = s.solve(p1, b1.with_init(None, T0=b1.T0, infeas_in=b1.infeas_in, init_poly=g["p0_poly"]))
+    assert (f1.rtn == g["p1_rtn"].astype(int)).all()
+    assert np.abs(f1.cost / g["p1_cost"] - 1).max() < 2e-2, np.abs(f1.cost / g["p1_cost"] - 1).max()
+    assert helpers.rel(f1.T, g["p1_T"]) < 5e-2
+    same = f1.iter_used == g["p1_iter_used"].astype(int)
+    assert np.abs(f1.cost / g["p1_cost"] - 1)[same].max(initial=0) < 1e-3
     s.close()
 
 
@@ -87,9 +93,11 @@ def test_random_batch_against_oracle_fp64(built):
     g0, g1 = s.plan(p0, p1, batch)
     assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
     assert (g1.rtn == r1.rtn).all() and (g1.iter_used == r1.iter_used).all()
-    assert np.abs(g1.cost / r1.cost - 1).max() < 1e-8
-    assert helpers.rel(g1.bez, r1.bez) < 1e-6 and helpers.rel(g1.T, r1.T) < 1e-6
-    assert helpers.rel(g1.terminal_norm2, r1.terminal_norm2) < 1e-6
+    # the fused plan hands the warm start over as monomial coefficients, the oracle as Bezier points:
+    # identical in exact arithmetic, ~1e-7 apart after 10-20 ill-conditioned iterations
+    assert np.abs(g1.cost / r1.cost - 1).max() < 1e-6
+    assert helpers.rel(g1.bez, r1.bez) < 1e-4 and helpers.rel(g1.T, r1.T) < 1e-4
+    assert helpers.rel(g1.terminal_norm2, r1.terminal_norm2) < 1e-4
     s.close()
 
 
@@ -135,7 +143,7 @@ def test_error_paths(built):
         s.solve(abi.phase0_params(line_init=1), batch)
     assert e.value.status == abi.DIRECT_ERR_UNSUPPORTED
     with pytest.raises(solver.DirectError) as e:
-        s.solve(abi.phase1_params(), batch)          # warm start without init_bez
+        s.solve(abi.phase1_params(), batch)          # warm start without init_bez / init_poly
     assert e.value.status == abi.DIRECT_ERR_INVALID
     big = problems.make_batch("free", 8, 5, seed=1)
     with pytest.raises(solver.DirectError):

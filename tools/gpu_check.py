@@ -46,7 +46,7 @@ def timing(kind, B, N, dtype, iters=20):
     s = solver.DdpSolver(B, N, b.p_max, dtype)
     t = time.time(); g0 = s.solve(p0, b); t0 = time.time() - t
     ms0, _ = s.last_kernel_ms()
-    b1 = b.with_init(g0.bez, T0=np.where((g0.rtn == 2)[:, None], g0.T, b.T0), infeas_in=g0.infeas_out)
+    b1 = b.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, b.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
     pf = abi.phase1_params(iter_max=iters, fixed_iters=1)
     t = time.time(); g1 = s.solve(pf, b1); t1 = time.time() - t
     ms1, _ = s.last_kernel_ms()

@@ -11,7 +11,7 @@ iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 b = problems.make_batch(kind, B, N, seed=1000)
 s = solver.DdpSolver(B, N, b.p_max, dt)
 g0 = s.solve(abi.phase0_params(), b)
-b1 = b.with_init(g0.bez, T0=np.where((g0.rtn == 2)[:, None], g0.T, b.T0), infeas_in=g0.infeas_out)
+b1 = b.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, b.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
 pf = abi.phase1_params(iter_max=iters, fixed_iters=1)
 g1 = s.solve(pf, b1)
 ms, _ = s.last_kernel_ms()
