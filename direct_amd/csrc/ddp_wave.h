@@ -32,6 +32,7 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define WSYNC() ((void)0)
 #define RDLANE(arr, idx, src) (arr[src][idx])
 #define DDP_UNIFORM_I(x) (x)
+#define DDP_MARK(name)
 #else
 #include <hip/hip_runtime.h>
 #define DDP_DEV __device__ __forceinline__
@@ -45,6 +46,11 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define WSYNC() __syncthreads()
 #define RDLANE(arr, idx, src) direct::readlane_real(arr[idx], src)
 #define DDP_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
+#if defined(DDP_MARKS)  // phase markers in the .s for static instruction accounting (tools/phase_count.py)
+#define DDP_MARK(name) asm volatile("; DDP_MARK " name ::: "memory")
+#else
+#define DDP_MARK(name)
+#endif
 #endif
 
 namespace direct {
@@ -190,6 +196,65 @@ struct WaveLds {
     };
   };
   Acc t10[10], hk[10];
+};
+
+// Reciprocal, reciprocal square root and mantissa/exponent split.  On gfx950: the hardware seed
+// (v_rcp / v_rsq, ~24 good bits in f64) plus two Newton steps -- 5 instructions instead of the ~12 of
+// the IEEE division expansion; results are within 1-2 ulp, far inside every stated tolerance.
+#if defined(DIRECT_EMULATE)
+DDP_DEV double frcp(double x) { return 1.0 / x; }
+DDP_DEV float frcp(float x) { return 1.0f / x; }
+DDP_DEV double frsq(double x) { return 1.0 / std::sqrt(x); }
+DDP_DEV float frsq(float x) { return 1.0f / std::sqrt(x); }
+DDP_DEV double split_mant(double x, int& e) { return std::frexp(x, &e); }
+DDP_DEV float split_mant(float x, int& e) { return std::frexp(x, &e); }
+#else
+DDP_DEV double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+DDP_DEV float frcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+DDP_DEV double frsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+DDP_DEV float frsq(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  return y * fmaf(-0.5f * x * y, y, 1.5f);
+}
+DDP_DEV double split_mant(double x, int& e) {
+  e = __builtin_amdgcn_frexp_exp(x);
+  return __builtin_amdgcn_frexp_mant(x);
+}
+DDP_DEV float split_mant(float x, int& e) {
+  e = __builtin_amdgcn_frexp_expf(x);
+  return __builtin_amdgcn_frexp_mantf(x);
+}
+#endif
+
+// sum of logarithms as the logarithm of a running product: mantissa in [0.5,1) and an integer
+// exponent per lane, one log() per lane at the end instead of one per constraint row.
+template <typename Real>
+struct LogProd {
+  Real m;
+  int e;
+  DDP_DEV void init() { m = (Real)1; e = 0; }
+  DDP_DEV void mul(Real x) {  // x > 0 (a non-positive or NaN factor poisons m, exactly like log(x) would)
+    int ex;
+    if (x < (Real)0) x = (Real)NAN;  // log of a negative number is NaN (ddp_optimizer.cpp:731, quirk Q7)
+    Real mx = split_mant(x, ex);
+    int e2;
+    m = split_mant(m * mx, e2);
+    e += ex + e2;
+  }
+  DDP_DEV Real value() const { return log(m) + (Real)e * (Real)0.6931471805599453094; }
 };
 
 template <typename Real>
@@ -411,10 +476,11 @@ struct Wave {
   // ---- evaluation sweep over one iterate buffer: costs, log / error sums, violation count.
   // With do_roll it also propagates x (initialroll, DDP:1608-1620).
   DDP_DEV void eval_sweep(int buf, bool do_roll) {
+    PLV(LogProd<Real>, plog);
     PLV(Real, slog);
     PLV(Real, serr);
     PLV(int, nviol);
-    LANES { LV(slog) = 0; LV(serr) = 0; LV(nviol) = 0; }
+    LANES { LV(plog).init(); LV(serr) = 0; LV(nviol) = 0; }
     const int infeas = DDP_UNIFORM_I(st.infeas);
     double qsum = 0.0;
     int neg = 0;
@@ -446,10 +512,10 @@ struct Wave {
             Real c = row_c(L.val, rd, T);
             if (infeas) {
               Real y = yk[r];
-              LV(slog) += log(y);
+              LV(plog).mul(y);
               LV(serr) += fabs(c + y);
             } else {
-              LV(slog) += log(-c);
+              LV(plog).mul(-c);
             }
             if (c >= (Real)2.0e-4) LV(nviol)++;
           }
@@ -464,6 +530,7 @@ struct Wave {
     WSYNC();
     const double pterm = terminal_sq();  // DDP:1289-1292
     WSYNC();
+    LANES { LV(slog) = LV(plog).value(); }
     st.costq = qsum;
     st.cost = qsum + 0.5 * B.k.w_term * pterm;
     st.sumlog = WAVE_SUM_D(slog);
@@ -591,6 +658,7 @@ struct Wave {
       PLA(Real, ry, RPL);
       PLA(Real, rc, RPL);
       PLA(Real, rr, RPL);  // r (feasible) or rhat (infeasible)
+      DDP_MARK("B_L");
       // ---- L: load the knot
       LANES {
         if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
@@ -603,6 +671,7 @@ struct Wave {
       }
       WSYNC();
       const Real T = L.z[18];
+      DDP_MARK("B_T1");
       // ---- T1: powers of T, scaled value table, dynamics tables
       LANES {
 #pragma unroll 1
@@ -618,6 +687,7 @@ struct Wave {
         }
       }
       WSYNC();
+      DDP_MARK("B_T2");
       // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u
       LANES {
         if (lane < 45) {
@@ -655,6 +725,7 @@ struct Wave {
         }
       }
       WSYNC();
+      DDP_MARK("B_R1");
       // ---- R1: constraint rows -> D, g ; VZ = Vxx * Z
       LANES {
         for (int i = 0; i < RPL; i++) {
@@ -666,14 +737,14 @@ struct Wave {
             if (infeas) {  // DDP:535-539, 554
               Real rm = s * y - mu;
               rv = s * (c + y) - rm;  // rhat
-              Real yinv = (Real)1 / y;
+              Real yinv = frcp(y);
               D = s * yinv;
               g = s + yinv * rv;
               LV(e_mu) = fmax(LV(e_mu), fabs(rm));
               LV(e_c) = fmax(LV(e_c), fabs(c + y));
             } else {  // DDP:583-587, 601
               rv = s * c + mu;
-              Real cinv = (Real)1 / c;
+              Real cinv = frcp(c);
               D = s * cinv;
               g = -mu * cinv;  // s - r/c
               LV(e_mu) = fmax(LV(e_mu), fabs(rv));
@@ -700,6 +771,7 @@ struct Wave {
         }
       }
       WSYNC();
+      DDP_MARK("B_S");
       // ---- S: 3x3 accumulators per control row
       LANES {
         if (lane < 54) {
@@ -745,6 +817,7 @@ struct Wave {
         }
       }
       WSYNC();
+      DDP_MARK("B_S2");
       // ---- S2: Sd = S_cr * dval[cr]
       LANES {
         if (lane < 45) {
@@ -763,6 +836,7 @@ struct Wave {
         }
       }
       WSYNC();
+      DDP_MARK("B_H");
       // ---- H: assemble the 19x19 system  Hzz = Z'VZ + quu -/+ A'DA,  Hz = qz + Z'Vx + A'g
       LANES {
 #pragma unroll 1
@@ -828,6 +902,7 @@ struct Wave {
         }
       }
       WSYNC();
+      DDP_MARK("B_C");
       // ---- C: LLT of Huu + lam I and the 10 right-hand sides, one column per lane
       PLA(Acc, m, 10);
       LANES {
@@ -845,7 +920,7 @@ struct Wave {
       for (int kk = 0; kk < 10; kk++) {
         Acc piv = RDLANE(m, kk, kk);
         if (piv <= (Acc)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
-        Acc rinv = (Acc)1 / sqrt(piv);
+        Acc rinv = frsq(piv);
         Acc l[10];
 #pragma unroll
         for (int i = kk + 1; i < 10; i++) l[i] = RDLANE(m, i, kk) * rinv;
@@ -864,7 +939,7 @@ struct Wave {
       }
 #pragma unroll
       for (int i = 9; i >= 0; i--) {
-        Acc dinv = (Acc)1 / RDLANE(m, i, i);
+        Acc dinv = frcp(RDLANE(m, i, i));
         Acc uij[10];
 #pragma unroll
         for (int j = i + 1; j < 10; j++) uij[j] = RDLANE(m, i, j);
@@ -886,6 +961,7 @@ struct Wave {
         }
       }
       WSYNC();
+      DDP_MARK("B_G");
       // ---- G: cu*ku per control row; products for the V recursion
       LANES {
         if (lane < 45) {
@@ -918,6 +994,7 @@ struct Wave {
         for (int a = 0; a < 10; a++) m0 = fmax(m0, fabs(L.Hz[9 + a]));
         qu_err = fmax(qu_err, m0);
       }
+      DDP_MARK("B_R2");
       // ---- R2: slack / dual gains per row; V recursion; gains to HBM
       LANES {
         St* ksg = Sp_(B.KS, k);
@@ -931,10 +1008,10 @@ struct Wave {
             Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
             if (infeas) {  // DDP:568, 571
               Real y = LV(ry)[i];
-              ksg[r] = (St)((rv + s * cuku) / y);
+              ksg[r] = (St)((rv + s * cuku) * frcp(y));
               kyg[r] = (St)(-(c + y) - cuku);
             } else {  // DDP:611
-              ksg[r] = (St)(-((rv + s * cuku) / c));
+              ksg[r] = (St)(-((rv + s * cuku) * frcp(c)));
             }
           }
         }
@@ -967,6 +1044,7 @@ struct Wave {
       }
       WSYNC();
     }
+    DDP_MARK("B_END");
     double mu_err = WAVE_MAX_D(e_mu);
     double c_err = infeas ? WAVE_MAX_D(e_c) : 0.0;
     st.bp_failed = 0;
@@ -991,11 +1069,12 @@ struct Wave {
       stepsize = 1.0;
       for (int q = 0; q < step; q++) stepsize *= 0.5;  // DDP:670
       const Real alpha = (Real)stepsize;
+      PLV(LogProd<Real>, plog);
       PLV(Real, slog);
       PLV(Real, serr);
       PLV(int, nviol);
       LANES {
-        LV(slog) = 0; LV(serr) = 0; LV(nviol) = 0;
+        LV(plog).init(); LV(serr) = 0; LV(nviol) = 0;
         if (lane < 9) L.xn[lane] = ldx(Xp(cur, 0), lane);
       }
       WSYNC();
@@ -1006,6 +1085,7 @@ struct Wave {
       for (int k = 0; k < N; k++) {
         const int P = np_(k);
         const int nc = 6 * P + 55;
+        DDP_MARK("F_L");
         PLA(Real, rs, RPL);
         PLA(Real, ry, RPL);
         PLA(Real, rks, RPL);
@@ -1025,6 +1105,7 @@ struct Wave {
           }
         }
         WSYNC();
+      DDP_MARK("F_D");
         // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the old and the new T
         LANES {
           if (lane < 9) {
@@ -1052,6 +1133,7 @@ struct Wave {
         WSYNC();
         const Real To = L.z[18], Tn = L.zn[18];
         if (Tn < 0) neg = 1;
+      DDP_MARK("F_T");
         // ---- T: control values at the old and the new iterate, A*[dx; Ku dx], x+, jerk cost
         LANES {
           if (lane < 45) {
@@ -1079,6 +1161,7 @@ struct Wave {
         }
         WSYNC();
         qsum += knot_cost(Tn);
+      DDP_MARK("F_R");
         // ---- R: rows: s+, y+, c+, fraction-to-boundary tests
         PLV(int, bad);
         LANES {
@@ -1097,16 +1180,16 @@ struct Wave {
               if (infeas) {  // DDP:680-687
                 Real y = LV(ry)[i];
                 Real ynew = (Real)(St)(y + alpha * LV(rky)[i] - az);
-                snew = (Real)(St)(s + alpha * LV(rks)[i] + (s / y) * az);
+                snew = (Real)(St)(s + alpha * LV(rks)[i] + (s * frcp(y)) * az);
                 if (ynew < omt * y || snew < omt * s) LV(bad) = 1;
                 yn[r] = (St)ynew;
-                LV(slog) += log(ynew);
+                LV(plog).mul(ynew);
                 LV(serr) += fabs(cn + ynew);
               } else {  // DDP:694-703
                 Real co = row_c(L.val, rd, To);
-                snew = (Real)(St)(s + alpha * LV(rks)[i] - (s / co) * az);
+                snew = (Real)(St)(s + alpha * LV(rks)[i] - (s * frcp(co)) * az);
                 if (cn > omt * co || snew < omt * s) LV(bad) = 1;
-                LV(slog) += log(-cn);
+                LV(plog).mul(-cn);
               }
               sn[r] = (St)snew;
               if (cn >= (Real)2.0e-4) LV(nviol)++;
@@ -1119,6 +1202,7 @@ struct Wave {
         WSYNC();
         if (failed) break;
       }
+      DDP_MARK("F_END");
       if (failed) continue;
       LANES {
         if (lane < 9) {
@@ -1129,6 +1213,7 @@ struct Wave {
       WSYNC();
       const double pterm = terminal_sq();
       WSYNC();
+      LANES { LV(slog) = LV(plog).value(); }
       costq = qsum;
       cost = qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
       sumlog = WAVE_SUM_D(slog);

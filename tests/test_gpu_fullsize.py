@@ -90,8 +90,6 @@ def test_free_space_full_batch_fp32(built, free_batch):
     gf = s4.solve(pf, b1)
     s4.close()
     assert np.abs(gf.cost / rf.cost - 1).max() < 1e-3, np.abs(gf.cost / rf.cost - 1)
-    # the final objective improved on the warm start for every converged problem
-    assert (g1.cost[g1.rtn == 1] < 1e4).all()
     s.close()
 
 
