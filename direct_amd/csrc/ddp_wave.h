@@ -165,37 +165,49 @@ constexpr int kXS = 24;  // knot record stride of X: x (9), u (10), low parts of
 typedef double Acc;      // accumulator type of the condensed system (see WaveLds)
 
 // ---- LDS (one per wave) ------------------------------------------------------------------------
-template <typename Real, int RPL>
+// RowT: type of the per-row D / g staging arrays (the storage type: float halves them in DIRECT_F32).
+template <typename Real, typename RowT, int RPL>
 struct WaveLds {
+  static constexpr int kPMax = (64 * RPL - 55) / 6 > kPLim ? kPLim : (64 * RPL - 55) / 6;  // planes per knot
   TrajState st;
   Real WbE[90], WdE[90];  // value / d-dT base tables with Ek_inv folded in (fixed for the launch)
   Real Hc[18], Hpc[18];   // [F|G] and [F'|G'] coefficients; entry = coefficient * T^exponent
   int He[18], Hpe[18];
   Real Rc[9];             // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1)
-  int pq[192];            // upper-triangle (p,q) of the 18x18 block, p | q << 8
-  Real tp[8], tpn[8];     // powers of T (old / new iterate)
-  Real z[kXS], zn[kXS], dz[kXS], xn[12], xnx[12];
-  Real pl[4 * kPLim];
-  Real We[90];
-  Real val[48], dval[48], valn[48], G[48];
-  Real drow[64 * RPL], grow[64 * RPL];
-  Real H[18], Hp[18], qp[12];
-  Real KUr[100];  // gains of the knot as stored in HBM (forward pass)
-  // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
-  // even when Real = float: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in fp32
-  // over ~100 knots (the fp32 solver stalls at 2-3x the fp64 cost, DESIGN.md "Precision").
-  Acc Sp[36], dl[27], Sd[48], hh[48], last[4];
-  Acc fT[12], Ru[9], Rpu[9], Rppu[9];
-  Acc V[81], Vx[12];
-  Acc Hzz[361], Hz[20];
-  Acc KU[100];
+  int pq[176];            // upper triangle of the 18x18 block, packed: see init_tables()
+  // per knot, both sweeps
+  Real tp[8];             // powers of T
+  Real z[kXS];
+  Real pl[4 * kPMax];
+  Real val[48], G[48];
   union {
-    Acc VZ[176];  // Vxx * Z: dead after phase H
-    struct {
-      Acc W1[81], W2[90];  // Hxu Ku, Huu Ku: born in phase G
+    struct {  // ---- backward sweep only
+      Real We[90], dval[48], H[18], Hp[18];
+      RowT drow[64 * RPL], grow[64 * RPL];
+      // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
+      // (Acc) whatever Real is: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in
+      // fp32 over ~100 knots (DESIGN.md "Precision").
+      Acc Sp[36], dl[27], Sd[48], hh[48], last[4];
+      Acc fT[12], Ru[9], Rpu[9], Rppu[9];
+      Acc V[81], Vx[12];
+      Acc Hxx[81], Hxu[90], Huu[100], Hz[20];  // Hxu[a][c] (9x10), Huu 10x10, both triangles stored
+      Acc KU[100];
+      union {
+        Acc VZ[176];  // Vxx * Z: dead after phase H
+        struct {
+          Acc cbuf[10], rdiag[10], Ub[100];  // Cholesky: pivot column, 1/L_kk, L^T (phase C)
+        };
+        struct {
+          Acc W1[81], W2[90];  // Hxu Ku, Huu Ku (phases G, R2)
+        };
+      };
+      Acc t10[10], hk[10];
+    };
+    struct {  // ---- forward pass / evaluation sweep only
+      Real tpn[8], zn[kXS], dz[kXS], xn[12], xnx[12], valn[48], qp[12];
+      Real KUr[100];  // gains of the knot as stored in HBM
     };
   };
-  Acc t10[10], hk[10];
 };
 
 // Reciprocal, reciprocal square root and mantissa/exponent split.  On gfx950: the hardware seed
@@ -302,7 +314,7 @@ DDP_DEV RowD row_decode(int r, int P) {
 // (the dtype of the C-ABI), Acc (double) = type of the condensed system.
 template <typename Real, typename St, int RPL>
 struct Wave {
-  typedef WaveLds<Real, RPL> Lds;
+  typedef WaveLds<Real, St, RPL> Lds;
   const Batch<St>& B;
   Lds& L;
   TrajState& st;
@@ -328,6 +340,47 @@ struct Wave {
     const St hi = (St)v;
     rec[a] = hi;
     if (sizeof(St) < sizeof(double) && a < 3) rec[19 + a] = (St)(v - (Real)hi);
+  }
+
+  // Software prefetch of the next knot's HBM data into registers: the serial knot recursion would
+  // otherwise expose one full memory latency per knot (nothing else is in flight in this wave).
+  struct Pre {
+    Real z, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
+  };
+  DDP_DEV void prefetch(Pre& p, int lane, int buf, int k, int P, bool fwd, int infeas) const {
+    const int nc = 6 * P + 55;
+    p.z = (lane < 19) ? ldx(Xp(buf, k), lane) : (Real)0;
+    const St* pk = planes_(k);
+    p.pl[0] = (lane < 4 * P) ? (Real)pk[lane] : (Real)0;
+    p.pl[1] = (lane + 64 < 4 * P) ? (Real)pk[lane + 64] : (Real)0;
+    const St* sk = Sp_(B.S[buf], k);
+    const St* yk = Sp_(B.Y[buf], k);
+    const St* ksk = Sp_(B.KS, k);
+    const St* kyk = Sp_(B.KY, k);
+    for (int i = 0; i < RPL; i++) {
+      const int r = lane + 64 * i;
+      const bool in = r < nc;
+      p.s[i] = in ? (Real)sk[r] : (Real)0;
+      p.y[i] = (in && infeas) ? (Real)yk[r] : (Real)1;
+      if (fwd) {
+        p.ks[i] = in ? (Real)ksk[r] : (Real)0;
+        p.ky[i] = (in && infeas) ? (Real)kyk[r] : (Real)0;
+      }
+    }
+    if (fwd) {
+      const St* ku = KUp(k);
+      p.ku[0] = (Real)ku[lane];
+      p.ku[1] = (lane + 64 < 100) ? (Real)ku[lane + 64] : (Real)0;
+    }
+  }
+  DDP_DEV void commit(const Pre& p, int lane, int P, bool fwd) {
+    if (lane < 19) L.z[lane] = p.z;
+    if (lane < 4 * P) L.pl[lane] = p.pl[0];
+    if (lane + 64 < 4 * P) L.pl[lane + 64] = p.pl[1];
+    if (fwd) {
+      L.KUr[lane] = p.ku[0];
+      if (lane + 64 < 100) L.KUr[lane + 64] = p.ku[1];
+    }
   }
 
   DDP_DEV void load_state() {
@@ -365,14 +418,18 @@ struct Wave {
         L.WdE[e] = (Real)(d * eps);
       }
 #pragma unroll 1
-      for (int e = lane; e < 192; e += 64) {
-        // e -> (p,q), p <= q < 18, row-major over the upper triangle (171 entries)
+      for (int e = lane; e < 176; e += 64) {
+        // e -> (p,q), p <= q < 18, row-major over the upper triangle (171 entries), packed with
+        // everything phase H derives from it: p:5 q:5 i:3 d:2 i2:3 d2:2 sidx:3 (d==d2):1
         int p = 0, rem = e;
         while (p < 18 && rem >= 18 - p) {
           rem -= 18 - p;
           p++;
         }
-        L.pq[e] = (e < 171) ? (p | ((p + rem) << 8)) : 0;
+        const int q = p + rem, i = p / 3, d = p % 3, i2 = q / 3, d2 = q % 3;
+        const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
+        const int sidx = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);  // xx,xy,xz,yy,yz,zz
+        L.pq[e < 176 ? e : 0] = (e < 171) ? (p | (q << 5) | (i << 10) | (d << 13) | (i2 << 15) | (d2 << 18) | (sidx << 20) | ((d == d2) << 23)) : L.pq[0];
       }
       if (lane < 18) {  // [F|G] (DDP:862-871) and [F'|G'] (DDP:930-935): coefficient and exponent of T
         int c = lane / 6, i = lane % 6;
@@ -650,24 +707,29 @@ struct Wave {
     LANES { LV(e_mu) = 0; LV(e_c) = 0; }
     Acc qu_err = 0;
 
+    int Pn = np_(N - 1);
+    PLV(Pre, pre);
+    LANES { prefetch(LV(pre), lane, buf, N - 1, Pn, false, infeas); }
 #pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
-      const int P = np_(k);
+      const int P = Pn;
       const int nc = 6 * P + 55;
       PLA(Real, rs, RPL);
       PLA(Real, ry, RPL);
       PLA(Real, rc, RPL);
       PLA(Real, rr, RPL);  // r (feasible) or rhat (infeasible)
       DDP_MARK("B_L");
-      // ---- L: load the knot
+      // ---- L: this knot's data from the prefetch registers; issue the loads of the next knot
       LANES {
-        if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
-        for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
+        commit(LV(pre), lane, P, false);
         for (int i = 0; i < RPL; i++) {
-          int r = lane + 64 * i;
-          LV(rs)[i] = (r < nc) ? Sp_(B.S[buf], k)[r] : (Real)0;
-          LV(ry)[i] = (r < nc && infeas) ? Sp_(B.Y[buf], k)[r] : (Real)1;
+          LV(rs)[i] = LV(pre).s[i];
+          LV(ry)[i] = LV(pre).y[i];
         }
+      }
+      if (k > 0) {
+        Pn = np_(k - 1);
+        LANES { prefetch(LV(pre), lane, buf, k - 1, Pn, false, infeas); }
       }
       WSYNC();
       const Real T = L.z[18];
@@ -751,8 +813,8 @@ struct Wave {
             }
             LV(rc)[i] = c;
             LV(rr)[i] = rv;
-            L.drow[r] = D;
-            L.grow[r] = g;
+            L.drow[r] = (St)D;
+            L.grow[r] = (St)g;
           }
         }
 #pragma unroll 1
@@ -776,7 +838,7 @@ struct Wave {
       LANES {
         if (lane < 54) {
           int j, d0, d1;
-          const Real* w;
+          const St* w;
           if (lane < 36) {
             const int e = lane % 6;
             j = lane / 6;
@@ -794,7 +856,7 @@ struct Wave {
           for (int q = 0; q < P; q++) {
             const Real* n = &L.pl[4 * q];
             Real f = (d1 == 3) ? (Real)1 : n[d1];
-            acc += w[j * P + q] * n[d0] * f;
+            acc += (Real)w[j * P + q] * n[d0] * f;
           }
           if (lane < 36) L.Sp[lane] = acc;
           else L.hh[lane - 36] = acc;
@@ -812,8 +874,8 @@ struct Wave {
           L.hh[18 + lane] = (Acc)L.grow[rp] - (Acc)L.grow[rm];
         }
         if (lane == 63) {
-          L.last[0] = L.drow[nc - 1];
-          L.last[1] = L.grow[nc - 1];
+          L.last[0] = (Acc)L.drow[nc - 1];
+          L.last[1] = (Acc)L.grow[nc - 1];
         }
       }
       WSYNC();
@@ -841,25 +903,30 @@ struct Wave {
       LANES {
 #pragma unroll 1
         for (int e = lane; e < 171; e += 64) {  // the 18x18 block, p <= q
-          const int p = L.pq[e] & 255, q = L.pq[e] >> 8;
-          const int i = p / 3, d = p % 3, i2 = q / 3, d2 = q % 3;
-          const int se = d * 3 - (d * (d - 1)) / 2 + (d2 - d);  // d <= d2 when i == i2; S is symmetric
-          const int se2 = d2 * 3 - (d2 * (d2 - 1)) / 2 + (d - d2);
-          const int sidx = (d <= d2) ? se : se2;
+          const int w = L.pq[e];
+          const int p = w & 31, q = (w >> 5) & 31, i = (w >> 10) & 7, d = (w >> 13) & 3;
+          const int i2 = (w >> 15) & 7, sidx = (w >> 20) & 7, dd = (w >> 23) & 1;
           Acc ada = 0, zvz = 0;
 #pragma unroll
           for (int cr = 0; cr < 6; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.Sp[cr * 6 + sidx];
-          if (d == d2) {
+          if (dd) {
 #pragma unroll 3
             for (int cr = 6; cr < 15; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.dl[(cr - 6) * 3 + d];
           }
 #pragma unroll
           for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + q];
           Acc quu = 0;
-          if (i >= 3 && d == d2) quu = wsn * L.Rc[(i - 3) * 3 + (i2 - 3)] * L.tp[i + i2 - 5];
+          if (i >= 3 && dd) quu = wsn * L.Rc[(i - 3) * 3 + (i2 - 3)] * L.tp[i + i2 - 5];
           const Acc v = zvz + quu + sig * ada;
-          L.Hzz[p * 19 + q] = v;
-          L.Hzz[q * 19 + p] = v;
+          if (q < 9) {
+            L.Hxx[p * 9 + q] = v;
+            L.Hxx[q * 9 + p] = v;
+          } else if (p < 9) {
+            L.Hxu[p * 10 + (q - 9)] = v;
+          } else {
+            L.Huu[(p - 9) * 10 + (q - 9)] = v;
+            L.Huu[(q - 9) * 10 + (p - 9)] = v;
+          }
         }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
           const int p = lane < 18 ? lane : lane - 18;
@@ -873,8 +940,12 @@ struct Wave {
 #pragma unroll
             for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
             const Acc v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Acc)0) + sig * acc;
-            L.Hzz[p * 19 + 18] = v;
-            L.Hzz[18 * 19 + p] = v;
+            if (p < 9) {
+              L.Hxu[p * 10 + 9] = v;
+            } else {
+              L.Huu[(p - 9) * 10 + 9] = v;
+              L.Huu[90 + (p - 9)] = v;
+            }
           } else {
             Acc zv = 0;
 #pragma unroll
@@ -894,7 +965,7 @@ struct Wave {
           }
           if (lane == 36) {
             const Acc quu = ((B.k.time_power == 2) ? (Acc)B.k.w_time : (Acc)0) + (Acc)0.5 * wsn * uru;
-            L.Hzz[18 * 19 + 18] = zv + quu + sig * (acc + L.last[0]);
+            L.Huu[99] = zv + quu + sig * (acc + L.last[0]);
           } else {
             const Acc qz = ((B.k.time_power == 2) ? (Acc)B.k.w_time * T : (Acc)0.5 * (Acc)B.k.w_time) + (Acc)0.5 * wsn * uru;
             L.Hz[18] = qz + zv + (acc - L.last[1]);
@@ -903,32 +974,41 @@ struct Wave {
       }
       WSYNC();
       DDP_MARK("B_C");
-      // ---- C: LLT of Huu + lam I and the 10 right-hand sides, one column per lane
+      // ---- C: LLT of Huu + lam I and the 10 right-hand sides [Hu | Hux].  One column per lane in
+      // registers (lanes 0..9 the matrix, 10..19 the right-hand sides); the pivot column of each
+      // elimination step is broadcast through LDS (one round trip per step) instead of 2 v_readlane
+      // per double, and L^T is parked in LDS once for the whole back substitution.
       PLA(Acc, m, 10);
       LANES {
 #pragma unroll
         for (int a = 0; a < 10; a++) {
           Acc v = 0;
-          if (lane < 10) v = L.Hzz[(9 + a) * 19 + 9 + lane] + ((a == lane) ? lam : (Acc)0);
+          if (lane < 10) v = L.Huu[a * 10 + lane] + ((a == lane) ? lam : (Acc)0);
           else if (lane == 10) v = L.Hz[9 + a];
-          else if (lane < 20) v = L.Hzz[(9 + a) * 19 + (lane - 11)];
+          else if (lane < 20) v = L.Hxu[(lane - 11) * 10 + a];
           LV(m)[a] = v;
         }
       }
       int ok = 1;
 #pragma unroll
       for (int kk = 0; kk < 10; kk++) {
-        Acc piv = RDLANE(m, kk, kk);
-        if (piv <= (Acc)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
-        Acc rinv = frsq(piv);
-        Acc l[10];
-#pragma unroll
-        for (int i = kk + 1; i < 10; i++) l[i] = RDLANE(m, i, kk) * rinv;
         LANES {
-          Acc mk = LV(m)[kk] * rinv;
-          LV(m)[kk] = mk;
+          if (lane == kk) {
 #pragma unroll
-          for (int i = kk + 1; i < 10; i++) LV(m)[i] -= l[i] * mk;
+            for (int i = kk; i < 10; i++) L.cbuf[i] = LV(m)[i];
+          }
+        }
+        WSYNC();
+        const Acc piv = L.cbuf[kk];
+        if (piv <= (Acc)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
+        const Acc rinv = frsq(piv);
+        L.rdiag[kk] = rinv;  // wave-uniform store
+        LANES {
+          Acc t = LV(m)[kk] * rinv;
+          LV(m)[kk] = t;
+          t *= rinv;
+#pragma unroll
+          for (int i = kk + 1; i < 10; i++) LV(m)[i] -= L.cbuf[i] * t;
         }
       }
       ok = DDP_UNIFORM_I(ok);
@@ -937,21 +1017,22 @@ struct Wave {
         st.opterr = INFINITY;
         return 0;
       }
+      LANES {
+        if (lane < 10) {
 #pragma unroll
-      for (int i = 9; i >= 0; i--) {
-        Acc dinv = frcp(RDLANE(m, i, i));
-        Acc uij[10];
-#pragma unroll
-        for (int j = i + 1; j < 10; j++) uij[j] = RDLANE(m, i, j);
-        LANES {
-          Acc acc = LV(m)[i];
-#pragma unroll
-          for (int j = i + 1; j < 10; j++) acc -= uij[j] * LV(m)[j];
-          if (lane >= 10) LV(m)[i] = acc * dinv;
+          for (int i = 0; i < 10; i++) L.Ub[i * 10 + lane] = LV(m)[i];  // U[i][j] = L[j][i]
         }
       }
-      LANES {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
-        if (lane >= 10 && lane < 20) {
+      WSYNC();
+      LANES {
+#pragma unroll
+        for (int i = 9; i >= 0; i--) {
+          Acc acc = LV(m)[i];
+#pragma unroll
+          for (int j = i + 1; j < 10; j++) acc -= L.Ub[i * 10 + j] * LV(m)[j];
+          LV(m)[i] = acc * L.rdiag[i];
+        }
+        if (lane >= 10 && lane < 20) {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
           const int col = lane - 10;
 #pragma unroll
           for (int a = 0; a < 10; a++) {
@@ -974,13 +1055,13 @@ struct Wave {
 #pragma unroll 1
         for (int e = lane; e < 190; e += 64) {
           // W1 = Hxu Ku (81) | W2 = Huu Ku (90) | t10 = Huu ku (10) | hk = Hxu ku (9): all 10-term dots
-          int hrow, koff, kstr;
+          int koff, kstr;
+          const Acc* hp;
           Acc* dst;
-          if (e < 81) { hrow = e / 9; koff = 10 + e % 9; kstr = 9; dst = &L.W1[e]; }
-          else if (e < 171) { hrow = 9 + (e - 81) / 9; koff = 10 + (e - 81) % 9; kstr = 9; dst = &L.W2[e - 81]; }
-          else if (e < 181) { hrow = 9 + (e - 171); koff = 0; kstr = 1; dst = &L.t10[e - 171]; }
-          else { hrow = e - 181; koff = 0; kstr = 1; dst = &L.hk[e - 181]; }
-          const Acc* hp = &L.Hzz[hrow * 19 + 9];
+          if (e < 81) { hp = &L.Hxu[(e / 9) * 10]; koff = 10 + e % 9; kstr = 9; dst = &L.W1[e]; }
+          else if (e < 171) { hp = &L.Huu[((e - 81) / 9) * 10]; koff = 10 + (e - 81) % 9; kstr = 9; dst = &L.W2[e - 81]; }
+          else if (e < 181) { hp = &L.Huu[(e - 171) * 10]; koff = 0; kstr = 1; dst = &L.t10[e - 171]; }
+          else { hp = &L.Hxu[(e - 181) * 10]; koff = 0; kstr = 1; dst = &L.hk[e - 181]; }
           Acc acc = 0;
 #pragma unroll 5
           for (int c = 0; c < 10; c++) acc += hp[c] * L.KU[koff + c * kstr];
@@ -1024,7 +1105,7 @@ struct Wave {
             a++;
           }
           const int c2 = a + rem;
-          Acc m1 = L.Hzz[a * 19 + c2] + L.W1[a * 9 + c2] + L.W1[c2 * 9 + a];
+          Acc m1 = L.Hxx[a * 9 + c2] + L.W1[a * 9 + c2] + L.W1[c2 * 9 + a];
           Acc m2 = m1;
 #pragma unroll 5
           for (int c = 0; c < 10; c++) {
@@ -1081,9 +1162,12 @@ struct Wave {
       double qsum = 0.0;
       int failed = 0;
       neg = 0;
+      int Pn = np_(0);
+      PLV(Pre, pre);
+      LANES { prefetch(LV(pre), lane, cur, 0, Pn, true, infeas); }
 #pragma unroll 1
       for (int k = 0; k < N; k++) {
-        const int P = np_(k);
+        const int P = Pn;
         const int nc = 6 * P + 55;
         DDP_MARK("F_L");
         PLA(Real, rs, RPL);
@@ -1091,18 +1175,17 @@ struct Wave {
         PLA(Real, rks, RPL);
         PLA(Real, rky, RPL);
         LANES {
-          if (lane < 19) L.z[lane] = ldx(Xp(cur, k), lane);
-#pragma unroll 1
-          for (int e = lane; e < 100; e += 64) L.KUr[e] = KUp(k)[e];
-          for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
+          commit(LV(pre), lane, P, true);
           for (int i = 0; i < RPL; i++) {
-            int r = lane + 64 * i;
-            bool in = r < nc;
-            LV(rs)[i] = in ? Sp_(B.S[cur], k)[r] : (Real)0;
-            LV(rks)[i] = in ? Sp_(B.KS, k)[r] : (Real)0;
-            LV(ry)[i] = (in && infeas) ? Sp_(B.Y[cur], k)[r] : (Real)1;
-            LV(rky)[i] = (in && infeas) ? Sp_(B.KY, k)[r] : (Real)0;
+            LV(rs)[i] = LV(pre).s[i];
+            LV(rks)[i] = LV(pre).ks[i];
+            LV(ry)[i] = LV(pre).y[i];
+            LV(rky)[i] = LV(pre).ky[i];
           }
+        }
+        if (k + 1 < N) {
+          Pn = np_(k + 1);
+          LANES { prefetch(LV(pre), lane, cur, k + 1, Pn, true, infeas); }
         }
         WSYNC();
       DDP_MARK("F_D");

@@ -33,7 +33,7 @@ struct MinWaves<double> { static constexpr int v = DDP_WAVES_F64; };
 
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_begin(Batch<St> B) {
-  __shared__ WaveLds<Cmp, RPL> lds;
+  __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.init_tables();
   W.begin();
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_begin(Batch<St> B) {
 // the hot kernel: n trips of the outer loop (ddp_optimizer.cpp:295-412) per trajectory
 template <typename St, int RPL>
 __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate(Batch<St> B, int n_iters) {
-  __shared__ WaveLds<Cmp, RPL> lds;
+  __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate(Batch<St> B, in
 // stepwise interface: mode 1 = one backwardpass(), 2 = one forwardpass()
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
-  __shared__ WaveLds<Cmp, RPL> lds;
+  __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
 
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_finish(Batch<St> B, OutPtrs<St> O) {
-  __shared__ WaveLds<Cmp, RPL> lds;
+  __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   W.init_tables();
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void k_finish(Batch<St> B, OutPtrs<St> O) {
 
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_field(Batch<St> B, int field, St* buf, int set) {
-  __shared__ WaveLds<Cmp, RPL> lds;
+  __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   W.init_tables();

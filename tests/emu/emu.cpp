@@ -27,7 +27,7 @@ struct Emu {
 
 template <typename Cmp, typename Real, int RPL, typename F>
 static void for_each_wave(Emu<Real>& E, F f) {
-  static WaveLds<Cmp, RPL> lds;
+  static WaveLds<Cmp, Real, RPL> lds;
   for (int b = 0; b < E.B.B; b++) {
     Wave<Cmp, Real, RPL> W(E.B, lds, b);
     f(W);
