@@ -33,11 +33,13 @@ FIXED_ITERS = 20
 def cpu_baseline(batch1, params, sample):
     """The oracle ("port": Eigen-free restatement of the reference, the original cannot be built
     here) on a bounded sample of the same workload, OpenMP over all host cores."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import refapi
     refapi.build()
     sub = batch1.select(np.arange(sample))
     n_threads = os.cpu_count() or 1
-    refapi.solve_batch(params, sub.select(np.arange(min(sample, n_threads))), n_threads=n_threads)  # warm up
+    refapi.solve_batch(params, sub.select(np.arange(min(sample, 2 * n_threads))), n_threads=n_threads)  # warm up threads + arenas
     t = time.perf_counter()
     res, _ = refapi.solve_batch(params, sub, n_threads=n_threads)
     dt = time.perf_counter() - t
@@ -48,6 +50,18 @@ def cpu_baseline(batch1, params, sample):
             "sample": "%d of the %d corridors of rank 0's batch, same fixed-%d-iteration phase-1 solve, fp64, "
                       "OpenMP schedule(dynamic,1); %.1f s wall" % (sample, batch1.batch, FIXED_ITERS, dt),
             "single_thread_value": float(res1.fwd_passes.sum() / dt1)}
+
+
+def measured_traffic_bytes():
+    """HBM bytes per k_iterate launch from the committed rocprofv3 PMC passes of THIS command
+    (profiles/*_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, KB units); None if absent.
+    Dword loads, so the guide's x2 FETCH_SIZE correction for 16 B/lane streams is not applied."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    return (d["FETCH_SIZE"]["workload_mean_kb"] + d["WRITE_SIZE"]["workload_mean_kb"]) * 1024.0
 
 
 def main():
@@ -158,13 +172,15 @@ def main():
             "metric": "ddp_iterations_per_sec", "value": iters_all / dt, "unit": "iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            # arithmetic type of the path: double for both storage types
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config 2: %d %s corridors per GPU, N=%d segments, polynomial-segment IPDDP "
                                    "(9 states / 10 controls), phase-1 weights, fixed %d iterations, warm start from phase 0"
                                    % (B, "free-space" if args.kind == "free" else "polyhedron", N, FIXED_ITERS),
-                       "batch_per_gpu": B, "n_seg": N, "fixed_iters": FIXED_ITERS, "parallelism": "shard%d" % world},
+                       "batch_per_gpu": B, "n_seg": N, "fixed_iters": FIXED_ITERS, "parallelism": "shard%d" % world,
+                       "storage_dtype": args.dtype},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
                          "kernel": "k_iterate", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "iters_per_step_rank0": iters_step, "best_cost": bc, "best_index": bidx, "gather_ms": gather_ms,
         }

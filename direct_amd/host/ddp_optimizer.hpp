@@ -1,0 +1,197 @@
+// Host-side C++ mirror of the reference's optimiser interface on top of the C-ABI (include/direct_ddp.h).
+//
+// The reference class is `ddpTrajOptimizer` (global_planner/include/global_planner/ddp_optimizer.h:241-342)
+// with `int polyCurveGeneration(corridor, MQM_u, MQM_l, pos, vel, acc, jer, minimize_order, max_vel,
+// max_acc, max_jer, initbezCoeff, w_snap, w_terminal, w_time, iter_max, bool& infeas, zero_init_flag,
+// line_init_flag, bool& line_failed, time_power, minvo_flag)` and the getters getPolyCoeff(),
+// getBezCoeff(), getPolyTime(), getDDPObjective(), getCompTime(), getTerminalNorm(), getIterUsed(),
+// getJerkCost().  This header keeps those names, argument order and return codes; the only change is
+// that it accepts a BATCH of corridors (a batch of one is the reference call).  It is templated on the
+// dense matrix / vector types so that the real node passes Eigen::MatrixXd / Eigen::VectorXd
+//  while the tests, which have no Eigen, pass direct::DenseMatrix / DenseVector.
+//
+// Requirements on Mat: Mat(rows, cols), rows(), cols(), operator()(i, j).  On Vec: Vec(n), size(), operator()(i).
+#pragma once
+#include <array>
+#include <chrono>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/direct_ddp.h"
+
+namespace decomp_cvx_space {  // same names as global_planner/include/global_planner/utils/data_type.h:124-245
+struct Vec3 { double x = 0, y = 0, z = 0; };
+struct Polytope {
+  Vec3 center, seed_coord;
+  std::vector<std::array<double, 4>> planes;  // (a,b,c,d): outward normal, inside <=> ax+by+cz+d <= 0
+  void appendPlane(const std::array<double, 4>& p) { planes.push_back(p); }
+};
+struct FlightCorridor {
+  std::vector<double> durations;
+  std::vector<Polytope> polyhedrons;
+  double scale_factor = 1.0;
+  void appendPolytope(const Polytope& p) { polyhedrons.push_back(p); }
+  void appendTime(double t) { durations.push_back(t); }
+  void clear() { durations.clear(); polyhedrons.clear(); }
+  bool isEmpty() const { return polyhedrons.empty(); }
+};
+}  // namespace decomp_cvx_space
+
+namespace direct {
+
+struct DenseMatrix {  // minimal row-major stand-in for Eigen::MatrixXd in the tests
+  int r = 0, c = 0;
+  std::vector<double> d;
+  DenseMatrix() {}
+  DenseMatrix(int rows, int cols) : r(rows), c(cols), d((size_t)rows * cols, 0.0) {}
+  int rows() const { return r; }
+  int cols() const { return c; }
+  double& operator()(int i, int j) { return d[(size_t)i * c + j]; }
+  double operator()(int i, int j) const { return d[(size_t)i * c + j]; }
+};
+struct DenseVector {
+  std::vector<double> d;
+  DenseVector() {}
+  explicit DenseVector(int n) : d((size_t)n, 0.0) {}
+  int size() const { return (int)d.size(); }
+  double& operator()(int i) { return d[i]; }
+  double operator()(int i) const { return d[i]; }
+};
+
+// One GPU handle shared by the optimiser objects of a process (the reference news/deletes an optimiser
+// per call, teach_repeat_planner.cpp:853-854, 950-951; creating device buffers per call would be wasteful).
+class DdpDevice {
+ public:
+  DdpDevice(int max_batch, int n_seg_max, int p_max, direct_dtype_t dtype = DIRECT_F64, int device = 0)
+      : max_batch_(max_batch), n_seg_max_(n_seg_max), p_max_(p_max), dtype_(dtype) {
+    direct_ddp_config_t cfg{(int32_t)dtype, device, max_batch, n_seg_max, p_max, 0};
+    if (direct_ddp_create(&cfg, &h_) != DIRECT_OK) throw std::runtime_error(direct_ddp_last_error());
+  }
+  ~DdpDevice() { direct_ddp_destroy(h_); }
+  DdpDevice(const DdpDevice&) = delete;
+  DdpDevice& operator=(const DdpDevice&) = delete;
+  direct_ddp_handle_t handle() const { return h_; }
+  int max_batch() const { return max_batch_; }
+  int n_seg_max() const { return n_seg_max_; }
+  int p_max() const { return p_max_; }
+  direct_dtype_t dtype() const { return dtype_; }
+
+ private:
+  direct_ddp_handle_t h_ = nullptr;
+  int max_batch_, n_seg_max_, p_max_;
+  direct_dtype_t dtype_;
+};
+
+template <class Mat = DenseMatrix, class Vec = DenseVector>
+class ddpTrajOptimizer {
+ public:
+  explicit ddpTrajOptimizer(DdpDevice& dev) : dev_(dev) {}
+
+  // Batched polyCurveGeneration (ddp_optimizer.h:267-289).  pos/vel/acc/jer: one 2x3 matrix per corridor
+  // (row 0 start, row 1 goal); initbezCoeff: one N x 18 matrix per corridor (ignored when zero_init_flag);
+  // infeas / line_failed: in-out per corridor.  Returns the per-corridor return codes.
+  std::vector<int> polyCurveGeneration(const std::vector<decomp_cvx_space::FlightCorridor>& corridors,
+                                       const Mat& /*MQM_u: unused by the reference, ddp_optimizer.cpp:7*/,
+                                       const Mat& /*MQM_l: unused*/, const std::vector<Mat>& pos,
+                                       const std::vector<Mat>& vel, const std::vector<Mat>& acc,
+                                       const std::vector<Mat>& /*jer: only read when sys_order == 4*/,
+                                       double /*minimize_order: unused*/, double max_vel, double max_acc,
+                                       double /*max_jer: unused*/, const std::vector<Mat>& initbezCoeff, double w_snap,
+                                       double w_terminal, double w_time, int iter_max, std::vector<uint8_t>& infeas,
+                                       bool zero_init_flag, bool line_init_flag, std::vector<uint8_t>& line_failed,
+                                       int time_power, bool minvo_flag) {
+    const int B = (int)corridors.size(), nm = dev_.n_seg_max(), pm = dev_.p_max();
+    if (B < 1 || B > dev_.max_batch()) throw std::invalid_argument("batch size");
+    const bool f64 = dev_.dtype() == DIRECT_F64;
+    n_seg_.assign(B, 0);
+    std::vector<int32_t> n_planes((size_t)B * nm, 1);
+    std::vector<double> x0((size_t)B * 9, 0.0), xd((size_t)B * 9, 0.0), T0((size_t)B * nm, 1.0);
+    std::vector<double> planes((size_t)B * nm * pm * 4, 0.0), seeds((size_t)B * nm * 3, 0.0), bez((size_t)B * nm * 18, 0.0);
+    for (int b = 0; b < B; b++) {
+      const auto& cor = corridors[b];
+      const int N = (int)cor.polyhedrons.size();
+      if (N < 1 || N > nm || (int)cor.durations.size() < N) throw std::invalid_argument("corridor size");
+      n_seg_[b] = N;
+      for (int d = 0; d < 3; d++) {
+        x0[(size_t)b * 9 + d] = pos[b](0, d); x0[(size_t)b * 9 + 3 + d] = vel[b](0, d); x0[(size_t)b * 9 + 6 + d] = acc[b](0, d);
+        xd[(size_t)b * 9 + d] = pos[b](1, d); xd[(size_t)b * 9 + 3 + d] = vel[b](1, d); xd[(size_t)b * 9 + 6 + d] = acc[b](1, d);
+      }
+      for (int k = 0; k < N; k++) {
+        const auto& pl = cor.polyhedrons[k];
+        if ((int)pl.planes.size() < 1 || (int)pl.planes.size() > pm) throw std::invalid_argument("planes per polytope");
+        n_planes[(size_t)b * nm + k] = (int32_t)pl.planes.size();
+        T0[(size_t)b * nm + k] = cor.durations[k];
+        for (size_t p = 0; p < pl.planes.size(); p++)
+          for (int q = 0; q < 4; q++) planes[(((size_t)b * nm + k) * pm + p) * 4 + q] = pl.planes[p][q];
+        seeds[((size_t)b * nm + k) * 3 + 0] = pl.seed_coord.x;
+        seeds[((size_t)b * nm + k) * 3 + 1] = pl.seed_coord.y;
+        seeds[((size_t)b * nm + k) * 3 + 2] = pl.seed_coord.z;
+        if (!zero_init_flag)
+          for (int q = 0; q < 18; q++) bez[((size_t)b * nm + k) * 18 + q] = initbezCoeff[b](k, q);
+      }
+    }
+    direct_ddp_params_t p{max_vel, max_acc, w_snap, w_terminal, w_time, iter_max, time_power, zero_init_flag,
+                          line_init_flag, minvo_flag, 1, 0, 0};
+    // the C-ABI is typed by the handle's storage dtype: narrow once here when it is float
+    std::vector<float> fx0, fxd, fT0, fpl, fsd, fbz;
+    auto narrow = [](const std::vector<double>& a, std::vector<float>& o) { o.assign(a.begin(), a.end()); return (const void*)o.data(); };
+    direct_ddp_batch_in_t in{};
+    in.batch = B; in.n_seg_max = nm; in.p_max = pm; in.mem = DIRECT_MEM_HOST;
+    in.n_seg = n_seg_.data(); in.n_planes = n_planes.data(); in.infeas_in = infeas.data();
+    in.x0 = f64 ? (const void*)x0.data() : narrow(x0, fx0);
+    in.xd = f64 ? (const void*)xd.data() : narrow(xd, fxd);
+    in.T0 = f64 ? (const void*)T0.data() : narrow(T0, fT0);
+    in.planes = f64 ? (const void*)planes.data() : narrow(planes, fpl);
+    in.seeds = f64 ? (const void*)seeds.data() : narrow(seeds, fsd);
+    in.init_bez = zero_init_flag ? nullptr : (f64 ? (const void*)bez.data() : narrow(bez, fbz));
+    rtn_.assign(B, 0); iter_.assign(B, 0);
+    std::vector<uint8_t> inf_out(B), lf_out(B);
+    const size_t rs = f64 ? 8 : 4;
+    raw_cost_.assign(B * rs, 0); raw_jerk_.assign(B * rs, 0); raw_tn_.assign(B * rs, 0);
+    raw_bez_.assign((size_t)B * nm * 18 * rs, 0); raw_poly_.assign((size_t)B * nm * 18 * rs, 0); raw_T_.assign((size_t)B * nm * rs, 0);
+    direct_ddp_batch_out_t out{};
+    out.mem = DIRECT_MEM_HOST; out.rtn = rtn_.data(); out.iter_used = iter_.data();
+    out.infeas_out = inf_out.data(); out.line_failed_out = lf_out.data();
+    out.cost = raw_cost_.data(); out.jerk_cost = raw_jerk_.data(); out.terminal_norm2 = raw_tn_.data();
+    out.bez = raw_bez_.data(); out.poly = raw_poly_.data(); out.T = raw_T_.data();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (direct_ddp_solve_batch(dev_.handle(), &p, &in, &out) != DIRECT_OK) throw std::runtime_error(direct_ddp_last_error());
+    compTime_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    infeas = inf_out;
+    (void)line_failed;  // only written by the line-init exit (ddp_optimizer.cpp:384), not supported on the device yet
+    return std::vector<int>(rtn_.begin(), rtn_.end());
+  }
+
+  // getters (ddp_optimizer.h:299-340), per corridor b
+  Mat getPolyCoeff(int b = 0) const { return rows18(raw_poly_, b); }
+  Mat getBezCoeff(int b = 0) const { return rows18(raw_bez_, b); }
+  Vec getPolyTime(int b = 0) const {
+    Vec v(n_seg_[b]);
+    for (int k = 0; k < n_seg_[b]; k++) v(k) = at(raw_T_, (size_t)b * dev_.n_seg_max() + k);
+    return v;
+  }
+  double getDDPObjective(int b = 0) const { return at(raw_cost_, b); }
+  double getCompTime() const { return compTime_; }
+  double getTerminalNorm(int b = 0) const { return at(raw_tn_, b); }
+  int getIterUsed(int b = 0) const { return iter_[b]; }
+  double getJerkCost(int b = 0) const { return at(raw_jerk_, b); }
+
+ private:
+  double at(const std::vector<uint8_t>& raw, size_t i) const {
+    return dev_.dtype() == DIRECT_F64 ? ((const double*)raw.data())[i] : (double)((const float*)raw.data())[i];
+  }
+  Mat rows18(const std::vector<uint8_t>& raw, int b) const {
+    Mat m(n_seg_[b], 18);
+    for (int k = 0; k < n_seg_[b]; k++)
+      for (int q = 0; q < 18; q++) m(k, q) = at(raw, ((size_t)b * dev_.n_seg_max() + k) * 18 + q);
+    return m;
+  }
+  DdpDevice& dev_;
+  std::vector<int32_t> n_seg_, rtn_, iter_;
+  std::vector<uint8_t> raw_cost_, raw_jerk_, raw_tn_, raw_bez_, raw_poly_, raw_T_;
+  double compTime_ = 0.0;
+};
+
+}  // namespace direct

@@ -22,6 +22,7 @@
  */
 #include "../include/direct_ddp.h"
 
+#include <malloc.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1343,6 +1344,10 @@ int direct_ref_solve_batch(const direct_ddp_params_t* pr, const direct_ddp_batch
   if (!pr || !in || !out) return DIRECT_ERR_INVALID;
   if (pr->time_power != 1 && pr->time_power != 2) return DIRECT_ERR_INVALID;
   int B = in->batch;
+  /* keep the per-problem work arrays (a few MB) on the per-thread malloc arenas: with the default
+   * mmap threshold every solve would mmap/munmap them and 100+ threads serialise in the kernel */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel for schedule(dynamic, 1)

@@ -1,0 +1,90 @@
+// C++ host-side check (GPU needed): drives the reference-shaped class of direct_amd/host/ddp_optimizer.hpp
+// exactly as fastTrajPlanning does (teach_repeat_planner.cpp:886-921: phase 0, UpdateTime, phase 1) and
+// compares the result with the CPU oracle linked in as the checker.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../direct_amd/host/ddp_optimizer.hpp"
+
+extern "C" int direct_ref_plan_batch(const direct_ddp_params_t*, const direct_ddp_params_t*, const direct_ddp_batch_in_t*,
+                                     direct_ddp_batch_out_t*, direct_ddp_batch_out_t*, int);
+
+using direct::DenseMatrix;
+using direct::DenseVector;
+
+int main() {
+  const int N = 6, B = 2;
+  std::vector<decomp_cvx_space::FlightCorridor> cors(B);
+  std::vector<DenseMatrix> pos, vel, acc, jer, bez0;
+  for (int b = 0; b < B; b++) {
+    DenseMatrix p(2, 3), z(2, 3);
+    p(0, 0) = 1.0 + b; p(0, 1) = -2.0; p(0, 2) = 1.0;
+    p(1, 0) = p(0, 0) + 2.5 * N; p(1, 1) = -2.0 + 0.3 * N; p(1, 2) = 1.2;
+    for (int k = 0; k < N; k++) {
+      decomp_cvx_space::Polytope pl;
+      const double cx = p(0, 0) + 2.5 * (k + 0.5), cy = -2.0 + 0.3 * (k + 0.5), cz = 1.1;
+      // axis-aligned box of half-width (2.6, 1.5, 1.0) around the segment midpoint, plus one slanted cut
+      const double hx = 2.6, hy = 1.5, hz = 1.0;
+      pl.appendPlane({1, 0, 0, -(cx + hx)}); pl.appendPlane({-1, 0, 0, cx - hx});
+      pl.appendPlane({0, 1, 0, -(cy + hy)}); pl.appendPlane({0, -1, 0, cy - hy});
+      pl.appendPlane({0, 0, 1, -(cz + hz)}); pl.appendPlane({0, 0, -1, cz - hz});
+      const double s = std::sqrt(0.5);
+      pl.appendPlane({0, s, s, -(s * cy + s * cz + 1.2)});
+      pl.seed_coord = {p(0, 0) + 2.5 * k, -2.0 + 0.3 * k, 1.0};
+      cors[b].appendPolytope(pl);
+      cors[b].appendTime(2.2);
+    }
+    pos.push_back(p); vel.push_back(z); acc.push_back(z); jer.push_back(z);
+    bez0.push_back(DenseMatrix(N, 18));
+  }
+  direct::DdpDevice dev(B, N, 8, DIRECT_F64);
+  DenseMatrix none(1, 1);
+  std::vector<uint8_t> infeas(B, 1), line_failed(B, 1);
+  direct::ddpTrajOptimizer<> opt0(dev), opt1(dev);
+  // phase 0 (TRP:895-897)
+  auto rtn0 = opt0.polyCurveGeneration(cors, none, none, pos, vel, acc, jer, 3.0, 2.0, 2.0, 10.0, bez0, 1.0, 1.0, 1.0, 50,
+                                       infeas, true, false, line_failed, 2, false);
+  std::vector<DenseMatrix> bez1;
+  auto cors1 = cors;
+  for (int b = 0; b < B; b++) {
+    if (rtn0[b] == 2) {  // UpdateTime (TRP:911-915)
+      auto T = opt0.getPolyTime(b);
+      cors1[b].durations.clear();
+      for (int k = 0; k < T.size(); k++) cors1[b].appendTime(T(k));
+    }
+    bez1.push_back(opt0.getBezCoeff(b));  // TRP:918
+  }
+  // phase 1 (TRP:919-921)
+  auto rtn1 = opt1.polyCurveGeneration(cors1, none, none, pos, vel, acc, jer, 3.0, 2.0, 2.0, 10.0, bez1, 1.0, 100.0, 20.0, 100,
+                                       infeas, false, false, line_failed, 2, false);
+
+  // the oracle on the same flat inputs
+  std::vector<int32_t> n_seg(B, N), n_planes((size_t)B * N, 7), r0(B), r1(B), it1(B);
+  std::vector<double> x0(B * 9, 0.0), xd(B * 9, 0.0), T0((size_t)B * N), planes((size_t)B * N * 8 * 4, 0.0), c1(B), Tout((size_t)B * N);
+  for (int b = 0; b < B; b++) {
+    for (int d = 0; d < 3; d++) { x0[b * 9 + d] = pos[b](0, d); xd[b * 9 + d] = pos[b](1, d); }
+    for (int k = 0; k < N; k++) {
+      T0[(size_t)b * N + k] = 2.2;
+      for (int p = 0; p < 7; p++)
+        for (int q = 0; q < 4; q++) planes[(((size_t)b * N + k) * 8 + p) * 4 + q] = cors[b].polyhedrons[k].planes[p][q];
+    }
+  }
+  direct_ddp_params_t p0{2.0, 2.0, 1.0, 1.0, 1.0, 50, 2, 1, 0, 0, 1, 0, 0}, p1{2.0, 2.0, 1.0, 100.0, 20.0, 100, 2, 0, 0, 0, 0, 0, 0};
+  direct_ddp_batch_in_t in{};
+  in.batch = B; in.n_seg_max = N; in.p_max = 8; in.mem = DIRECT_MEM_HOST; in.n_seg = n_seg.data(); in.x0 = x0.data();
+  in.xd = xd.data(); in.T0 = T0.data(); in.n_planes = n_planes.data(); in.planes = planes.data();
+  direct_ddp_batch_out_t o0{}, o1{};
+  o0.rtn = r0.data(); o1.rtn = r1.data(); o1.iter_used = it1.data(); o1.cost = c1.data(); o1.T = Tout.data();
+  direct_ref_plan_batch(&p0, &p1, &in, &o0, &o1, 1);
+  int bad = 0;
+  for (int b = 0; b < B; b++) {
+    const double rel = std::fabs(opt1.getDDPObjective(b) / c1[b] - 1.0);
+    std::printf("corridor %d: rtn0 %d/%d rtn1 %d/%d iters %d/%d cost %.9g/%.9g rel %.2e T0 %.6f/%.6f\n", b, rtn0[b], r0[b], rtn1[b],
+                r1[b], opt1.getIterUsed(b), it1[b], opt1.getDDPObjective(b), c1[b], rel, opt1.getPolyTime(b)(0), Tout[(size_t)b * N]);
+    if (rtn0[b] != r0[b] || rtn1[b] != r1[b] || opt1.getIterUsed(b) != it1[b] || rel > 1e-8) bad++;
+  }
+  std::printf(bad ? "FAIL\n" : "PASS\n");
+  return bad ? 1 : 0;
+}

@@ -164,3 +164,17 @@ def test_best_cost_reduction(built):
     want = np.where(rtn >= 0, cost, np.inf)
     assert i == int(np.argmin(want)) and abs(c - float(want.min())) < 1e-6
     s.close()
+
+
+def test_cpp_host_shim_two_phase_plan(built, tmp_path):
+    """The reference-shaped C++ class (direct_amd/host/ddp_optimizer.hpp) driven like fastTrajPlanning."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_shim")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(root, "tests/cpp/test_shim.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "direct_amd/lib"), "-ldirect_ddp",
+                           "-L" + os.path.join(root, "oracle"), "-ldirect_ref",
+                           "-Wl,-rpath," + os.path.join(root, "direct_amd/lib") + ":" + os.path.join(root, "oracle") + ":/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
