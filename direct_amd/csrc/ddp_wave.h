@@ -25,6 +25,7 @@ namespace direct {
 using std::fabs; using std::fmax; using std::fmin; using std::log; using std::pow; using std::sqrt;
 }
 #define DDP_DEV inline
+#define DDP_DEV_NOINLINE inline
 #define LANES for (int lane = 0; lane < 64; ++lane)
 #define PLV(T, name) T name[64]
 #define PLA(T, name, n) T name[64][n]
@@ -32,10 +33,17 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define WSYNC() ((void)0)
 #define RDLANE(arr, idx, src) (arr[src][idx])
 #define DDP_UNIFORM_I(x) (x)
+#define DDP_LAUNDER_S(x) ((void)0)
+#define DDP_LOADS_ISSUED() ((void)0)
 #define DDP_MARK(name)
 #else
 #include <hip/hip_runtime.h>
 #define DDP_DEV __device__ __forceinline__
+#ifdef DDP_NOINLINE_SWEEPS
+#define DDP_DEV_NOINLINE __device__ __attribute__((noinline))
+#else
+#define DDP_DEV_NOINLINE __device__ __forceinline__
+#endif
 // `lane` is laundered through an empty asm so that LICM cannot hoist the dozens of lane-derived
 // indices and loop-invariant LDS table reads of every phase out of the knot loop (that costs >128
 // VGPRs and with them the occupancy); re-deriving them per phase is a handful of integer ops.
@@ -43,11 +51,29 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define PLV(T, name) T name
 #define PLA(T, name, n) T name[n]
 #define LV(name) name
-#define WSYNC() __syncthreads()
+// Wave-local phase boundary.  One workgroup is one wavefront and the LDS unit executes a wave's DS
+// instructions in order, so a ds_write is visible to every later ds_read of the same wave without any
+// wait; all that is needed is that the COMPILER does not reorder LDS accesses across the boundary.
+// (__syncthreads() would also emit s_waitcnt vmcnt(0) and stall every phase on the outstanding HBM
+// prefetch loads and gain stores.)  Global memory is only ever re-read by the lane that wrote it.
+#define WSYNC()                                  \
+  do {                                           \
+    asm volatile("" ::: "memory");               \
+    __builtin_amdgcn_wave_barrier();             \
+  } while (0)
 #define RDLANE(arr, idx, src) direct::readlane_real(arr[idx], src)
 #define DDP_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
+// re-materialise a wave-uniform value: stops LICM from hoisting everything derived from it (slab
+// pointers, strides) out of the outer iteration loop, where it would stay live across both sweeps
+#define DDP_LAUNDER_S(x) asm volatile("" : "+s"(x))
+// Compiler-only memory barrier placed after a block of LDS operand loads: the scheduler otherwise
+// sinks each load next to its use (3 loads, wait, 2 FMAs, 3 loads, wait ...) and every wait exposes
+// a full LDS round trip; with the barrier all loads of the block are in flight before the first wait.
+#define DDP_LOADS_ISSUED() asm volatile("" ::: "memory")
 #if defined(DDP_MARKS)  // phase markers in the .s for static instruction accounting (tools/phase_count.py)
 #define DDP_MARK(name) asm volatile("; DDP_MARK " name ::: "memory")
+#elif defined(DDP_TIMING)  // per-phase cycle accounting with s_memtime (tools/phase_timing.py); debug builds only
+#define DDP_MARK(name) direct::phase_tick(name)
 #else
 #define DDP_MARK(name)
 #endif
@@ -58,6 +84,30 @@ namespace direct {
 constexpr int kPLim = 32;  // DIRECT_P_LIMIT
 
 #if !defined(DIRECT_EMULATE)
+#if defined(DDP_TIMING)
+__device__ unsigned long long g_phase_cycles[32];
+__device__ unsigned long long g_phase_last;
+__device__ __forceinline__ constexpr int phase_id(const char* n) {
+  // B_L 0 B_T1 1 B_T2 2 B_R1 3 B_S 4 B_S2 5 B_H 6 B_C 7 B_G 8 B_R2 9 B_END 10 F_L 11 F_D 12 F_T 13 F_R 14 F_END 15
+  return n[0] == 'B' ? (n[2] == 'L' ? 0 : n[2] == 'T' ? (n[3] == '1' ? 1 : 2) : n[2] == 'R' ? (n[3] == '1' ? 3 : 9)
+                        : n[2] == 'S' ? (n[3] == '2' ? 5 : 4) : n[2] == 'H' ? 6 : n[2] == 'C' ? 7 : n[2] == 'G' ? 8 : 10)
+                     : (n[2] == 'L' ? 11 : n[2] == 'D' ? 12 : n[2] == 'T' ? 13 : n[2] == 'R' ? 14 : 15);
+}
+// time since the previous mark is charged to the phase that ENDS here (= the previous mark's phase)
+__device__ __forceinline__ void phase_tick(const char* name) {
+  if (blockIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    unsigned long long t = __builtin_readcyclecounter();
+    static __device__ int last_id;
+    if (threadIdx.x == 0) {
+      g_phase_cycles[last_id] += t - g_phase_last;
+      g_phase_cycles[16 + last_id] += 1;
+      g_phase_last = t;
+      last_id = phase_id(name);
+    }
+  }
+}
+#endif
 __device__ __forceinline__ int opaque_lane() {
   int l = (int)threadIdx.x;
   asm volatile("" : "+v"(l));
@@ -84,10 +134,17 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 __device__ __forceinline__ int wave_any(int v) { return __any(v) ? 1 : 0; }
+// number of lanes below this one with a non-zero flag (exclusive prefix count) and the wave total
+__device__ __forceinline__ int wave_prefix_count(int flag, int& total) {
+  const unsigned long long m = __ballot(flag);
+  total = __popcll(m);
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 #define WAVE_SUM_D(name) direct::wave_sum_d((double)(name))
 #define WAVE_MAX_D(name) direct::wave_max_d((double)(name))
 #define WAVE_SUM_I(name) direct::wave_sum_i(name)
 #define WAVE_ANY(name) direct::wave_any(name)
+#define WAVE_PREFIX_COUNT(flag, pos, total) pos = direct::wave_prefix_count(flag, total)
 #else
 template <typename T>
 inline double emu_sum_d(const T* v) {
@@ -117,6 +174,14 @@ inline int emu_any(const int* v) {
 #define WAVE_MAX_D(name) direct::emu_max_d(name)
 #define WAVE_SUM_I(name) direct::emu_sum_i(name)
 #define WAVE_ANY(name) direct::emu_any(name)
+#define WAVE_PREFIX_COUNT(flag, pos, total)                 \
+  do {                                                      \
+    total = 0;                                              \
+    for (int l_ = 0; l_ < 64; l_++) {                       \
+      pos[l_] = total;                                      \
+      total += flag[l_] ? 1 : 0;                            \
+    }                                                       \
+  } while (0)
 #endif
 
 // ---- per-solve constants (by-value arguments of polyCurveGeneration, DDPH:275-289) ------------
@@ -197,11 +262,8 @@ struct WaveLds {
         struct {
           Acc cbuf[10], rdiag[10], Ub[100];  // Cholesky: pivot column, 1/L_kk, L^T (phase C)
         };
-        struct {
-          Acc W1[81], W2[90];  // Hxu Ku, Huu Ku (phases G, R2)
-        };
       };
-      Acc t10[10], hk[10];
+      Acc Yb[100];  // [y | Y] = L^-1 [Hu | Hux], column c at Yb[k*10 + c] (phases C, R2)
     };
     struct {  // ---- forward pass / evaluation sweep only
       Real tpn[8], zn[kXS], dz[kXS], xn[12], xnx[12], valn[48], qp[12];
@@ -318,8 +380,8 @@ struct Wave {
   const Batch<St>& B;
   Lds& L;
   TrajState& st;
-  const int b;  // trajectory
-  int N;        // segments
+  int b;  // trajectory
+  int N;  // segments
 
   DDP_DEV Wave(const Batch<St>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
 
@@ -677,7 +739,9 @@ struct Wave {
   }
 
   // ---- backward sweep (DDP:440-644).  Returns 1 on success, 0 when the LLT failed. ---------------
-  DDP_DEV int bwd_sweep() {
+  DDP_DEV_NOINLINE int bwd_sweep() {
+    DDP_LAUNDER_S(b);
+    DDP_LAUNDER_S(N);
     {  // regulariser schedule (DDP:452-474)
       int reg = st.reg;
       if (st.fp_failed || st.bp_failed) reg += 1;
@@ -754,13 +818,20 @@ struct Wave {
       LANES {
         if (lane < 45) {
           int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
-          Real v = 0, dv = 0;
+          Real v = 0, dv = 0, z6[6], we6[6], wd6[6], tp6[6];
 #pragma unroll
           for (int i = 0; i < 6; i++) {
-            Real zi = L.z[3 * i + d];
-            v += L.We[cr * 6 + i] * zi;
-            int e = i - o - 1;
-            dv += L.WdE[cr * 6 + i] * L.tp[e < 0 ? 0 : e] * zi;  // WdE is 0 where e < 0
+            const int e = i - o - 1;
+            z6[i] = L.z[3 * i + d];
+            we6[i] = L.We[cr * 6 + i];
+            wd6[i] = L.WdE[cr * 6 + i];
+            tp6[i] = L.tp[e < 0 ? 0 : e];  // WdE is 0 where e < 0
+          }
+          DDP_LOADS_ISSUED();
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            v += we6[i] * z6[i];
+            dv += wd6[i] * tp6[i] * z6[i];
           }
           L.val[lane] = v;
           L.dval[lane] = dv;
@@ -823,11 +894,26 @@ struct Wave {
           Acc acc = 0;
           if (q < 18) {
             int i = q / 3, d = q % 3;
+            Acc v3[3];
+            Real h3[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc += L.V[a * 9 + 3 * c + d] * L.H[c * 6 + i];
+            for (int c = 0; c < 3; c++) {
+              v3[c] = L.V[a * 9 + 3 * c + d];
+              h3[c] = L.H[c * 6 + i];
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc += v3[c] * h3[c];
           } else {
+            Acc v9[9], f9[9];
 #pragma unroll
-            for (int c = 0; c < 9; c++) acc += L.V[a * 9 + c] * L.fT[c];
+            for (int c = 0; c < 9; c++) {
+              v9[c] = L.V[a * 9 + c];
+              f9[c] = L.fT[c];
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int c = 0; c < 9; c++) acc += v9[c] * f9[c];
           }
           L.VZ[e] = acc;
         }
@@ -907,16 +993,27 @@ struct Wave {
           const int p = w & 31, q = (w >> 5) & 31, i = (w >> 10) & 7, d = (w >> 13) & 3;
           const int i2 = (w >> 15) & 7, sidx = (w >> 20) & 7, dd = (w >> 23) & 1;
           Acc ada = 0, zvz = 0;
+          Real w1[6], w2[6], hh3[3];
+          Acc sp6[6], vz3[3];
 #pragma unroll
-          for (int cr = 0; cr < 6; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.Sp[cr * 6 + sidx];
-          if (dd) {
-#pragma unroll 3
-            for (int cr = 6; cr < 15; cr++) ada += L.We[cr * 6 + i] * L.We[cr * 6 + i2] * L.dl[(cr - 6) * 3 + d];
+          for (int cr = 0; cr < 6; cr++) {
+            w1[cr] = L.We[cr * 6 + i];
+            w2[cr] = L.We[cr * 6 + i2];
+            sp6[cr] = L.Sp[cr * 6 + sidx];
           }
 #pragma unroll
-          for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + q];
-          Acc quu = 0;
-          if (i >= 3 && dd) quu = wsn * L.Rc[(i - 3) * 3 + (i2 - 3)] * L.tp[i + i2 - 5];
+          for (int c = 0; c < 3; c++) {
+            hh3[c] = L.H[c * 6 + i];
+            vz3[c] = L.VZ[(3 * c + d) * 19 + q];
+          }
+          const bool hasq = (i >= 3 && dd);
+          const Real rc1 = L.Rc[hasq ? (i - 3) * 3 + (i2 - 3) : 0], tp1 = L.tp[hasq ? i + i2 - 5 : 0];
+          DDP_LOADS_ISSUED();
+#pragma unroll
+          for (int cr = 0; cr < 6; cr++) ada += w1[cr] * w2[cr] * sp6[cr];
+#pragma unroll
+          for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
+          const Acc quu = hasq ? wsn * rc1 * tp1 : (Acc)0;
           const Acc v = zvz + quu + sig * ada;
           if (q < 9) {
             L.Hxx[p * 9 + q] = v;
@@ -928,13 +1025,59 @@ struct Wave {
             L.Huu[(q - 9) * 10 + (p - 9)] = v;
           }
         }
+      }
+      WSYNC();
+      LANES {
+        if (lane < 63) {  // velocity / acceleration rows only touch entries with d == d2: 21 (i,i2) pairs x 3 axes
+          const int pr = lane / 3, d = lane % 3;
+          int i = 0, rem = pr;
+          while (rem >= 6 - i) {
+            rem -= 6 - i;
+            i++;
+          }
+          const int i2 = i + rem, p = 3 * i + d, q = 3 * i2 + d;
+          Acc ada = 0;
+          Real w1[9], w2[9];
+          Acc dl9[9];
+#pragma unroll
+          for (int cr = 0; cr < 9; cr++) {
+            w1[cr] = L.We[(cr + 6) * 6 + i];
+            w2[cr] = L.We[(cr + 6) * 6 + i2];
+            dl9[cr] = L.dl[cr * 3 + d];
+          }
+          DDP_LOADS_ISSUED();
+#pragma unroll
+          for (int cr = 0; cr < 9; cr++) ada += w1[cr] * w2[cr] * dl9[cr];
+          ada *= sig;
+          if (q < 9) {
+            const Acc v = L.Hxx[p * 9 + q] + ada;
+            L.Hxx[p * 9 + q] = v;
+            L.Hxx[q * 9 + p] = v;
+          } else if (p < 9) {
+            L.Hxu[p * 10 + (q - 9)] += ada;
+          } else {
+            const Acc v = L.Huu[(p - 9) * 10 + (q - 9)] + ada;
+            L.Huu[(p - 9) * 10 + (q - 9)] = v;
+            L.Huu[(q - 9) * 10 + (p - 9)] = v;
+          }
+        }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
           const int p = lane < 18 ? lane : lane - 18;
           const int i = p / 3, d = p % 3;
           const Acc* vec = lane < 18 ? L.Sd : L.hh;
           Acc acc = 0;
-#pragma unroll 5
-          for (int cr = 0; cr < 15; cr++) acc += L.We[cr * 6 + i] * vec[cr * 3 + d];
+          {
+            Real w1[15];
+            Acc v15[15];
+#pragma unroll
+            for (int cr = 0; cr < 15; cr++) {
+              w1[cr] = L.We[cr * 6 + i];
+              v15[cr] = vec[cr * 3 + d];
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int cr = 0; cr < 15; cr++) acc += w1[cr] * v15[cr];
+          }
           if (lane < 18) {
             Acc zvz = 0;
 #pragma unroll
@@ -1018,9 +1161,10 @@ struct Wave {
         return 0;
       }
       LANES {
-        if (lane < 10) {
+        if (lane < 20) {
+          Acc* dstc = lane < 10 ? &L.Ub[lane] : &L.Yb[lane - 10];
 #pragma unroll
-          for (int i = 0; i < 10; i++) L.Ub[i * 10 + lane] = LV(m)[i];  // U[i][j] = L[j][i]
+          for (int i = 0; i < 10; i++) dstc[i * 10] = LV(m)[i];  // U[i][j] = L[j][i];  [y | Y] = L^-1 [Hu | Hux]
         }
       }
       WSYNC();
@@ -1051,21 +1195,6 @@ struct Wave {
 #pragma unroll
           for (int i = 3; i < 6; i++) acc += L.We[cr * 6 + i] * L.KU[(i - 3) * 3 + d];
           L.G[lane] = (Real)acc;
-        }
-#pragma unroll 1
-        for (int e = lane; e < 190; e += 64) {
-          // W1 = Hxu Ku (81) | W2 = Huu Ku (90) | t10 = Huu ku (10) | hk = Hxu ku (9): all 10-term dots
-          int koff, kstr;
-          const Acc* hp;
-          Acc* dst;
-          if (e < 81) { hp = &L.Hxu[(e / 9) * 10]; koff = 10 + e % 9; kstr = 9; dst = &L.W1[e]; }
-          else if (e < 171) { hp = &L.Huu[((e - 81) / 9) * 10]; koff = 10 + (e - 81) % 9; kstr = 9; dst = &L.W2[e - 81]; }
-          else if (e < 181) { hp = &L.Huu[(e - 171) * 10]; koff = 0; kstr = 1; dst = &L.t10[e - 171]; }
-          else { hp = &L.Hxu[(e - 181) * 10]; koff = 0; kstr = 1; dst = &L.hk[e - 181]; }
-          Acc acc = 0;
-#pragma unroll 5
-          for (int c = 0; c < 10; c++) acc += hp[c] * L.KU[koff + c * kstr];
-          *dst = acc;
         }
       }
       WSYNC();
@@ -1098,29 +1227,45 @@ struct Wave {
         }
 #pragma unroll 1
         for (int e = lane; e < 100; e += 64) KUp(k)[e] = (St)L.KU[e];
-        if (lane < 45) {  // Vxx (DDP:627-628), pairs a <= c2.  V is dead since phase R1: overwrite in place
-          int a = 0, rem = lane;
+        // Value-function recursion (DDP:626-628).  With [y | Y] = L^-1 [Hu | Hux], LL' = Huu + lam I and
+        // [ku | Ku] = -(Huu + lam I)^-1 [Hu | Hux] the reference's
+        //   Vxx = Hxx + Hxu Ku + (Hxu Ku)' + Ku' Huu Ku,   Vx = Hx + Ku'Hu + Ku'Huu ku + Hxu ku
+        // are identically  Vxx = Hxx - Y'Y - lam Ku'Ku,   Vx = Hx - Y'y - lam Ku'ku   (10-term dots instead
+        // of two 10x10x9 products).  V / Vx are dead since phases R1 / H: overwritten in place.
+        {
+          const int l45 = lane < 45 ? lane : 44;
+          int a = 0, rem = l45;
           while (rem >= 9 - a) {
             rem -= 9 - a;
             a++;
           }
           const int c2 = a + rem;
-          Acc m1 = L.Hxx[a * 9 + c2] + L.W1[a * 9 + c2] + L.W1[c2 * 9 + a];
-          Acc m2 = m1;
-#pragma unroll 5
-          for (int c = 0; c < 10; c++) {
-            m1 += L.KU[10 + c * 9 + a] * L.W2[c * 9 + c2];
-            m2 += L.KU[10 + c * 9 + c2] * L.W2[c * 9 + a];
+          const int aa = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
+          // lanes 0..44: (colA, colB) = Y columns 1+a, 1+c2;  lanes 45..53: Y column 1+aa against y (column 0)
+          const int cA = lane < 45 ? 1 + a : 1 + aa, cB = lane < 45 ? 1 + c2 : 0;
+          Acc ya[10], yb[10], ka[10], kb[10];
+#pragma unroll
+          for (int k2 = 0; k2 < 10; k2++) {
+            ya[k2] = L.Yb[k2 * 10 + cA];
+            yb[k2] = L.Yb[k2 * 10 + cB];
+            ka[k2] = (cA == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cA - 1)];
+            kb[k2] = (cB == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cB - 1)];
           }
-          const Acc vnew = (Acc)0.5 * (m1 + m2);
-          L.V[a * 9 + c2] = vnew;
-          L.V[c2 * 9 + a] = vnew;
-        } else if (lane < 54) {  // Vx (DDP:626); Vx is dead since phase H
-          const int aa = lane - 45;
-          Acc v2 = L.Hz[aa] + L.hk[aa];
-#pragma unroll 5
-          for (int c = 0; c < 10; c++) v2 += L.KU[10 + c * 9 + aa] * (L.Hz[9 + c] + L.t10[c]);
-          L.Vx[aa] = v2;
+          const Acc h0 = lane < 45 ? L.Hxx[a * 9 + c2] : L.Hz[aa];
+          DDP_LOADS_ISSUED();
+          Acc yy = 0, kk2 = 0;
+#pragma unroll
+          for (int k2 = 0; k2 < 10; k2++) {
+            yy += ya[k2] * yb[k2];
+            kk2 += ka[k2] * kb[k2];
+          }
+          const Acc vnew = h0 - yy - lam * kk2;
+          if (lane < 45) {
+            L.V[a * 9 + c2] = vnew;
+            L.V[c2 * 9 + a] = vnew;
+          } else if (lane < 54) {
+            L.Vx[aa] = vnew;
+          }
         }
       }
       WSYNC();
@@ -1134,7 +1279,9 @@ struct Wave {
   }
 
   // ---- forward pass (DDP:647-778) ---------------------------------------------------------------
-  DDP_DEV void fwd_pass() {
+  DDP_DEV_NOINLINE void fwd_pass() {
+    DDP_LAUNDER_S(b);
+    DDP_LAUNDER_S(N);
     const int cur = DDP_UNIFORM_I(st.cur), nxt = 1 - cur;
     const int infeas = DDP_UNIFORM_I(st.infeas);
     const double mu_d = st.mu;
@@ -1222,16 +1369,28 @@ struct Wave {
           if (lane < 45) {
             int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
             Real vo = 0, dvo = 0, vn = 0, gf = 0;
+            Real wb6[6], wd6[6], t0[6], t1[6], tn6[6], zo6[6], dz6[6], zn6[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-              int e = i - o;
-              int e0 = e < 0 ? 0 : e, e1 = e < 1 ? 0 : e - 1;
-              Real wb = L.WbE[cr * 6 + i];
-              Real w = wb * L.tp[e0];
-              vo += w * L.z[3 * i + d];
-              gf += w * L.dz[3 * i + d];
-              dvo += L.WdE[cr * 6 + i] * L.tp[e1] * L.z[3 * i + d];
-              vn += wb * L.tpn[e0] * L.zn[3 * i + d];
+              const int e = i - o;
+              const int e0 = e < 0 ? 0 : e, e1 = e < 1 ? 0 : e - 1;
+              wb6[i] = L.WbE[cr * 6 + i];
+              wd6[i] = L.WdE[cr * 6 + i];
+              t0[i] = L.tp[e0];
+              t1[i] = L.tp[e1];
+              tn6[i] = L.tpn[e0];
+              zo6[i] = L.z[3 * i + d];
+              dz6[i] = L.dz[3 * i + d];
+              zn6[i] = L.zn[3 * i + d];
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+              const Real w = wb6[i] * t0[i];
+              vo += w * zo6[i];
+              gf += w * dz6[i];
+              dvo += wd6[i] * t1[i] * zo6[i];
+              vn += wb6[i] * tn6[i] * zn6[i];
             }
             L.val[lane] = vo;
             L.valn[lane] = vn;
@@ -1304,26 +1463,43 @@ struct Wave {
       viol = WAVE_SUM_I(nviol);
       logcost = cost - mu_d * sumlog;  // DDP:718-732
       err = infeas ? fmax(B.k.tol, errsum) : 0.0;
-      // filter (DDP:737-757)
+      // filter (DDP:737-757), one entry per lane: a serial scan would chain one HBM round trip per entry
       int rejected = 0;
-      for (int i = 0; i < nfilter; i++) {
-        double f0 = filt[2 * i], f1 = filt[2 * i + 1];
-        if (logcost >= f0 && err >= f1) {
-          rejected = 1;
-          break;
+      for (int base = 0; base < nfilter && !rejected; base += 64) {
+        PLV(int, rej);
+        LANES {
+          const int idx = base + lane;
+          const bool valid = idx < nfilter;
+          const double f0 = valid ? filt[2 * idx] : 0.0, f1 = valid ? filt[2 * idx + 1] : 0.0;
+          LV(rej) = (valid && logcost >= f0 && err >= f1) ? 1 : 0;
         }
+        rejected = WAVE_ANY(rej);
       }
       if (rejected) continue;
       nkeep = 0;
-      for (int i = 0; i < nfilter; i++) {
-        double f0 = filt[2 * i], f1 = filt[2 * i + 1];
-        if (logcost > f0 || err > f1) {  // wave-uniform stores (nkeep <= i)
-          filt[2 * nkeep] = f0;
-          filt[2 * nkeep + 1] = f1;
-          nkeep++;
+      for (int base = 0; base < nfilter; base += 64) {
+        PLV(int, keep);
+        PLV(int, pos);
+        PLV(double, e0);
+        PLV(double, e1);
+        LANES {
+          const int idx = base + lane;
+          const bool valid = idx < nfilter;
+          LV(e0) = valid ? filt[2 * idx] : 0.0;
+          LV(e1) = valid ? filt[2 * idx + 1] : 0.0;
+          LV(keep) = (valid && (logcost > LV(e0) || err > LV(e1))) ? 1 : 0;
         }
+        int total;
+        WAVE_PREFIX_COUNT(keep, pos, total);
+        LANES {
+          if (LV(keep)) {  // compaction in place: nkeep + pos <= base + lane
+            filt[2 * (nkeep + LV(pos))] = LV(e0);
+            filt[2 * (nkeep + LV(pos)) + 1] = LV(e1);
+          }
+        }
+        nkeep += total;
       }
-      filt[2 * nkeep] = logcost;
+      filt[2 * nkeep] = logcost;  // wave-uniform stores
       filt[2 * nkeep + 1] = err;
       accepted = 1;
       break;

@@ -603,6 +603,20 @@ direct_status_t direct_ddp_best_cost(direct_ddp_handle_t h, int32_t mem, const v
   return DIRECT_OK;
 }
 
+#if defined(DDP_TIMING)
+// debug builds only (not declared in the header): per-phase cycle totals of workgroup 0
+direct_status_t direct_ddp_debug_phase_cycles(unsigned long long* out32, int reset) {
+  if (reset) {
+    unsigned long long z[32] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(direct::g_phase_cycles), z, sizeof z));
+    return DIRECT_OK;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(direct::g_phase_cycles), 32 * sizeof(unsigned long long)));
+  return DIRECT_OK;
+}
+#endif
+
 // initTimeAllocation (teach_repeat_planner.cpp:583-639) with v0 = 0: host-side, double precision.
 direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const int32_t* n_seg, const double* start,
                                        const double* goal, const double* seeds, double max_vel, double max_acc,
