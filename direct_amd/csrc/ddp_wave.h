@@ -341,35 +341,17 @@ DDP_DEV Real powi(Real T, int e) {  // T^e for 0 <= e <= 7 without a register-ar
 
 DDP_DEV int ctrl_off(int cr) { return cr < 6 ? 0 : (cr < 11 ? 1 : 2); }
 
-// one constraint row, decoded: kind 0 = position (plane pi, control point vi/3), 1 / 2 = +/- velocity or
-// acceleration component val[vi], 3 = the T >= 0.3 row          (DDP:1181-1188, 1236-1238, 1274-1279)
-struct RowD {
-  int kind, vi, pi;
+// One constraint row as seen by (slot, lane).  Rows are dealt to lanes BY KIND so that a slot runs one
+// kind of code: slots 0..RPL-2 hold position rows r = lane + 64*slot (r < 6P); the last slot holds the
+// 55 velocity / acceleration / T_min rows in lanes 0..54 (r = 6P + lane) and, in lanes 55..63, the few
+// position rows beyond 64*(RPL-1).  HBM arrays stay indexed by r (DDP:1181-1188, 1236-1238, 1274-1279).
+//   position row:  c = n . A[a0..a0+2] + n[3] - shift         (pi = offset of the plane in L.pl)
+//   other rows:    c = sgn * A[a0] + off - shift              (pi = -1; A[45] carries T for the T_min row)
+template <typename Real>
+struct RowK {
+  int r, a0, pi;
+  Real sgn, off;
 };
-DDP_DEV RowD row_decode(int r, int P) {
-  RowD d;
-  int rr = r - 6 * P;
-  if (rr < 0) {
-    int j = (r >= P) + (r >= 2 * P) + (r >= 3 * P) + (r >= 4 * P) + (r >= 5 * P);
-    d.kind = 0;
-    d.vi = 3 * j;
-    d.pi = 4 * (r - j * P);
-  } else if (rr < 30) {
-    d.kind = rr < 15 ? 1 : 2;
-    d.vi = 18 + (rr < 15 ? rr : rr - 15);
-    d.pi = 0;
-  } else if (rr < 54) {
-    int r2 = rr - 30;
-    d.kind = r2 < 12 ? 1 : 2;
-    d.vi = 33 + (r2 < 12 ? r2 : r2 - 12);
-    d.pi = 0;
-  } else {
-    d.kind = 3;
-    d.vi = 0;
-    d.pi = 0;
-  }
-  return d;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Real = arithmetic type of the per-row / roll-out work, St = storage type of everything in HBM
@@ -420,8 +402,8 @@ struct Wave {
     const St* ksk = Sp_(B.KS, k);
     const St* kyk = Sp_(B.KY, k);
     for (int i = 0; i < RPL; i++) {
-      const int r = lane + 64 * i;
-      const bool in = r < nc;
+      const int r = row_slot(i, lane, P).r;
+      const bool in = r >= 0;
       p.s[i] = in ? (Real)sk[r] : (Real)0;
       p.y[i] = (in && infeas) ? (Real)yk[r] : (Real)1;
       if (fwd) {
@@ -523,30 +505,49 @@ struct Wave {
   }
 
   // ---- shared pieces ---------------------------------------------------------------------------
-  // value of row d over the control-value array A: n.A[cp] for position rows, +/-A[vi] otherwise
-  DDP_DEV Real row_lin(const Real* A, const RowD& d) const {
-    if (d.kind == 0) {
-      const Real* n = &L.pl[d.pi];
-      return n[0] * A[d.vi] + n[1] * A[d.vi + 1] + n[2] * A[d.vi + 2];
+  DDP_DEV RowK<Real> row_slot(int slot, int lane, int P) const {
+    RowK<Real> k;
+    k.sgn = (Real)1;
+    k.off = (Real)0;
+    const bool other = (slot == RPL - 1) && lane < 55;
+    if (!other) {
+      const int r = (slot == RPL - 1) ? 64 * (RPL - 1) + lane - 55 : lane + 64 * slot;
+      const int j = (r >= P) + (r >= 2 * P) + (r >= 3 * P) + (r >= 4 * P) + (r >= 5 * P);
+      k.r = (r < 6 * P) ? r : -1;
+      k.a0 = 3 * j;
+      k.pi = (r < 6 * P) ? 4 * (r - j * P) : 0;
+    } else {
+      k.r = 6 * P + lane;
+      k.pi = -1;
+      if (lane < 30) {
+        k.a0 = 18 + (lane < 15 ? lane : lane - 15);
+        k.sgn = lane < 15 ? (Real)1 : (Real)-1;
+        k.off = -(Real)B.k.max_vel;
+      } else if (lane < 54) {
+        const int l2 = lane - 30;
+        k.a0 = 33 + (l2 < 12 ? l2 : l2 - 12);
+        k.sgn = l2 < 12 ? (Real)1 : (Real)-1;
+        k.off = -(Real)B.k.max_acc;
+      } else {
+        k.a0 = 45;  // A[45] = T:  c = -T + 0.3 - shift (DDP:1279)
+        k.sgn = (Real)-1;
+        k.off = (Real)0.3;
+      }
     }
-    if (d.kind == 3) return (Real)0;
-    return d.kind == 1 ? A[d.vi] : -A[d.vi];
+    return k;
   }
-  // constant part of the constraint row: d_k, -vmax, -amax or +0.3, minus the 2e-4 shift (DDP:1279-1283)
-  DDP_DEV Real row_off(const RowD& d) const {
-    Real o;
-    if (d.kind == 0) o = L.pl[d.pi + 3];
-    else if (d.kind == 3) o = (Real)0.3;
-    else o = (d.vi < 33) ? -(Real)B.k.max_vel : -(Real)B.k.max_acc;
-    return o - (Real)B.k.shift;
+  // A_r . w: position rows n . A[cp], other rows +/- A[a0]
+  DDP_DEV Real row_lin(const Real* A, const RowK<Real>& k) const {
+    if (k.pi >= 0) {
+      const Real* n = &L.pl[k.pi];
+      return n[0] * A[k.a0] + n[1] * A[k.a0 + 1] + n[2] * A[k.a0 + 2];
+    }
+    return k.sgn * A[k.a0];
   }
-  // c_r = row_lin(val) + row_off - [T for the last row];  A_r . w = row_lin(G) - [wT for the last row]
-  DDP_DEV Real row_c(const Real* val, const RowD& d, Real T) const {
-    Real c = row_lin(val, d) + row_off(d);
-    return d.kind == 3 ? c - T : c;
-  }
-  DDP_DEV Real row_dot(const Real* G, const RowD& d, Real wT) const {
-    return d.kind == 3 ? -wT : row_lin(G, d);
+  // c_r (val[45] must hold T), shifted by 2e-4 unless minvo (DDP:1281-1283)
+  DDP_DEV Real row_c(const Real* val, const RowK<Real>& k) const {
+    const Real o = (k.pi >= 0) ? L.pl[k.pi + 3] : k.off;
+    return row_lin(val, k) + o - (Real)B.k.shift;
   }
 
   // control values val[cr][d] = sum_i W[cr][i] T^(i-o) C_i[d] from a knot record zz with powers tpw
@@ -619,16 +620,17 @@ struct Wave {
         if (lane < 45) L.val[lane] = ctrl_val(L.z, L.tp, lane / 3, lane % 3);
         else if (lane < 54) { if (do_roll) L.xnx[lane - 45] = next_x(L.z, L.tp, lane - 45); }
         else if (lane < 63) L.qp[lane - 54] = jerk_part(L.z, L.tp, lane - 54);
+        else L.val[45] = T;
       }
       WSYNC();
       qsum += knot_cost(T);
       LANES {
         const St* yk = Sp_(B.Y[buf], k);
         for (int i = 0; i < RPL; i++) {
-          int r = lane + 64 * i;
-          if (r < nc) {
-            RowD rd = row_decode(r, P);
-            Real c = row_c(L.val, rd, T);
+          const RowK<Real> rk = row_slot(i, lane, P);
+          const int r = rk.r;
+          if (r >= 0) {
+            Real c = row_c(L.val, rk);
             if (infeas) {
               Real y = yk[r];
               LV(plog).mul(y);
@@ -835,6 +837,8 @@ struct Wave {
           }
           L.val[lane] = v;
           L.dval[lane] = dv;
+        } else if (lane == 45) {
+          L.val[45] = T;
         }
         if (lane < 27) {  // Ru, R'u, R''u (DDP:1349-1355)
           int t = lane / 9, a9 = lane % 9, a = a9 / 3, d = a9 % 3;
@@ -862,10 +866,10 @@ struct Wave {
       // ---- R1: constraint rows -> D, g ; VZ = Vxx * Z
       LANES {
         for (int i = 0; i < RPL; i++) {
-          int r = lane + 64 * i;
-          if (r < nc) {
-            RowD rd = row_decode(r, P);
-            Real c = row_c(L.val, rd, T), s = LV(rs)[i], y = LV(ry)[i];
+          const RowK<Real> rk = row_slot(i, lane, P);
+          const int r = rk.r;
+          if (r >= 0) {
+            Real c = row_c(L.val, rk), s = LV(rs)[i], y = LV(ry)[i];
             Real D, g, rv;
             if (infeas) {  // DDP:535-539, 554
               Real rm = s * y - mu;
@@ -1195,6 +1199,8 @@ struct Wave {
 #pragma unroll
           for (int i = 3; i < 6; i++) acc += L.We[cr * 6 + i] * L.KU[(i - 3) * 3 + d];
           L.G[lane] = (Real)acc;
+        } else if (lane == 45) {
+          L.G[45] = (Real)L.KU[9];  // the T_min row: A_r . ku = -ku_T
         }
       }
       WSYNC();
@@ -1209,12 +1215,11 @@ struct Wave {
       LANES {
         St* ksg = Sp_(B.KS, k);
         St* kyg = Sp_(B.KY, k);
-        const Real kuT = (Real)L.KU[9];
         for (int i = 0; i < RPL; i++) {
-          int r = lane + 64 * i;
-          if (r < nc) {
-            RowD rd = row_decode(r, P);
-            Real cuku = row_dot(L.G, rd, kuT);
+          const RowK<Real> rk = row_slot(i, lane, P);
+          const int r = rk.r;
+          if (r >= 0) {
+            Real cuku = row_lin(L.G, rk);
             Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
             if (infeas) {  // DDP:568, 571
               Real y = LV(ry)[i];
@@ -1395,6 +1400,10 @@ struct Wave {
             L.val[lane] = vo;
             L.valn[lane] = vn;
             L.G[lane] = gf + dvo * L.dz[18];
+          } else if (lane == 63) {
+            L.val[45] = L.z[18];
+            L.valn[45] = L.zn[18];
+            L.G[45] = L.dz[18];
           } else if (lane < 54) {
             L.xnx[lane - 45] = next_x(L.zn, L.tpn, lane - 45);
           } else if (lane < 63) {
@@ -1410,13 +1419,12 @@ struct Wave {
           LV(bad) = 0;
           St* sn = Sp_(B.S[nxt], k);
           St* yn = Sp_(B.Y[nxt], k);
-          const Real dzT = L.dz[18];
           for (int i = 0; i < RPL; i++) {
-            int r = lane + 64 * i;
-            if (r < nc) {
-              RowD rd = row_decode(r, P);
-              Real az = row_dot(L.G, rd, dzT);
-              Real cn = row_c(L.valn, rd, Tn);
+            const RowK<Real> rk = row_slot(i, lane, P);
+            const int r = rk.r;
+            if (r >= 0) {
+              Real az = row_lin(L.G, rk);
+              Real cn = row_c(L.valn, rk);
               Real s = LV(rs)[i];
               Real snew;
               if (infeas) {  // DDP:680-687
@@ -1428,7 +1436,7 @@ struct Wave {
                 LV(plog).mul(ynew);
                 LV(serr) += fabs(cn + ynew);
               } else {  // DDP:694-703
-                Real co = row_c(L.val, rd, To);
+                Real co = row_c(L.val, rk);
                 snew = (Real)(St)(s + alpha * LV(rks)[i] - (s * frcp(co)) * az);
                 if (cn > omt * co || snew < omt * s) LV(bad) = 1;
                 LV(plog).mul(-cn);
@@ -1718,10 +1726,16 @@ DDP_DEV void get_field_wave(Wave<Real, St, RPL>& W, int field, St* dst) {
       const Real T = W.L.z[18];
       LANES { if (lane < 8) W.L.tp[lane] = powi(T, lane); }
       WSYNC();
-      LANES { if (lane < 45) W.L.val[lane] = W.ctrl_val(W.L.z, W.L.tp, lane / 3, lane % 3); }
+      LANES {
+        if (lane < 45) W.L.val[lane] = W.ctrl_val(W.L.z, W.L.tp, lane / 3, lane % 3);
+        else if (lane == 45) W.L.val[45] = T;
+      }
       WSYNC();
       LANES {
-        for (int r = lane; r < nc; r += 64) dst[rowbase + r] = (St)W.row_c(W.L.val, row_decode(r, P), T);
+        for (int i = 0; i < RPL; i++) {
+          const RowK<Real> rk = W.row_slot(i, lane, P);
+          if (rk.r >= 0) dst[rowbase + rk.r] = (St)W.row_c(W.L.val, rk);
+        }
       }
       WSYNC();
     } else {
