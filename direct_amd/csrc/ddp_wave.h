@@ -259,11 +259,11 @@ struct WaveLds {
       Acc KU[100];
       union {
         Acc VZ[176];  // Vxx * Z: dead after phase H
-        struct {
-          Acc cbuf[10], rdiag[10], Ub[100];  // Cholesky: pivot column, 1/L_kk, L^T (phase C)
-        };
       };
-      Acc Yb[100];  // [y | Y] = L^-1 [Hu | Hux], column c at Yb[k*10 + c] (phases C, R2)
+      // rows of [L^T | y | Y]: UY[k][j] = L[j][k] (j < 10), UY[k][10 + c] = (L^-1 [Hu | Hux])[k][c]; written
+      // one row per elimination step by all column lanes at once (phases C, R2).  Stride 20, 64 slots per
+      // row so that the idle lanes' stores need no masking.
+      Acc UY[10 * 20 + 44], rdiag[10];
     };
     struct {  // ---- forward pass / evaluation sweep only
       Real tpn[8], zn[kXS], dz[kXS], xn[12], xnx[12], valn[48], qp[12];
@@ -388,15 +388,16 @@ struct Wave {
 
   // Software prefetch of the next knot's HBM data into registers: the serial knot recursion would
   // otherwise expose one full memory latency per knot (nothing else is in flight in this wave).
-  struct Pre {
-    Real z, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
+  struct Pre {  // held in the storage type: half the registers in DIRECT_F32
+    Real z;
+    St pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
   DDP_DEV void prefetch(Pre& p, int lane, int buf, int k, int P, bool fwd, int infeas) const {
     const int nc = 6 * P + 55;
     p.z = (lane < 19) ? ldx(Xp(buf, k), lane) : (Real)0;
     const St* pk = planes_(k);
-    p.pl[0] = (lane < 4 * P) ? (Real)pk[lane] : (Real)0;
-    p.pl[1] = (lane + 64 < 4 * P) ? (Real)pk[lane + 64] : (Real)0;
+    p.pl[0] = (lane < 4 * P) ? pk[lane] : (St)0;
+    p.pl[1] = (lane + 64 < 4 * P) ? pk[lane + 64] : (St)0;
     const St* sk = Sp_(B.S[buf], k);
     const St* yk = Sp_(B.Y[buf], k);
     const St* ksk = Sp_(B.KS, k);
@@ -404,26 +405,26 @@ struct Wave {
     for (int i = 0; i < RPL; i++) {
       const int r = row_slot(i, lane, P).r;
       const bool in = r >= 0;
-      p.s[i] = in ? (Real)sk[r] : (Real)0;
-      p.y[i] = (in && infeas) ? (Real)yk[r] : (Real)1;
+      p.s[i] = in ? sk[r] : (St)0;
+      p.y[i] = (in && infeas) ? yk[r] : (St)1;
       if (fwd) {
-        p.ks[i] = in ? (Real)ksk[r] : (Real)0;
-        p.ky[i] = (in && infeas) ? (Real)kyk[r] : (Real)0;
+        p.ks[i] = in ? ksk[r] : (St)0;
+        p.ky[i] = (in && infeas) ? kyk[r] : (St)0;
       }
     }
     if (fwd) {
       const St* ku = KUp(k);
-      p.ku[0] = (Real)ku[lane];
-      p.ku[1] = (lane + 64 < 100) ? (Real)ku[lane + 64] : (Real)0;
+      p.ku[0] = ku[lane];
+      p.ku[1] = (lane + 64 < 100) ? ku[lane + 64] : (St)0;
     }
   }
   DDP_DEV void commit(const Pre& p, int lane, int P, bool fwd) {
     if (lane < 19) L.z[lane] = p.z;
-    if (lane < 4 * P) L.pl[lane] = p.pl[0];
-    if (lane + 64 < 4 * P) L.pl[lane + 64] = p.pl[1];
+    if (lane < 4 * P) L.pl[lane] = (Real)p.pl[0];
+    if (lane + 64 < 4 * P) L.pl[lane + 64] = (Real)p.pl[1];
     if (fwd) {
-      L.KUr[lane] = p.ku[0];
-      if (lane + 64 < 100) L.KUr[lane + 64] = p.ku[1];
+      L.KUr[lane] = (Real)p.ku[0];
+      if (lane + 64 < 100) L.KUr[lane + 64] = (Real)p.ku[1];
     }
   }
 
@@ -789,8 +790,8 @@ struct Wave {
       LANES {
         commit(LV(pre), lane, P, false);
         for (int i = 0; i < RPL; i++) {
-          LV(rs)[i] = LV(pre).s[i];
-          LV(ry)[i] = LV(pre).y[i];
+          LV(rs)[i] = (Real)LV(pre).s[i];
+          LV(ry)[i] = (Real)LV(pre).y[i];
         }
       }
       if (k > 0) {
@@ -1136,26 +1137,33 @@ struct Wave {
           LV(m)[a] = v;
         }
       }
+      // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
+      // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]), so each
+      // step needs one pivot broadcast (v_readlane) and ONE ds_write of the scaled row by all lanes,
+      // which at the same time leaves [L^T | y | Y] in LDS for the back substitution and for phase R2.
       int ok = 1;
 #pragma unroll
       for (int kk = 0; kk < 10; kk++) {
-        LANES {
-          if (lane == kk) {
-#pragma unroll
-            for (int i = kk; i < 10; i++) L.cbuf[i] = LV(m)[i];
-          }
-        }
-        WSYNC();
-        const Acc piv = L.cbuf[kk];
+        const Acc piv = RDLANE(m, kk, kk);
         if (piv <= (Acc)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
         const Acc rinv = frsq(piv);
         L.rdiag[kk] = rinv;  // wave-uniform store
         LANES {
-          Acc t = LV(m)[kk] * rinv;
+          const Acc t = LV(m)[kk] * rinv;
           LV(m)[kk] = t;
-          t *= rinv;
+          L.UY[kk * 20 + lane] = t;  // lanes >= 20 land in the padding / the next rows' not-yet-written slots
+        }
+        WSYNC();
+        if (kk < 9) {
+          Acc lrow[10];
 #pragma unroll
-          for (int i = kk + 1; i < 10; i++) LV(m)[i] -= L.cbuf[i] * t;
+          for (int i = kk + 1; i < 10; i++) lrow[i] = L.UY[kk * 20 + i];
+          DDP_LOADS_ISSUED();
+          LANES {
+            const Acc t = LV(m)[kk];
+#pragma unroll
+            for (int i = kk + 1; i < 10; i++) LV(m)[i] -= lrow[i] * t;
+          }
         }
       }
       ok = DDP_UNIFORM_I(ok);
@@ -1164,22 +1172,22 @@ struct Wave {
         st.opterr = INFINITY;
         return 0;
       }
-      LANES {
-        if (lane < 20) {
-          Acc* dstc = lane < 10 ? &L.Ub[lane] : &L.Yb[lane - 10];
+      // back substitution L^T X = [y | Y] in the right-hand-side lanes
 #pragma unroll
-          for (int i = 0; i < 10; i++) dstc[i * 10] = LV(m)[i];  // U[i][j] = L[j][i];  [y | Y] = L^-1 [Hu | Hux]
-        }
-      }
-      WSYNC();
-      LANES {
+      for (int i = 9; i >= 0; i--) {
+        Acc urow[10];
 #pragma unroll
-        for (int i = 9; i >= 0; i--) {
+        for (int j = i + 1; j < 10; j++) urow[j] = L.UY[i * 20 + j];
+        const Acc dinv = L.rdiag[i];
+        DDP_LOADS_ISSUED();
+        LANES {
           Acc acc = LV(m)[i];
 #pragma unroll
-          for (int j = i + 1; j < 10; j++) acc -= L.Ub[i * 10 + j] * LV(m)[j];
-          LV(m)[i] = acc * L.rdiag[i];
+          for (int j = i + 1; j < 10; j++) acc -= urow[j] * LV(m)[j];
+          LV(m)[i] = acc * dinv;
         }
+      }
+      LANES {
         if (lane >= 10 && lane < 20) {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
           const int col = lane - 10;
 #pragma unroll
@@ -1251,8 +1259,8 @@ struct Wave {
           Acc ya[10], yb[10], ka[10], kb[10];
 #pragma unroll
           for (int k2 = 0; k2 < 10; k2++) {
-            ya[k2] = L.Yb[k2 * 10 + cA];
-            yb[k2] = L.Yb[k2 * 10 + cB];
+            ya[k2] = L.UY[k2 * 20 + 10 + cA];
+            yb[k2] = L.UY[k2 * 20 + 10 + cB];
             ka[k2] = (cA == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cA - 1)];
             kb[k2] = (cB == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cB - 1)];
           }
@@ -1329,10 +1337,10 @@ struct Wave {
         LANES {
           commit(LV(pre), lane, P, true);
           for (int i = 0; i < RPL; i++) {
-            LV(rs)[i] = LV(pre).s[i];
-            LV(rks)[i] = LV(pre).ks[i];
-            LV(ry)[i] = LV(pre).y[i];
-            LV(rky)[i] = LV(pre).ky[i];
+            LV(rs)[i] = (Real)LV(pre).s[i];
+            LV(rks)[i] = (Real)LV(pre).ks[i];
+            LV(ry)[i] = (Real)LV(pre).y[i];
+            LV(rky)[i] = (Real)LV(pre).ky[i];
           }
         }
         if (k + 1 < N) {
