@@ -339,6 +339,15 @@ DDP_DEV Real powi(Real T, int e) {  // T^e for 0 <= e <= 7 without a register-ar
   return r;
 }
 
+// T^e for 0 <= e <= 7 by binary powering from T, T^2, T^4 (3 selects + 2 multiplies)
+template <typename Real>
+DDP_DEV Real pow3(Real T, Real T2, Real T4, int e) {
+  Real r = (e & 1) ? T : (Real)1;
+  r *= (e & 2) ? T2 : (Real)1;
+  r *= (e & 4) ? T4 : (Real)1;
+  return r;
+}
+
 DDP_DEV int ctrl_off(int cr) { return cr < 6 ? 0 : (cr < 11 ? 1 : 2); }
 
 // One constraint row as seen by (slot, lane).  Rows are dealt to lanes BY KIND so that a slot runs one
@@ -802,25 +811,26 @@ struct Wave {
       const Real T = L.z[18];
       DDP_MARK("B_T1");
       // ---- T1: powers of T, scaled value table, dynamics tables
+      const Real T2 = T * T, T4 = T2 * T2;
       LANES {
-#pragma unroll 1
-        for (int e = lane; e < 90; e += 64) {
-          int cr = e / 6, i = e % 6;
-          L.We[e] = L.WbE[e] * powi(T, i - ctrl_off(cr));
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+          const int e = (lane + 64 * pass < 90) ? lane + 64 * pass : 89;
+          const int cr = e / 6, i = e % 6, ex = i - ctrl_off(cr);
+          L.We[e] = L.WbE[e] * pow3(T, T2, T4, ex < 0 ? 0 : ex);  // WbE is 0 where ex < 0
         }
-        if (lane < 18) {
-          L.H[lane] = L.Hc[lane] * powi(T, L.He[lane]);
-          L.Hp[lane] = L.Hpc[lane] * powi(T, L.Hpe[lane]);
-        } else if (lane < 26) {
-          L.tp[lane - 18] = powi(T, lane - 18);
-        }
+        const int l18 = lane < 18 ? lane : 17;
+        L.H[l18] = L.Hc[l18] * pow3(T, T2, T4, L.He[l18]);
+        L.Hp[l18] = L.Hpc[l18] * pow3(T, T2, T4, L.Hpe[l18]);
+        L.tp[lane & 7] = pow3(T, T2, T4, lane & 7);
       }
       WSYNC();
       DDP_MARK("B_T2");
-      // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u
+      // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u (all lanes run all roles, clamped)
       LANES {
-        if (lane < 45) {
-          int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
+        {
+          const int l45 = lane < 45 ? lane : 44;
+          const int cr = l45 / 3, d = l45 % 3, o = ctrl_off(cr);
           Real v = 0, dv = 0, z6[6], we6[6], wd6[6], tp6[6];
 #pragma unroll
           for (int i = 0; i < 6; i++) {
@@ -836,30 +846,31 @@ struct Wave {
             v += we6[i] * z6[i];
             dv += wd6[i] * tp6[i] * z6[i];
           }
-          L.val[lane] = v;
-          L.dval[lane] = dv;
-        } else if (lane == 45) {
+          L.val[l45] = v;
+          L.dval[l45] = dv;
           L.val[45] = T;
         }
-        if (lane < 27) {  // Ru, R'u, R''u (DDP:1349-1355)
-          int t = lane / 9, a9 = lane % 9, a = a9 / 3, d = a9 % 3;
+        {  // Ru, R'u, R''u (DDP:1349-1355)
+          const int l27 = lane < 27 ? lane : 26;
+          const int t = l27 / 9, a9 = l27 % 9, a = a9 / 3, d = a9 % 3;
           Acc acc = 0;
 #pragma unroll
           for (int a2 = 0; a2 < 3; a2++) {
-            int e = a + a2 + 1 - t;
+            const int e = a + a2 + 1 - t;
             Real cf = L.Rc[a * 3 + a2];
-            if (t >= 1) cf *= (Real)(a + a2 + 1);
-            if (t == 2) cf *= (Real)(a + a2);
+            cf *= (t >= 1) ? (Real)(a + a2 + 1) : (Real)1;
+            cf *= (t == 2) ? (Real)(a + a2) : (Real)1;
             acc += cf * L.tp[e < 0 ? 0 : e] * L.z[9 + 3 * a2 + d];  // cf is 0 where e < 0
           }
           Acc* dst = (t == 0) ? L.Ru : (t == 1 ? L.Rpu : L.Rppu);
           dst[a9] = acc;
-        } else if (lane < 36) {
-          int a = lane - 27, c = a / 3, d = a % 3;
+        }
+        {  // fT = (F' (x) I) x + (G' (x) I) u  (DDP:1332)
+          const int a = lane < 27 ? 0 : (lane < 36 ? lane - 27 : 8), c = a / 3, d = a % 3;
           Acc acc = 0;
 #pragma unroll
           for (int i = 0; i < 6; i++) acc += L.Hp[c * 6 + i] * L.z[3 * i + d];
-          L.fT[a] = acc;  // DDP:1332
+          L.fT[a] = acc;
         }
       }
       WSYNC();
@@ -893,9 +904,10 @@ struct Wave {
             L.grow[r] = (St)g;
           }
         }
-#pragma unroll 1
-        for (int e = lane; e < 171; e += 64) {  // VZ[a][q]
-          int a = e / 19, q = e % 19;
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) {  // VZ[a][q], 171 entries
+          const int e = (lane + 64 * pass < 171) ? lane + 64 * pass : 170;
+          const int a = e / 19, q = e % 19;
           Acc acc = 0;
           if (q < 18) {
             int i = q / 3, d = q % 3;
@@ -925,75 +937,59 @@ struct Wave {
       }
       WSYNC();
       DDP_MARK("B_S");
-      // ---- S: 3x3 accumulators per control row
+      // ---- S: 3x3 accumulators per control row.  Every lane runs every role on a clamped index: idle
+      // lanes recompute (and re-store) a neighbour's value, which costs no extra instruction in SIMT and
+      // removes the exec-mask bookkeeping of role branches.
       LANES {
-        if (lane < 54) {
-          int j, d0, d1;
-          const St* w;
-          if (lane < 36) {
-            const int e = lane % 6;
-            j = lane / 6;
-            d0 = (e < 3) ? 0 : (e < 5 ? 1 : 2);
-            d1 = (e < 3) ? e : (e < 5 ? e - 2 : 2);
-            w = L.drow;
-          } else {
-            j = (lane - 36) / 3;
-            d0 = (lane - 36) % 3;
-            d1 = 3;
-            w = L.grow;
-          }
+        {
+          const int l54 = lane < 54 ? lane : 53;
+          const bool isS = l54 < 36;
+          const int e = l54 % 6, j = isS ? l54 / 6 : (l54 - 36) / 3;
+          const int d0 = isS ? ((e < 3) ? 0 : (e < 5 ? 1 : 2)) : (l54 - 36) % 3;
+          const int d1 = isS ? ((e < 3) ? e : (e < 5 ? e - 2 : 2)) : 0;
+          const St* w = isS ? L.drow : L.grow;
           Acc acc = 0;
 #pragma unroll 2
           for (int q = 0; q < P; q++) {
             const Real* n = &L.pl[4 * q];
-            Real f = (d1 == 3) ? (Real)1 : n[d1];
+            const Real f = isS ? n[d1] : (Real)1;
             acc += (Real)w[j * P + q] * n[d0] * f;
           }
-          if (lane < 36) L.Sp[lane] = acc;
-          else L.hh[lane - 36] = acc;
+          Acc* dst = isS ? &L.Sp[l54] : &L.hh[l54 - 36];
+          *dst = acc;
         }
-        if (lane < 27) {  // velocity / acceleration rows: +/- pairs
-          int rp, rm;
-          if (lane < 15) {
-            rp = 6 * P + lane;
-            rm = rp + 15;
-          } else {
-            rp = 6 * P + 30 + (lane - 15);
-            rm = rp + 12;
-          }
-          L.dl[lane] = (Acc)L.drow[rp] + (Acc)L.drow[rm];
-          L.hh[18 + lane] = (Acc)L.grow[rp] - (Acc)L.grow[rm];
+        {  // velocity / acceleration rows: +/- pairs
+          const int l27 = lane < 27 ? lane : 26;
+          const int rp = 6 * P + (l27 < 15 ? l27 : 15 + l27);  // 6P + l | 6P + 30 + (l - 15)
+          const int rm = rp + (l27 < 15 ? 15 : 12);
+          L.dl[l27] = (Acc)L.drow[rp] + (Acc)L.drow[rm];
+          L.hh[18 + l27] = (Acc)L.grow[rp] - (Acc)L.grow[rm];
         }
-        if (lane == 63) {
-          L.last[0] = (Acc)L.drow[nc - 1];
-          L.last[1] = (Acc)L.grow[nc - 1];
-        }
+        L.last[0] = (Acc)L.drow[nc - 1];
+        L.last[1] = (Acc)L.grow[nc - 1];
       }
       WSYNC();
       DDP_MARK("B_S2");
       // ---- S2: Sd = S_cr * dval[cr]
       LANES {
-        if (lane < 45) {
-          int cr = lane / 3, d = lane % 3;
-          Acc acc;
-          if (cr < 6) {
-            const Acc* S = &L.Sp[cr * 6];  // xx,xy,xz,yy,yz,zz
-            const Real* dv = &L.dval[cr * 3];
-            if (d == 0) acc = S[0] * dv[0] + S[1] * dv[1] + S[2] * dv[2];
-            else if (d == 1) acc = S[1] * dv[0] + S[3] * dv[1] + S[4] * dv[2];
-            else acc = S[2] * dv[0] + S[4] * dv[1] + S[5] * dv[2];
-          } else {
-            acc = L.dl[lane - 18] * L.dval[lane];
-          }
-          L.Sd[lane] = acc;
-        }
+        const int l45 = lane < 45 ? lane : 44;
+        const int cr = l45 / 3, d = l45 % 3;
+        const int crp = cr < 6 ? cr : 5;
+        const Acc* S = &L.Sp[crp * 6];  // xx,xy,xz,yy,yz,zz
+        const Real* dv = &L.dval[crp * 3];
+        // row d of the symmetric 3x3: (0,1,2) | (1,3,4) | (2,4,5)
+        const int i0 = d, i1 = d == 0 ? 1 : (d == 1 ? 3 : 4), i2 = d == 2 ? 5 : (d == 1 ? 4 : 2);
+        const Acc pos = S[i0] * dv[0] + S[i1] * dv[1] + S[i2] * dv[2];
+        const Acc oth = L.dl[l45 < 18 ? 0 : l45 - 18] * L.dval[l45];
+        L.Sd[l45] = cr < 6 ? pos : oth;
       }
       WSYNC();
       DDP_MARK("B_H");
       // ---- H: assemble the 19x19 system  Hzz = Z'VZ + quu -/+ A'DA,  Hz = qz + Z'Vx + A'g
       LANES {
-#pragma unroll 1
-        for (int e = lane; e < 171; e += 64) {  // the 18x18 block, p <= q
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) {  // the 18x18 block, p <= q: 171 entries, idle lanes redo the last
+          const int e = (lane + 64 * pass < 171) ? lane + 64 * pass : 170;
           const int w = L.pq[e];
           const int p = w & 31, q = (w >> 5) & 31, i = (w >> 10) & 7, d = (w >> 13) & 3;
           const int i2 = (w >> 15) & 7, sidx = (w >> 20) & 7, dd = (w >> 23) & 1;
@@ -1020,15 +1016,14 @@ struct Wave {
           for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
           const Acc quu = hasq ? wsn * rc1 * tp1 : (Acc)0;
           const Acc v = zvz + quu + sig * ada;
-          if (q < 9) {
-            L.Hxx[p * 9 + q] = v;
-            L.Hxx[q * 9 + p] = v;
-          } else if (p < 9) {
-            L.Hxu[p * 10 + (q - 9)] = v;
-          } else {
-            L.Huu[(p - 9) * 10 + (q - 9)] = v;
-            L.Huu[(q - 9) * 10 + (p - 9)] = v;
-          }
+          // Hxx | Hxu | Huu are consecutive members: element offsets from Hxx[0] (81, 171), integer selects
+          Acc* Hb = L.Hxx;
+          const int oxx = p * 9 + q, oxu = 81 + p * 10 + (q - 9), ouu = 171 + (p - 9) * 10 + (q - 9);
+          const int txx = q * 9 + p, tuu = 171 + (q - 9) * 10 + (p - 9);
+          const int o1 = q < 9 ? oxx : (p < 9 ? oxu : ouu);
+          const int o2 = q < 9 ? txx : (p < 9 ? oxu : tuu);
+          Hb[o1] = v;
+          Hb[o2] = v;
         }
       }
       WSYNC();
@@ -1054,17 +1049,14 @@ struct Wave {
 #pragma unroll
           for (int cr = 0; cr < 9; cr++) ada += w1[cr] * w2[cr] * dl9[cr];
           ada *= sig;
-          if (q < 9) {
-            const Acc v = L.Hxx[p * 9 + q] + ada;
-            L.Hxx[p * 9 + q] = v;
-            L.Hxx[q * 9 + p] = v;
-          } else if (p < 9) {
-            L.Hxu[p * 10 + (q - 9)] += ada;
-          } else {
-            const Acc v = L.Huu[(p - 9) * 10 + (q - 9)] + ada;
-            L.Huu[(p - 9) * 10 + (q - 9)] = v;
-            L.Huu[(q - 9) * 10 + (p - 9)] = v;
-          }
+          Acc* Hb = L.Hxx;
+          const int oxx = p * 9 + q, oxu = 81 + p * 10 + (q - 9), ouu = 171 + (p - 9) * 10 + (q - 9);
+          const int txx = q * 9 + p, tuu = 171 + (q - 9) * 10 + (p - 9);
+          const int o1 = q < 9 ? oxx : (p < 9 ? oxu : ouu);
+          const int o2 = q < 9 ? txx : (p < 9 ? oxu : tuu);
+          const Acc v = Hb[o1] + ada;
+          Hb[o1] = v;
+          Hb[o2] = v;
         }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
           const int p = lane < 18 ? lane : lane - 18;
@@ -1128,14 +1120,12 @@ struct Wave {
       // per double, and L^T is parked in LDS once for the whole back substitution.
       PLA(Acc, m, 10);
       LANES {
+        // column `lane` of [Huu + lam I | Hu | Hux]; lanes >= 20 redo column 19 (their results are never read)
+        const int l19 = lane < 20 ? lane : 19;
+        const Acc* src = l19 < 10 ? &L.Huu[l19] : (l19 == 10 ? &L.Hz[9] : &L.Hxu[(l19 - 11) * 10]);
+        const int stride = l19 < 10 ? 10 : 1;
 #pragma unroll
-        for (int a = 0; a < 10; a++) {
-          Acc v = 0;
-          if (lane < 10) v = L.Huu[a * 10 + lane] + ((a == lane) ? lam : (Acc)0);
-          else if (lane == 10) v = L.Hz[9 + a];
-          else if (lane < 20) v = L.Hxu[(lane - 11) * 10 + a];
-          LV(m)[a] = v;
-        }
+        for (int a = 0; a < 10; a++) LV(m)[a] = src[a * stride] + ((a == lane) ? lam : (Acc)0);
       }
       // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
       // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]), so each
@@ -1145,7 +1135,7 @@ struct Wave {
 #pragma unroll
       for (int kk = 0; kk < 10; kk++) {
         const Acc piv = RDLANE(m, kk, kk);
-        if (piv <= (Acc)0) ok = 0;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
+        ok = (piv <= (Acc)0) ? 0 : ok;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
         const Acc rinv = frsq(piv);
         L.rdiag[kk] = rinv;  // wave-uniform store
         LANES {
@@ -1238,8 +1228,11 @@ struct Wave {
             }
           }
         }
-#pragma unroll 1
-        for (int e = lane; e < 100; e += 64) KUp(k)[e] = (St)L.KU[e];
+        KUp(k)[lane] = (St)L.KU[lane];
+        {
+          const int e2 = lane + 64 < 100 ? lane + 64 : 99;
+          KUp(k)[e2] = (St)L.KU[e2];
+        }
         // Value-function recursion (DDP:626-628).  With [y | Y] = L^-1 [Hu | Hux], LL' = Huu + lam I and
         // [ku | Ku] = -(Huu + lam I)^-1 [Hu | Hux] the reference's
         //   Vxx = Hxx + Hxu Ku + (Hxu Ku)' + Ku' Huu Ku,   Vx = Hx + Ku'Hu + Ku'Huu ku + Hxu ku
