@@ -33,8 +33,10 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define WSYNC() ((void)0)
 #define RDLANE(arr, idx, src) (arr[src][idx])
 #define DDP_UNIFORM_I(x) (x)
+#define DDP_UNIFORM_R(x) (x)
 #define DDP_LAUNDER_S(x) ((void)0)
 #define DDP_LOADS_ISSUED() ((void)0)
+#define DDP_PIN(x) ((void)0)
 #define DDP_MARK(name)
 #else
 #include <hip/hip_runtime.h>
@@ -63,6 +65,8 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
   } while (0)
 #define RDLANE(arr, idx, src) direct::readlane_real(arr[idx], src)
 #define DDP_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
+// a wave-uniform real computed by the VALU (or read from LDS) moved to SGPRs: frees its VGPRs
+#define DDP_UNIFORM_R(x) direct::uniform_real(x)
 // re-materialise a wave-uniform value: stops LICM from hoisting everything derived from it (slab
 // pointers, strides) out of the outer iteration loop, where it would stay live across both sweeps
 #define DDP_LAUNDER_S(x) asm volatile("" : "+s"(x))
@@ -70,6 +74,10 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 // sinks each load next to its use (3 loads, wait, 2 FMAs, 3 loads, wait ...) and every wait exposes
 // a full LDS round trip; with the barrier all loads of the block are in flight before the first wait.
 #define DDP_LOADS_ISSUED() asm volatile("" ::: "memory")
+// Pins a value's computation at this point of the program.  Without it the compiler sinks a whole
+// unrolled recurrence below the operand loads of ALL its steps (into the block that finally stores
+// the result), and the operands of every step are live at once.
+#define DDP_PIN(x) asm volatile("" : "+v"(x))
 #if defined(DDP_MARKS)  // phase markers in the .s for static instruction accounting (tools/phase_count.py)
 #define DDP_MARK(name) asm volatile("; DDP_MARK " name ::: "memory")
 #elif defined(DDP_TIMING)  // per-phase cycle accounting with s_memtime (tools/phase_timing.py); debug builds only
@@ -119,6 +127,14 @@ __device__ __forceinline__ float readlane_real(float v, int src) {
 __device__ __forceinline__ double readlane_real(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float uniform_real(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ double uniform_real(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -397,38 +413,44 @@ struct Wave {
 
   // Software prefetch of the next knot's HBM data into registers: the serial knot recursion would
   // otherwise expose one full memory latency per knot (nothing else is in flight in this wave).
+  // Nothing here may WAIT on a load it has just issued (no arithmetic on the loaded words, no
+  // load-dependent branch): every access is an unconditional load from a clamped, always valid index
+  // and the words stay raw until commit().
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
-    Real z;
-    St pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
+    St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
   DDP_DEV void prefetch(Pre& p, int lane, int buf, int k, int P, bool fwd, int infeas) const {
-    const int nc = 6 * P + 55;
-    p.z = (lane < 19) ? ldx(Xp(buf, k), lane) : (Real)0;
+    const St* rec = Xp(buf, k);
+    p.zh = rec[lane < 19 ? lane : 18];
+    p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 3 ? lane : 2)] : (St)0;  // see ldx()
     const St* pk = planes_(k);
-    p.pl[0] = (lane < 4 * P) ? pk[lane] : (St)0;
-    p.pl[1] = (lane + 64 < 4 * P) ? pk[lane + 64] : (St)0;
+    const int pend = 4 * P - 1;
+    p.pl[0] = pk[lane < pend ? lane : pend];
+    p.pl[1] = pk[lane + 64 < pend ? lane + 64 : pend];
     const St* sk = Sp_(B.S[buf], k);
     const St* yk = Sp_(B.Y[buf], k);
     const St* ksk = Sp_(B.KS, k);
     const St* kyk = Sp_(B.KY, k);
     for (int i = 0; i < RPL; i++) {
       const int r = row_slot(i, lane, P).r;
-      const bool in = r >= 0;
-      p.s[i] = in ? sk[r] : (St)0;
-      p.y[i] = (in && infeas) ? yk[r] : (St)1;
+      const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0 and are masked in commit_rows()
+      p.s[i] = sk[rc];
+      if (infeas) p.y[i] = yk[rc];
       if (fwd) {
-        p.ks[i] = in ? ksk[r] : (St)0;
-        p.ky[i] = (in && infeas) ? kyk[r] : (St)0;
+        p.ks[i] = ksk[rc];
+        if (infeas) p.ky[i] = kyk[rc];
       }
     }
     if (fwd) {
       const St* ku = KUp(k);
       p.ku[0] = ku[lane];
-      p.ku[1] = (lane + 64 < 100) ? ku[lane + 64] : (St)0;
+      p.ku[1] = ku[lane + 64 < 100 ? lane + 64 : 99];
     }
   }
   DDP_DEV void commit(const Pre& p, int lane, int P, bool fwd) {
-    if (lane < 19) L.z[lane] = p.z;
+    Real z = (Real)p.zh;
+    if (sizeof(St) < sizeof(double) && lane < 3) z += (Real)p.zl;
+    if (lane < 19) L.z[lane] = z;
     if (lane < 4 * P) L.pl[lane] = (Real)p.pl[0];
     if (lane + 64 < 4 * P) L.pl[lane + 64] = (Real)p.pl[1];
     if (fwd) {
@@ -764,10 +786,10 @@ struct Wave {
     const int regi = DDP_UNIFORM_I(st.reg);
     double lam_d = 1.0;
     for (int q = 0; q < regi; q++) lam_d *= B.k.reg_base;
-    const Acc lam = (Acc)(lam_d - 1.0);  // DDP:529
+    const Acc lam = DDP_UNIFORM_R((Acc)(lam_d - 1.0));  // DDP:529
     const int buf = DDP_UNIFORM_I(st.cur);
     const int infeas = DDP_UNIFORM_I(st.infeas);
-    const Real mu = (Real)st.mu;
+    const Real mu = DDP_UNIFORM_R((Real)st.mu);
     const Real wsn = (Real)B.k.w_snap;
     const Acc sig = infeas ? (Acc)1 : (Acc)-1;
 
@@ -783,11 +805,18 @@ struct Wave {
     LANES { LV(e_mu) = 0; LV(e_c) = 0; }
     Acc qu_err = 0;
 
-    int Pn = np_(N - 1);
+    // plane counts run two knots ahead of the sweep (the prefetch of knot k-1 needs P(k-1) for its
+    // addresses: loading it on the spot would expose one HBM round trip per knot)
+    int Pn = DDP_UNIFORM_I(np_(N - 1));
+    int Pnn = np_(N > 1 ? N - 2 : 0);
     PLV(Pre, pre);
     LANES { prefetch(LV(pre), lane, buf, N - 1, Pn, false, infeas); }
 #pragma unroll 1
-    for (int k = N - 1; k >= 0; k--) {
+    for (int k_ = N - 1; k_ >= 0; k_--) {
+      // the knot index is re-materialised every trip: as a visible induction variable it makes loop
+      // strength reduction keep one 64-bit pointer PER ARRAY live (and spilled) across the whole body
+      int k = k_;
+      DDP_LAUNDER_S(k);
       const int P = Pn;
       const int nc = 6 * P + 55;
       PLA(Real, rs, RPL);
@@ -800,18 +829,19 @@ struct Wave {
         commit(LV(pre), lane, P, false);
         for (int i = 0; i < RPL; i++) {
           LV(rs)[i] = (Real)LV(pre).s[i];
-          LV(ry)[i] = (Real)LV(pre).y[i];
+          LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
         }
       }
       if (k > 0) {
-        Pn = np_(k - 1);
+        Pn = DDP_UNIFORM_I(Pnn);
+        Pnn = np_(k > 1 ? k - 2 : 0);
         LANES { prefetch(LV(pre), lane, buf, k - 1, Pn, false, infeas); }
       }
       WSYNC();
-      const Real T = L.z[18];
+      const Real T = DDP_UNIFORM_R(L.z[18]);
       DDP_MARK("B_T1");
       // ---- T1: powers of T, scaled value table, dynamics tables
-      const Real T2 = T * T, T4 = T2 * T2;
+      const Real T2 = DDP_UNIFORM_R(T * T), T4 = DDP_UNIFORM_R(T2 * T2);
       LANES {
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
@@ -1125,7 +1155,10 @@ struct Wave {
         const Acc* src = l19 < 10 ? &L.Huu[l19] : (l19 == 10 ? &L.Hz[9] : &L.Hxu[(l19 - 11) * 10]);
         const int stride = l19 < 10 ? 10 : 1;
 #pragma unroll
-        for (int a = 0; a < 10; a++) LV(m)[a] = src[a * stride] + ((a == lane) ? lam : (Acc)0);
+        for (int a = 0; a < 10; a++) LV(m)[a] = src[a * stride];
+        DDP_LOADS_ISSUED();
+#pragma unroll
+        for (int a = 0; a < 10; a++) LV(m)[a] += ((a == lane) ? lam : (Acc)0);
       }
       // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
       // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]), so each
@@ -1175,6 +1208,7 @@ struct Wave {
 #pragma unroll
           for (int j = i + 1; j < 10; j++) acc -= urow[j] * LV(m)[j];
           LV(m)[i] = acc * dinv;
+          DDP_PIN(LV(m)[i]);
         }
       }
       LANES {
@@ -1249,21 +1283,25 @@ struct Wave {
           const int aa = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
           // lanes 0..44: (colA, colB) = Y columns 1+a, 1+c2;  lanes 45..53: Y column 1+aa against y (column 0)
           const int cA = lane < 45 ? 1 + a : 1 + aa, cB = lane < 45 ? 1 + c2 : 0;
-          Acc ya[10], yb[10], ka[10], kb[10];
-#pragma unroll
-          for (int k2 = 0; k2 < 10; k2++) {
-            ya[k2] = L.UY[k2 * 20 + 10 + cA];
-            yb[k2] = L.UY[k2 * 20 + 10 + cB];
-            ka[k2] = (cA == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cA - 1)];
-            kb[k2] = (cB == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cB - 1)];
-          }
           const Acc h0 = lane < 45 ? L.Hxx[a * 9 + c2] : L.Hz[aa];
-          DDP_LOADS_ISSUED();
           Acc yy = 0, kk2 = 0;
 #pragma unroll
-          for (int k2 = 0; k2 < 10; k2++) {
-            yy += ya[k2] * yb[k2];
-            kk2 += ka[k2] * kb[k2];
+          for (int half = 0; half < 2; half++) {  // two batches of 20 operands: 40 live doubles would spill
+            Acc ya[5], yb[5], ka[5], kb[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+              const int k2 = 5 * half + j;
+              ya[j] = L.UY[k2 * 20 + 10 + cA];
+              yb[j] = L.UY[k2 * 20 + 10 + cB];
+              ka[j] = (cA == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cA - 1)];
+              kb[j] = (cB == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cB - 1)];
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+              yy += ya[j] * yb[j];
+              kk2 += ka[j] * kb[j];
+            }
           }
           const Acc vnew = h0 - yy - lam * kk2;
           if (lane < 45) {
@@ -1292,7 +1330,7 @@ struct Wave {
     const int infeas = DDP_UNIFORM_I(st.infeas);
     const double mu_d = st.mu;
     const double tau_d = fmax(0.99, 1.0 - mu_d);
-    const Real omt = (Real)(1.0 - tau_d);
+    const Real omt = DDP_UNIFORM_R((Real)(1.0 - tau_d));
     const int nfilter = DDP_UNIFORM_I(st.nfilter);
     double* filt = B.filt + (size_t)b * B.fcap * 2;
     int accepted = 0, step = 0;
@@ -1302,7 +1340,7 @@ struct Wave {
     for (step = 0; step < 11; step++) {
       stepsize = 1.0;
       for (int q = 0; q < step; q++) stepsize *= 0.5;  // DDP:670
-      const Real alpha = (Real)stepsize;
+      const Real alpha = DDP_UNIFORM_R((Real)stepsize);
       PLV(LogProd<Real>, plog);
       PLV(Real, slog);
       PLV(Real, serr);
@@ -1315,11 +1353,14 @@ struct Wave {
       double qsum = 0.0;
       int failed = 0;
       neg = 0;
-      int Pn = np_(0);
+      int Pn = DDP_UNIFORM_I(np_(0));
+      int Pnn = np_(N > 1 ? 1 : 0);
       PLV(Pre, pre);
       LANES { prefetch(LV(pre), lane, cur, 0, Pn, true, infeas); }
 #pragma unroll 1
-      for (int k = 0; k < N; k++) {
+      for (int k_ = 0; k_ < N; k_++) {
+        int k = k_;  // see bwd_sweep()
+        DDP_LAUNDER_S(k);
         const int P = Pn;
         const int nc = 6 * P + 55;
         DDP_MARK("F_L");
@@ -1332,12 +1373,13 @@ struct Wave {
           for (int i = 0; i < RPL; i++) {
             LV(rs)[i] = (Real)LV(pre).s[i];
             LV(rks)[i] = (Real)LV(pre).ks[i];
-            LV(ry)[i] = (Real)LV(pre).y[i];
-            LV(rky)[i] = (Real)LV(pre).ky[i];
+            LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
+            LV(rky)[i] = infeas ? (Real)LV(pre).ky[i] : (Real)0;
           }
         }
         if (k + 1 < N) {
-          Pn = np_(k + 1);
+          Pn = DDP_UNIFORM_I(Pnn);
+          Pnn = np_(k + 2 < N ? k + 2 : k + 1);
           LANES { prefetch(LV(pre), lane, cur, k + 1, Pn, true, infeas); }
         }
         WSYNC();
@@ -1367,7 +1409,7 @@ struct Wave {
           }
         }
         WSYNC();
-        const Real To = L.z[18], Tn = L.zn[18];
+        const Real To = DDP_UNIFORM_R(L.z[18]), Tn = DDP_UNIFORM_R(L.zn[18]);
         if (Tn < 0) neg = 1;
       DDP_MARK("F_T");
         // ---- T: control values at the old and the new iterate, A*[dx; Ku dx], x+, jerk cost
@@ -1375,28 +1417,32 @@ struct Wave {
           if (lane < 45) {
             int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
             Real vo = 0, dvo = 0, vn = 0, gf = 0;
-            Real wb6[6], wd6[6], t0[6], t1[6], tn6[6], zo6[6], dz6[6], zn6[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-              const int e = i - o;
-              const int e0 = e < 0 ? 0 : e, e1 = e < 1 ? 0 : e - 1;
-              wb6[i] = L.WbE[cr * 6 + i];
-              wd6[i] = L.WdE[cr * 6 + i];
-              t0[i] = L.tp[e0];
-              t1[i] = L.tp[e1];
-              tn6[i] = L.tpn[e0];
-              zo6[i] = L.z[3 * i + d];
-              dz6[i] = L.dz[3 * i + d];
-              zn6[i] = L.zn[3 * i + d];
-            }
-            DDP_LOADS_ISSUED();
+            for (int half = 0; half < 2; half++) {  // two batches of 24 operands (48 live doubles would spill)
+              Real wb6[3], wd6[3], t0[3], t1[3], tn6[3], zo6[3], dz6[3], zn6[3];
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-              const Real w = wb6[i] * t0[i];
-              vo += w * zo6[i];
-              gf += w * dz6[i];
-              dvo += wd6[i] * t1[i] * zo6[i];
-              vn += wb6[i] * tn6[i] * zn6[i];
+              for (int j = 0; j < 3; j++) {
+                const int i = 3 * half + j;
+                const int e = i - o;
+                const int e0 = e < 0 ? 0 : e, e1 = e < 1 ? 0 : e - 1;
+                wb6[j] = L.WbE[cr * 6 + i];
+                wd6[j] = L.WdE[cr * 6 + i];
+                t0[j] = L.tp[e0];
+                t1[j] = L.tp[e1];
+                tn6[j] = L.tpn[e0];
+                zo6[j] = L.z[3 * i + d];
+                dz6[j] = L.dz[3 * i + d];
+                zn6[j] = L.zn[3 * i + d];
+              }
+              DDP_LOADS_ISSUED();
+#pragma unroll
+              for (int j = 0; j < 3; j++) {
+                const Real w = wb6[j] * t0[j];
+                vo += w * zo6[j];
+                gf += w * dz6[j];
+                dvo += wd6[j] * t1[j] * zo6[j];
+                vn += wb6[j] * tn6[j] * zn6[j];
+              }
             }
             L.val[lane] = vo;
             L.valn[lane] = vn;
