@@ -268,18 +268,29 @@ struct WaveLds {
       // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
       // (Acc) whatever Real is: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in
       // fp32 over ~100 knots (DESIGN.md "Precision").
-      Acc Sp[36], dl[27], Sd[48], hh[48], last[4];
       Acc fT[12], Ru[9], Rpu[9], Rppu[9];
       Acc V[81], Vx[12];
-      Acc Hxx[81], Hxu[90], Huu[100], Hz[20];  // Hxu[a][c] (9x10), Huu 10x10, both triangles stored
-      Acc KU[100];
+      // Hxu[a][c] (9x10), Huu 10x10, both triangles stored.  Hxx | Hxu | Huu must stay consecutive
+      // (phase H stores through one base pointer).  Phase C reads Huu into registers and never again, so
+      // the gains it produces share that storage.
+      Acc Hxx[81], Hxu[90];
       union {
-        Acc VZ[176];  // Vxx * Z: dead after phase H
+        Acc Huu[100];
+        Acc KU[100];
       };
-      // rows of [L^T | y | Y]: UY[k][j] = L[j][k] (j < 10), UY[k][10 + c] = (L^-1 [Hu | Hux])[k][c]; written
-      // one row per elimination step by all column lanes at once (phases C, R2).  Stride 20, 64 slots per
-      // row so that the idle lanes' stores need no masking.
-      Acc UY[10 * 20 + 44], rdiag[10];
+      Acc Hz[20];
+      union {
+        struct {  // operands of the assembly: dead once phase H is done
+          Acc Sp[36], dl[27], Sd[48], hh[48], last[4];
+          Acc VZ[176];  // Vxx * Z
+        };
+        struct {
+          // rows of [L^T | y | Y]: UY[k][j] = L[j][k] (j < 10), UY[k][10 + c] = (L^-1 [Hu | Hux])[k][c];
+          // written one row per elimination step by all column lanes at once (phases C, R2).  Stride 20,
+          // 64 slots per row so that the idle lanes' stores need no masking.
+          Acc UY[10 * 20 + 44], rdiag[10];
+        };
+      };
     };
     struct {  // ---- forward pass / evaluation sweep only
       Real tpn[8], zn[kXS], dz[kXS], xn[12], xnx[12], valn[48], qp[12];
