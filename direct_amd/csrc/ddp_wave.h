@@ -37,6 +37,7 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define DDP_LAUNDER_S(x) ((void)0)
 #define DDP_LOADS_ISSUED() ((void)0)
 #define DDP_PIN(x) ((void)0)
+#define DDP_OPAQUE_S(x) ((void)0)
 #define DDP_MARK(name)
 #else
 #include <hip/hip_runtime.h>
@@ -78,6 +79,10 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 // unrolled recurrence below the operand loads of ALL its steps (into the block that finally stores
 // the result), and the operands of every step are live at once.
 #define DDP_PIN(x) asm volatile("" : "+v"(x))
+// A wave-uniform value the compiler must treat as an opaque SGPR operand.  Without it a lane-dependent
+// select between two kernel-argument fields is turned into ONE lane-indexed vector load from the kernarg
+// segment, i.e. a full memory round trip (and a vmcnt(0) that also drains the prefetch) in the row loop.
+#define DDP_OPAQUE_S(x) asm("" : "+s"(x))
 #if defined(DDP_MARKS)  // phase markers in the .s for static instruction accounting (tools/phase_count.py)
 #define DDP_MARK(name) asm volatile("; DDP_MARK " name ::: "memory")
 #elif defined(DDP_TIMING)  // per-phase cycle accounting with s_memtime (tools/phase_timing.py); debug builds only
@@ -347,13 +352,17 @@ struct LogProd {
   Real m;
   int e;
   DDP_DEV void init() { m = (Real)1; e = 0; }
-  DDP_DEV void mul(Real x) {  // x > 0 (a non-positive or NaN factor poisons m, exactly like log(x) would)
-    int ex;
+  // x > 0 (a negative or NaN factor poisons m, a zero one makes it 0, exactly like log(x) would).  The
+  // product is only renormalised by norm(), which the sweeps call once per knot: at most RPL factors,
+  // each within a few hundred binades of 1, accumulate in between.
+  DDP_DEV void mul(Real x) {
     if (x < (Real)0) x = (Real)NAN;  // log of a negative number is NaN (ddp_optimizer.cpp:731, quirk Q7)
-    Real mx = split_mant(x, ex);
+    m *= x;
+  }
+  DDP_DEV void norm() {
     int e2;
-    m = split_mant(m * mx, e2);
-    e += ex + e2;
+    m = split_mant(m, e2);
+    e += e2;
   }
   DDP_DEV Real value() const { return log(m) + (Real)e * (Real)0.6931471805599453094; }
 };
@@ -381,12 +390,16 @@ DDP_DEV int ctrl_off(int cr) { return cr < 6 ? 0 : (cr < 11 ? 1 : 2); }
 // kind of code: slots 0..RPL-2 hold position rows r = lane + 64*slot (r < 6P); the last slot holds the
 // 55 velocity / acceleration / T_min rows in lanes 0..54 (r = 6P + lane) and, in lanes 55..63, the few
 // position rows beyond 64*(RPL-1).  HBM arrays stay indexed by r (DDP:1181-1188, 1236-1238, 1274-1279).
-//   position row:  c = n . A[a0..a0+2] + n[3] - shift         (pi = offset of the plane in L.pl)
-//   other rows:    c = sgn * A[a0] + off - shift              (pi = -1; A[45] carries T for the T_min row)
+// Every row is evaluated by ONE branch-free formula,  c = n . A[a0..a0+2] + o - shift :
+//   position row:  n = plane normal, o = plane offset, a0 = 3 * (control point)
+//   other rows:    n = (0, 0, +/-1), a0 = (index of the bounded value) - 2, o = -max_vel | -max_acc | 0.3
+//                  (A[45] carries T for the T_min row; the two zero products are exact)
+// Rows that do not exist (r < 0) alias position row 0: their arithmetic is harmless and callers mask the
+// stores and the reductions.
 template <typename Real>
 struct RowK {
-  int r, a0, pi;
-  Real sgn, off;
+  int r, a0;
+  Real n0, n1, n2, o;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -443,7 +456,7 @@ struct Wave {
     const St* ksk = Sp_(B.KS, k);
     const St* kyk = Sp_(B.KY, k);
     for (int i = 0; i < RPL; i++) {
-      const int r = row_slot(i, lane, P).r;
+      const int r = row_r(i, lane, P);
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0 and are masked in commit_rows()
       p.s[i] = sk[rc];
       if (infeas) p.y[i] = yk[rc];
@@ -548,49 +561,56 @@ struct Wave {
   }
 
   // ---- shared pieces ---------------------------------------------------------------------------
+  // HBM row index of (slot, lane), -1 if the slot is empty
+  DDP_DEV int row_r(int slot, int lane, int P) const {
+    if (slot == RPL - 1) {
+      const int rp = 64 * (RPL - 1) + lane - 55;
+      return lane < 55 ? 6 * P + lane : (rp < 6 * P ? rp : -1);
+    }
+    const int rp = lane + 64 * slot;
+    return rp < 6 * P ? rp : -1;
+  }
   DDP_DEV RowK<Real> row_slot(int slot, int lane, int P) const {
     RowK<Real> k;
-    k.sgn = (Real)1;
-    k.off = (Real)0;
-    const bool other = (slot == RPL - 1) && lane < 55;
-    if (!other) {
-      const int r = (slot == RPL - 1) ? 64 * (RPL - 1) + lane - 55 : lane + 64 * slot;
-      const int j = (r >= P) + (r >= 2 * P) + (r >= 3 * P) + (r >= 4 * P) + (r >= 5 * P);
-      k.r = (r < 6 * P) ? r : -1;
-      k.a0 = 3 * j;
-      k.pi = (r < 6 * P) ? 4 * (r - j * P) : 0;
-    } else {
-      k.r = 6 * P + lane;
-      k.pi = -1;
-      if (lane < 30) {
-        k.a0 = 18 + (lane < 15 ? lane : lane - 15);
-        k.sgn = lane < 15 ? (Real)1 : (Real)-1;
-        k.off = -(Real)B.k.max_vel;
-      } else if (lane < 54) {
-        const int l2 = lane - 30;
-        k.a0 = 33 + (l2 < 12 ? l2 : l2 - 12);
-        k.sgn = l2 < 12 ? (Real)1 : (Real)-1;
-        k.off = -(Real)B.k.max_acc;
-      } else {
-        k.a0 = 45;  // A[45] = T:  c = -T + 0.3 - shift (DDP:1279)
-        k.sgn = (Real)-1;
-        k.off = (Real)0.3;
-      }
+    const bool last = (slot == RPL - 1);  // a constant once the slot loop is unrolled
+    const int rp = last ? 64 * (RPL - 1) + lane - 55 : lane + 64 * slot;
+    const bool pv = rp >= 0 && rp < 6 * P;
+    const int rq = pv ? rp : 0;
+    const int j = (int)(((unsigned)rq * kInvP[P]) >> 16);  // rq / P: the control point
+    const Real* n = &L.pl[4 * (rq - j * P)];
+    k.n0 = n[0];
+    k.n1 = n[1];
+    k.n2 = n[2];
+    k.o = n[3];
+    k.r = pv ? rp : -1;
+    k.a0 = 3 * j;
+    if (last) {  // lanes 0..54: velocity (30), acceleration (24), T_min (1) rows  (DDP:1236-1238, 1274-1279)
+      const bool other = lane < 55;
+      const bool isv = lane < 30, isa = lane < 54;
+      const int l2 = lane - 30;
+      const int a0v = 16 + (lane < 15 ? lane : lane - 15);  // 18 + . - 2
+      const int a0a = 31 + (l2 < 12 ? l2 : l2 - 12);         // 33 + . - 2
+      const bool pos = isv ? lane < 15 : (isa ? l2 < 12 : false);
+      Real mvel = -(Real)B.k.max_vel, macc = -(Real)B.k.max_acc;
+      DDP_OPAQUE_S(mvel);
+      DDP_OPAQUE_S(macc);
+      const Real off = isv ? mvel : (isa ? macc : (Real)0.3);  // DDP:1279: -T + 0.3
+      k.r = other ? 6 * P + lane : k.r;
+      k.a0 = other ? (isv ? a0v : (isa ? a0a : 43)) : k.a0;
+      k.n0 = other ? (Real)0 : k.n0;
+      k.n1 = other ? (Real)0 : k.n1;
+      k.n2 = other ? (pos ? (Real)1 : (Real)-1) : k.n2;
+      k.o = other ? off : k.o;
     }
     return k;
   }
-  // A_r . w: position rows n . A[cp], other rows +/- A[a0]
+  // A_r . w
   DDP_DEV Real row_lin(const Real* A, const RowK<Real>& k) const {
-    if (k.pi >= 0) {
-      const Real* n = &L.pl[k.pi];
-      return n[0] * A[k.a0] + n[1] * A[k.a0 + 1] + n[2] * A[k.a0 + 2];
-    }
-    return k.sgn * A[k.a0];
+    return k.n0 * A[k.a0] + k.n1 * A[k.a0 + 1] + k.n2 * A[k.a0 + 2];
   }
   // c_r (val[45] must hold T), shifted by 2e-4 unless minvo (DDP:1281-1283)
   DDP_DEV Real row_c(const Real* val, const RowK<Real>& k) const {
-    const Real o = (k.pi >= 0) ? L.pl[k.pi + 3] : k.off;
-    return row_lin(val, k) + o - (Real)B.k.shift;
+    return row_lin(val, k) + k.o - (Real)B.k.shift;
   }
 
   // control values val[cr][d] = sum_i W[cr][i] T^(i-o) C_i[d] from a knot record zz with powers tpw
@@ -684,6 +704,7 @@ struct Wave {
             if (c >= (Real)2.0e-4) LV(nviol)++;
           }
         }
+        LV(plog).norm();
         if (do_roll && lane < 9) stx(Xp(buf, k + 1), lane, L.xnx[lane]);
       }
       WSYNC();
@@ -919,28 +940,31 @@ struct Wave {
       // ---- R1: constraint rows -> D, g ; VZ = Vxx * Z
       LANES {
         for (int i = 0; i < RPL; i++) {
+          // every lane runs the row arithmetic (empty slots alias row 0); only the stores and the
+          // running maxima are masked
           const RowK<Real> rk = row_slot(i, lane, P);
           const int r = rk.r;
-          if (r >= 0) {
-            Real c = row_c(L.val, rk), s = LV(rs)[i], y = LV(ry)[i];
-            Real D, g, rv;
-            if (infeas) {  // DDP:535-539, 554
-              Real rm = s * y - mu;
-              rv = s * (c + y) - rm;  // rhat
-              Real yinv = frcp(y);
-              D = s * yinv;
-              g = s + yinv * rv;
-              LV(e_mu) = fmax(LV(e_mu), fabs(rm));
-              LV(e_c) = fmax(LV(e_c), fabs(c + y));
-            } else {  // DDP:583-587, 601
-              rv = s * c + mu;
-              Real cinv = frcp(c);
-              D = s * cinv;
-              g = -mu * cinv;  // s - r/c
-              LV(e_mu) = fmax(LV(e_mu), fabs(rv));
-            }
-            LV(rc)[i] = c;
-            LV(rr)[i] = rv;
+          const bool in = r >= 0;
+          Real c = row_c(L.val, rk), s = LV(rs)[i], y = LV(ry)[i];
+          Real D, g, rv;
+          if (infeas) {  // DDP:535-539, 554
+            Real rm = s * y - mu;
+            rv = s * (c + y) - rm;  // rhat
+            Real yinv = frcp(y);
+            D = s * yinv;
+            g = s + yinv * rv;
+            LV(e_mu) = fmax(LV(e_mu), in ? fabs(rm) : (Real)0);
+            LV(e_c) = fmax(LV(e_c), in ? fabs(c + y) : (Real)0);
+          } else {  // DDP:583-587, 601
+            rv = s * c + mu;
+            Real cinv = frcp(c);
+            D = s * cinv;
+            g = -mu * cinv;  // s - r/c
+            LV(e_mu) = fmax(LV(e_mu), in ? fabs(rv) : (Real)0);
+          }
+          LV(rc)[i] = c;
+          LV(rr)[i] = rv;
+          if (in) {
             L.drow[r] = (St)D;
             L.grow[r] = (St)g;
           }
@@ -1261,16 +1285,19 @@ struct Wave {
         for (int i = 0; i < RPL; i++) {
           const RowK<Real> rk = row_slot(i, lane, P);
           const int r = rk.r;
-          if (r >= 0) {
-            Real cuku = row_lin(L.G, rk);
-            Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
-            if (infeas) {  // DDP:568, 571
-              Real y = LV(ry)[i];
-              ksg[r] = (St)((rv + s * cuku) * frcp(y));
-              kyg[r] = (St)(-(c + y) - cuku);
-            } else {  // DDP:611
-              ksg[r] = (St)(-((rv + s * cuku) * frcp(c)));
+          const Real cuku = row_lin(L.G, rk);
+          const Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
+          if (infeas) {  // DDP:568, 571
+            const Real y = LV(ry)[i];
+            const St ks = (St)((rv + s * cuku) * frcp(y));
+            const St ky = (St)(-(c + y) - cuku);
+            if (r >= 0) {
+              ksg[r] = ks;
+              kyg[r] = ky;
             }
+          } else {  // DDP:611
+            const St ks = (St)(-((rv + s * cuku) * frcp(c)));
+            if (r >= 0) ksg[r] = ks;
           }
         }
         KUp(k)[lane] = (St)L.KU[lane];
@@ -1478,31 +1505,35 @@ struct Wave {
           St* sn = Sp_(B.S[nxt], k);
           St* yn = Sp_(B.Y[nxt], k);
           for (int i = 0; i < RPL; i++) {
+            // branch-free rows: empty slots alias row 0, their stores / reductions are masked
             const RowK<Real> rk = row_slot(i, lane, P);
             const int r = rk.r;
-            if (r >= 0) {
-              Real az = row_lin(L.G, rk);
-              Real cn = row_c(L.valn, rk);
-              Real s = LV(rs)[i];
-              Real snew;
-              if (infeas) {  // DDP:680-687
-                Real y = LV(ry)[i];
-                Real ynew = (Real)(St)(y + alpha * LV(rky)[i] - az);
-                snew = (Real)(St)(s + alpha * LV(rks)[i] + (s * frcp(y)) * az);
-                if (ynew < omt * y || snew < omt * s) LV(bad) = 1;
+            const bool in = r >= 0;
+            const Real az = row_lin(L.G, rk);
+            const Real cn = row_c(L.valn, rk);
+            const Real s = LV(rs)[i];
+            Real snew;
+            if (infeas) {  // DDP:680-687
+              const Real y = LV(ry)[i];
+              const Real ynew = (Real)(St)(y + alpha * LV(rky)[i] - az);
+              snew = (Real)(St)(s + alpha * LV(rks)[i] + (s * frcp(y)) * az);
+              LV(bad) |= (in && (ynew < omt * y || snew < omt * s)) ? 1 : 0;
+              LV(plog).mul(in ? ynew : (Real)1);
+              LV(serr) += in ? fabs(cn + ynew) : (Real)0;
+              if (in) {
                 yn[r] = (St)ynew;
-                LV(plog).mul(ynew);
-                LV(serr) += fabs(cn + ynew);
-              } else {  // DDP:694-703
-                Real co = row_c(L.val, rk);
-                snew = (Real)(St)(s + alpha * LV(rks)[i] - (s * frcp(co)) * az);
-                if (cn > omt * co || snew < omt * s) LV(bad) = 1;
-                LV(plog).mul(-cn);
+                sn[r] = (St)snew;
               }
-              sn[r] = (St)snew;
-              if (cn >= (Real)2.0e-4) LV(nviol)++;
+            } else {  // DDP:694-703
+              const Real co = row_c(L.val, rk);
+              snew = (Real)(St)(s + alpha * LV(rks)[i] - (s * frcp(co)) * az);
+              LV(bad) |= (in && (cn > omt * co || snew < omt * s)) ? 1 : 0;
+              LV(plog).mul(in ? -cn : (Real)1);
+              if (in) sn[r] = (St)snew;
             }
+            LV(nviol) += (in && cn >= (Real)2.0e-4) ? 1 : 0;
           }
+          LV(plog).norm();
           if (lane < 19) stx(Xp(nxt, k), lane, L.zn[lane]);
           if (lane < 9) L.xn[lane] = L.xnx[lane];
         }

@@ -90,3 +90,15 @@ def test_algorithmic_words_formula():
     b = problems.make_batch("free", 2, 10, seed=1)
     assert problems.algorithmic_words(b.n_planes, b.n_seg) == 2 * 10 * 760
     assert problems.algorithmic_words(b.n_planes, b.n_seg, infeasible=True) == 2 * 10 * (257 + 910 + 48)
+
+
+def test_row_dealing_reciprocal_table_is_exact():
+    """kInvP of csrc/ddp_tables.h replaces r / P in the row -> (control point, plane) dealing."""
+    import re
+    txt = open(os.path.join(ROOT, "direct_amd", "csrc", "ddp_tables.h")).read()
+    body = re.search(r"kInvP\[33\]\s*=\s*\{([^}]*)\}", txt).group(1)
+    tab = [int(t) for t in body.replace("\n", " ").split(",")]
+    assert len(tab) == 33
+    for P in range(1, 33):
+        for r in range(1024):
+            assert (r * tab[P]) >> 16 == r // P
