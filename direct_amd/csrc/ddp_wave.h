@@ -32,6 +32,8 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define LV(name) name[lane]
 #define WSYNC() ((void)0)
 #define RDLANE(arr, idx, src) (arr[src][idx])
+#define RDLANE_M(var, member, src) (var[src].member)
+#define RDLANE_V(var, src) (var[src])
 #define DDP_UNIFORM_I(x) (x)
 #define DDP_UNIFORM_R(x) (x)
 #define DDP_LAUNDER_S(x) ((void)0)
@@ -65,6 +67,8 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
     __builtin_amdgcn_wave_barrier();             \
   } while (0)
 #define RDLANE(arr, idx, src) direct::readlane_real(arr[idx], src)
+#define RDLANE_M(var, member, src) direct::readlane_real(var.member, src)
+#define RDLANE_V(var, src) direct::readlane_real(var, src)
 #define DDP_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
 // a wave-uniform real computed by the VALU (or read from LDS) moved to SGPRs: frees its VGPRs
 #define DDP_UNIFORM_R(x) direct::uniform_real(x)
@@ -864,13 +868,14 @@ struct Wave {
           LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
         }
       }
+      // the segment time straight from lane 18's prefetch register (z[18], a single word: see ldx()):
+      // the T-dependent tables then need no LDS round trip and share this phase
+      const Real T = (Real)RDLANE_M(pre, zh, 18);
       if (k > 0) {
         Pn = DDP_UNIFORM_I(Pnn);
         Pnn = np_(k > 1 ? k - 2 : 0);
         LANES { prefetch(LV(pre), lane, buf, k - 1, Pn, false, infeas); }
       }
-      WSYNC();
-      const Real T = DDP_UNIFORM_R(L.z[18]);
       DDP_MARK("B_T1");
       // ---- T1: powers of T, scaled value table, dynamics tables
       const Real T2 = DDP_UNIFORM_R(T * T), T4 = DDP_UNIFORM_R(T2 * T2);
@@ -1415,6 +1420,11 @@ struct Wave {
             LV(rky)[i] = infeas ? (Real)LV(pre).ky[i] : (Real)0;
           }
         }
+        {  // powers of the old T, straight from lane 18's prefetch register (no LDS round trip)
+          const Real To = (Real)RDLANE_M(pre, zh, 18);
+          const Real To2 = DDP_UNIFORM_R(To * To), To4 = DDP_UNIFORM_R(To2 * To2);
+          LANES { L.tp[lane & 7] = pow3(To, To2, To4, lane & 7); }
+        }
         if (k + 1 < N) {
           Pn = DDP_UNIFORM_I(Pnn);
           Pnn = np_(k + 2 < N ? k + 2 : k + 1);
@@ -1422,32 +1432,42 @@ struct Wave {
         }
         WSYNC();
       DDP_MARK("F_D");
-        // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the old and the new T
+        // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the new T
+        PLV(Real, unew);
         LANES {
+          LV(unew) = (Real)0;
           if (lane < 9) {
-            L.dz[lane] = L.xn[lane] - L.z[lane];
-            L.zn[lane] = L.xn[lane];
+            const Real xv = L.xn[lane];
+            L.dz[lane] = xv - L.z[lane];
+            L.zn[lane] = xv;
           } else if (lane < 19) {
-            int a = lane - 9;
+            const int a = lane - 9;
+            Real kr[9], xv[9], zv[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+              kr[c] = L.KUr[10 + a * 9 + c];
+              xv[c] = L.xn[c];
+              zv[c] = L.z[c];
+            }
+            const Real zl = L.z[lane], kf = L.KUr[a];
+            DDP_LOADS_ISSUED();
             Real acc = 0;
-#pragma unroll 3
-            for (int c = 0; c < 9; c++) acc += L.KUr[10 + a * 9 + c] * (L.xn[c] - L.z[c]);
+#pragma unroll
+            for (int c = 0; c < 9; c++) acc += kr[c] * (xv[c] - zv[c]);
             L.dz[lane] = acc;
             // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
             // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
-            Real un = (Real)(St)(L.z[lane] + alpha * L.KUr[a] + acc);
+            const Real un = (Real)(St)(zl + alpha * kf + acc);
             L.zn[lane] = un;
-            if (lane == 18) {
-              Real pw = 1;
-              for (int q = 0; q < 8; q++) { L.tpn[q] = pw; pw *= un; }
-            }
-          } else if (lane == 19) {
-            Real To_ = L.z[18], pw = 1;
-            for (int q = 0; q < 8; q++) { L.tp[q] = pw; pw *= To_; }
+            LV(unew) = un;
           }
         }
+        const Real Tn = RDLANE_V(unew, 18);
+        {
+          const Real Tn2 = DDP_UNIFORM_R(Tn * Tn), Tn4 = DDP_UNIFORM_R(Tn2 * Tn2);
+          LANES { L.tpn[lane & 7] = pow3(Tn, Tn2, Tn4, lane & 7); }
+        }
         WSYNC();
-        const Real To = DDP_UNIFORM_R(L.z[18]), Tn = DDP_UNIFORM_R(L.zn[18]);
         if (Tn < 0) neg = 1;
       DDP_MARK("F_T");
         // ---- T: control values at the old and the new iterate, A*[dx; Ku dx], x+, jerk cost
