@@ -297,7 +297,7 @@ struct WaveLds {
           // rows of [L^T | y | Y]: UY[k][j] = L[j][k] (j < 10), UY[k][10 + c] = (L^-1 [Hu | Hux])[k][c];
           // written one row per elimination step by all column lanes at once (phases C, R2).  Stride 20,
           // 64 slots per row so that the idle lanes' stores need no masking.
-          Acc UY[10 * 20 + 44], rdiag[10];
+          Acc UY[10 * 20 + 44];
         };
       };
     };
@@ -1185,9 +1185,9 @@ struct Wave {
       WSYNC();
       DDP_MARK("B_C");
       // ---- C: LLT of Huu + lam I and the 10 right-hand sides [Hu | Hux].  One column per lane in
-      // registers (lanes 0..9 the matrix, 10..19 the right-hand sides); the pivot column of each
-      // elimination step is broadcast through LDS (one round trip per step) instead of 2 v_readlane
-      // per double, and L^T is parked in LDS once for the whole back substitution.
+      // registers (lanes 0..9 the matrix, 10..19 the right-hand sides).  Every multiplier is broadcast
+      // with v_readlane (SGPR operands of the FMAs): the LDS pipe is the busiest unit of the sweep and a
+      // round trip per elimination step would also sit on the serial dependency chain.
       PLA(Acc, m, 10);
       LANES {
         // column `lane` of [Huu + lam I | Hu | Hux]; lanes >= 20 redo column 19 (their results are never read)
@@ -1201,27 +1201,26 @@ struct Wave {
         for (int a = 0; a < 10; a++) LV(m)[a] += ((a == lane) ? lam : (Acc)0);
       }
       // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
-      // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]), so each
-      // step needs one pivot broadcast (v_readlane) and ONE ds_write of the scaled row by all lanes,
-      // which at the same time leaves [L^T | y | Y] in LDS for the back substitution and for phase R2.
+      // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]): the
+      // multiplier of row i is lane i's scaled entry.  The scaled rows are also written to LDS, where
+      // phase R2 reads [y | Y] = L^-1 [Hu | Hux] (columns 10..19).
       int ok = 1;
+      Acc rdiag[10];
 #pragma unroll
       for (int kk = 0; kk < 10; kk++) {
         const Acc piv = RDLANE(m, kk, kk);
         ok = (piv <= (Acc)0) ? 0 : ok;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
         const Acc rinv = frsq(piv);
-        L.rdiag[kk] = rinv;  // wave-uniform store
+        rdiag[kk] = rinv;
         LANES {
           const Acc t = LV(m)[kk] * rinv;
           LV(m)[kk] = t;
           L.UY[kk * 20 + lane] = t;  // lanes >= 20 land in the padding / the next rows' not-yet-written slots
         }
-        WSYNC();
         if (kk < 9) {
           Acc lrow[10];
 #pragma unroll
-          for (int i = kk + 1; i < 10; i++) lrow[i] = L.UY[kk * 20 + i];
-          DDP_LOADS_ISSUED();
+          for (int i = kk + 1; i < 10; i++) lrow[i] = RDLANE(m, kk, i);
           LANES {
             const Acc t = LV(m)[kk];
 #pragma unroll
@@ -1238,11 +1237,10 @@ struct Wave {
       // back substitution L^T X = [y | Y] in the right-hand-side lanes
 #pragma unroll
       for (int i = 9; i >= 0; i--) {
-        Acc urow[10];
+        Acc urow[10];  // L[j][i], j > i: lane j's entry i (back substitution only overwrites entries >= i so far)
 #pragma unroll
-        for (int j = i + 1; j < 10; j++) urow[j] = L.UY[i * 20 + j];
-        const Acc dinv = L.rdiag[i];
-        DDP_LOADS_ISSUED();
+        for (int j = i + 1; j < 10; j++) urow[j] = RDLANE(m, i, j);
+        const Acc dinv = rdiag[i];
         LANES {
           Acc acc = LV(m)[i];
 #pragma unroll
