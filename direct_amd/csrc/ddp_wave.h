@@ -146,9 +146,22 @@ __device__ __forceinline__ double uniform_real(double v) {
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// Wave reductions on the VALU alone (DPP): __shfl_xor compiles to ds_bpermute, i.e. onto the LDS pipe,
+// which is the busiest unit of the sweeps.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {  // lanes without a source read 0
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_d<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_d<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_d<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_d<0x140, 0xf>(v);  // row_mirror: every lane holds the sum of its row of 16
+  v += dpp_d<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_d<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lanes 48..63 hold the total
+  return readlane_real(v, 63);
 }
 __device__ __forceinline__ double wave_max_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -1162,25 +1175,28 @@ struct Wave {
             for (int c = 0; c < 3; c++) zv += L.H[c * 6 + i] * L.Vx[3 * c + d];
             L.Hz[p] = ((i >= 3) ? wsn * L.Ru[p - 9] : (Acc)0) + zv + acc;
           }
-        } else if (lane < 38) {  // (T,T) entry (lane 36) and Hz[T] (lane 37)
-          const Acc* vec = lane == 36 ? L.Sd : L.hh;
-          const Acc* rv = lane == 36 ? L.Rppu : L.Rpu;
-          Acc acc = 0, zv = 0, uru = 0;
-#pragma unroll 5
-          for (int t = 0; t < 45; t++) acc += L.dval[t] * vec[t];
-#pragma unroll 3
-          for (int a = 0; a < 9; a++) {
-            zv += L.fT[a] * (lane == 36 ? L.VZ[a * 19 + 18] : L.Vx[a]);
-            uru += L.z[9 + a] * rv[a];
-          }
-          if (lane == 36) {
-            const Acc quu = ((B.k.time_power == 2) ? (Acc)B.k.w_time : (Acc)0) + (Acc)0.5 * wsn * uru;
-            L.Huu[99] = zv + quu + sig * (acc + L.last[0]);
-          } else {
-            const Acc qz = ((B.k.time_power == 2) ? (Acc)B.k.w_time * T : (Acc)0.5 * (Acc)B.k.w_time) + (Acc)0.5 * wsn * uru;
-            L.Hz[18] = qz + zv + (acc - L.last[1]);
-          }
         }
+      }
+      {  // (T,T) entry and Hz[T]: 45 + 9 + 9 products each, one per lane, then a wave sum on the VALU
+        PLV(Acc, ptt);
+        PLV(Acc, pzt);
+        LANES {
+          const int t = lane < 45 ? lane : 44;
+          const int a = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
+          const Acc dv = L.dval[t], sd = L.Sd[t], hv = L.hh[t];
+          const Acc ft = L.fT[a], vzt = L.VZ[a * 19 + 18], vxa = L.Vx[a];
+          const Acc zu = L.z[9 + a], r2 = L.Rppu[a], r1 = L.Rpu[a];
+          DDP_LOADS_ISSUED();
+          const Acc tt = lane < 45 ? sig * (dv * sd) : (ft * vzt + (Acc)0.5 * wsn * (zu * r2));
+          const Acc zt = lane < 45 ? dv * hv : (ft * vxa + (Acc)0.5 * wsn * (zu * r1));
+          LV(ptt) = lane < 54 ? tt : (Acc)0;
+          LV(pzt) = lane < 54 ? zt : (Acc)0;
+        }
+        const Acc stt = (Acc)WAVE_SUM_D(ptt), szt = (Acc)WAVE_SUM_D(pzt);
+        const Acc quu = (B.k.time_power == 2) ? (Acc)B.k.w_time : (Acc)0;
+        const Acc qz = (B.k.time_power == 2) ? (Acc)B.k.w_time * T : (Acc)0.5 * (Acc)B.k.w_time;
+        L.Huu[99] = stt + quu + sig * L.last[0];  // wave-uniform stores
+        L.Hz[18] = szt + qz - L.last[1];
       }
       WSYNC();
       DDP_MARK("B_C");
@@ -1189,6 +1205,7 @@ struct Wave {
       // with v_readlane (SGPR operands of the FMAs): the LDS pipe is the busiest unit of the sweep and a
       // round trip per elimination step would also sit on the serial dependency chain.
       PLA(Acc, m, 10);
+      PLV(Acc, colmax);
       LANES {
         // column `lane` of [Huu + lam I | Hu | Hux]; lanes >= 20 redo column 19 (their results are never read)
         const int l19 = lane < 20 ? lane : 19;
@@ -1197,9 +1214,14 @@ struct Wave {
 #pragma unroll
         for (int a = 0; a < 10; a++) LV(m)[a] = src[a * stride];
         DDP_LOADS_ISSUED();
+        Acc cmax = 0;  // lane 10 holds Hu = Hz[9..18]: max |Qu| for the optimality error (DDP:633, quirk Q10)
+#pragma unroll
+        for (int a = 0; a < 10; a++) cmax = fmax(cmax, fabs(LV(m)[a]));
+        LV(colmax) = cmax;
 #pragma unroll
         for (int a = 0; a < 10; a++) LV(m)[a] += ((a == lane) ? lam : (Acc)0);
       }
+      const Acc qu_knot = RDLANE_V(colmax, 10);
       // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
       // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]): the
       // multiplier of row i is lane i's scaled entry.  The scaled rows are also written to LDS, where
@@ -1274,12 +1296,7 @@ struct Wave {
         }
       }
       WSYNC();
-      {  // DDP:633 (quirk Q10): Qu after the condensation correction
-        Acc m0 = 0;
-#pragma unroll
-        for (int a = 0; a < 10; a++) m0 = fmax(m0, fabs(L.Hz[9 + a]));
-        qu_err = fmax(qu_err, m0);
-      }
+      qu_err = fmax(qu_err, qu_knot);  // DDP:633 (quirk Q10): Qu after the condensation correction
       DDP_MARK("B_R2");
       // ---- R2: slack / dual gains per row; V recursion; gains to HBM
       LANES {
