@@ -988,34 +988,36 @@ struct Wave {
           }
         }
 #pragma unroll
-        for (int pass = 0; pass < 3; pass++) {  // VZ[a][q], 171 entries
-          const int e = (lane + 64 * pass < 171) ? lane + 64 * pass : 170;
-          const int a = e / 19, q = e % 19;
-          Acc acc = 0;
-          if (q < 18) {
-            int i = q / 3, d = q % 3;
-            Acc v3[3];
-            Real h3[3];
+        for (int pass = 0; pass < 3; pass++) {  // VZ[a][q], q < 18: 162 three-term entries (idle lanes redo the last)
+          const int e = (lane + 64 * pass < 162) ? lane + 64 * pass : 161;
+          const int a = e / 18, q = e % 18;
+          const int i = q / 3, d = q % 3;
+          Acc v3[3];
+          Real h3[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-              v3[c] = L.V[a * 9 + 3 * c + d];
-              h3[c] = L.H[c * 6 + i];
-            }
-            DDP_LOADS_ISSUED();
-#pragma unroll
-            for (int c = 0; c < 3; c++) acc += v3[c] * h3[c];
-          } else {
-            Acc v9[9], f9[9];
-#pragma unroll
-            for (int c = 0; c < 9; c++) {
-              v9[c] = L.V[a * 9 + c];
-              f9[c] = L.fT[c];
-            }
-            DDP_LOADS_ISSUED();
-#pragma unroll
-            for (int c = 0; c < 9; c++) acc += v9[c] * f9[c];
+          for (int c = 0; c < 3; c++) {
+            v3[c] = L.V[a * 9 + 3 * c + d];
+            h3[c] = L.H[c * 6 + i];
           }
-          L.VZ[e] = acc;
+          DDP_LOADS_ISSUED();
+          Acc acc = 0;
+#pragma unroll
+          for (int c = 0; c < 3; c++) acc += v3[c] * h3[c];
+          L.VZ[a * 19 + q] = acc;
+        }
+        if (lane >= 34 && lane < 43) {  // the T column VZ[a][18] = V[a][:] . fT on lanes the third pass leaves idle
+          const int a = lane - 34;
+          Acc v9[9], f9[9];
+#pragma unroll
+          for (int c = 0; c < 9; c++) {
+            v9[c] = L.V[a * 9 + c];
+            f9[c] = L.fT[c];
+          }
+          DDP_LOADS_ISSUED();
+          Acc acc = 0;
+#pragma unroll
+          for (int c = 0; c < 9; c++) acc += v9[c] * f9[c];
+          L.VZ[a * 19 + 18] = acc;
         }
       }
       WSYNC();
@@ -1435,11 +1437,8 @@ struct Wave {
             LV(rky)[i] = infeas ? (Real)LV(pre).ky[i] : (Real)0;
           }
         }
-        {  // powers of the old T, straight from lane 18's prefetch register (no LDS round trip)
-          const Real To = (Real)RDLANE_M(pre, zh, 18);
-          const Real To2 = DDP_UNIFORM_R(To * To), To4 = DDP_UNIFORM_R(To2 * To2);
-          LANES { L.tp[lane & 7] = pow3(To, To2, To4, lane & 7); }
-        }
+        // the old T straight from lane 18's prefetch register (no LDS round trip)
+        const Real To = (Real)RDLANE_M(pre, zh, 18);
         if (k + 1 < N) {
           Pn = DDP_UNIFORM_I(Pnn);
           Pnn = np_(k + 2 < N ? k + 2 : k + 1);
@@ -1449,26 +1448,31 @@ struct Wave {
       DDP_MARK("F_D");
         // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the new T
         PLV(Real, unew);
+        PLV(Real, dxl);
+        LANES {
+          const int l9 = lane < 9 ? lane : 8;
+          const Real xv = L.xn[l9];
+          LV(dxl) = xv - L.z[l9];
+          if (lane < 9) {
+            L.dz[lane] = LV(dxl);
+            L.zn[lane] = xv;
+          }
+        }
+        Real dx[9];  // dx is the same for the ten u lanes: broadcast from lanes 0..8 instead of 18 LDS reads each
+#pragma unroll
+        for (int c = 0; c < 9; c++) dx[c] = RDLANE_V(dxl, c);
         LANES {
           LV(unew) = (Real)0;
-          if (lane < 9) {
-            const Real xv = L.xn[lane];
-            L.dz[lane] = xv - L.z[lane];
-            L.zn[lane] = xv;
-          } else if (lane < 19) {
+          if (lane >= 9 && lane < 19) {
             const int a = lane - 9;
-            Real kr[9], xv[9], zv[9];
+            Real kr[9];
 #pragma unroll
-            for (int c = 0; c < 9; c++) {
-              kr[c] = L.KUr[10 + a * 9 + c];
-              xv[c] = L.xn[c];
-              zv[c] = L.z[c];
-            }
+            for (int c = 0; c < 9; c++) kr[c] = L.KUr[10 + a * 9 + c];
             const Real zl = L.z[lane], kf = L.KUr[a];
             DDP_LOADS_ISSUED();
             Real acc = 0;
 #pragma unroll
-            for (int c = 0; c < 9; c++) acc += kr[c] * (xv[c] - zv[c]);
+            for (int c = 0; c < 9; c++) acc += kr[c] * dx[c];
             L.dz[lane] = acc;
             // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
             // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
@@ -1478,9 +1482,15 @@ struct Wave {
           }
         }
         const Real Tn = RDLANE_V(unew, 18);
-        {
-          const Real Tn2 = DDP_UNIFORM_R(Tn * Tn), Tn4 = DDP_UNIFORM_R(Tn2 * Tn2);
-          LANES { L.tpn[lane & 7] = pow3(Tn, Tn2, Tn4, lane & 7); }
+        const Real To2 = DDP_UNIFORM_R(To * To), To4 = DDP_UNIFORM_R(To2 * To2);
+        const Real Tn2 = DDP_UNIFORM_R(Tn * Tn), Tn4 = DDP_UNIFORM_R(Tn2 * Tn2);
+        LANES { L.tpn[lane & 7] = pow3(Tn, Tn2, Tn4, lane & 7); }
+        // T^j, j = 0..5, of the old and the new iterate as wave-uniform operands (same values as the tables)
+        Real pwo[6], pwn[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          pwo[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(To, To2, To4, j));
+          pwn[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(Tn, Tn2, Tn4, j));
         }
         WSYNC();
         if (Tn < 0) neg = 1;
@@ -1490,31 +1500,33 @@ struct Wave {
           if (lane < 45) {
             int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
             Real vo = 0, dvo = 0, vn = 0, gf = 0;
+            // Summed over the exponent j = i - o instead of the coefficient index i (same terms, same
+            // order: the i < o terms have zero weight): the power T^j is then the same for every lane and
+            // comes from a uniform register instead of three LDS table reads per term.
 #pragma unroll
-            for (int half = 0; half < 2; half++) {  // two batches of 24 operands (48 live doubles would spill)
-              Real wb6[3], wd6[3], t0[3], t1[3], tn6[3], zo6[3], dz6[3], zn6[3];
+            for (int half = 0; half < 2; half++) {  // two batches of 15 operands
+              Real wb6[3], wd6[3], zo6[3], dz6[3], zn6[3];
 #pragma unroll
-              for (int j = 0; j < 3; j++) {
-                const int i = 3 * half + j;
-                const int e = i - o;
-                const int e0 = e < 0 ? 0 : e, e1 = e < 1 ? 0 : e - 1;
-                wb6[j] = L.WbE[cr * 6 + i];
-                wd6[j] = L.WdE[cr * 6 + i];
-                t0[j] = L.tp[e0];
-                t1[j] = L.tp[e1];
-                tn6[j] = L.tpn[e0];
-                zo6[j] = L.z[3 * i + d];
-                dz6[j] = L.dz[3 * i + d];
-                zn6[j] = L.zn[3 * i + d];
+              for (int jj = 0; jj < 3; jj++) {
+                const int j = 3 * half + jj;
+                const bool on = (j < 4) || (j + o < 6);  // o <= 2
+                const int i = on ? j + o : 5;
+                const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[cr * 6 + i];
+                wb6[jj] = on ? wbv : (Real)0;
+                wd6[jj] = on ? wdv : (Real)0;
+                zo6[jj] = L.z[3 * i + d];
+                dz6[jj] = L.dz[3 * i + d];
+                zn6[jj] = L.zn[3 * i + d];
               }
               DDP_LOADS_ISSUED();
 #pragma unroll
-              for (int j = 0; j < 3; j++) {
-                const Real w = wb6[j] * t0[j];
-                vo += w * zo6[j];
-                gf += w * dz6[j];
-                dvo += wd6[j] * t1[j] * zo6[j];
-                vn += wb6[j] * tn6[j] * zn6[j];
+              for (int jj = 0; jj < 3; jj++) {
+                const int j = 3 * half + jj;
+                const Real w = wb6[jj] * pwo[j];
+                vo += w * zo6[jj];
+                gf += w * dz6[jj];
+                dvo += wd6[jj] * pwo[j < 1 ? 0 : j - 1] * zo6[jj];
+                vn += wb6[jj] * pwn[j] * zn6[jj];
               }
             }
             L.val[lane] = vo;
