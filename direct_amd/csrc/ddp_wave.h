@@ -277,7 +277,6 @@ struct WaveLds {
   Real Hc[18], Hpc[18];   // [F|G] and [F'|G'] coefficients; entry = coefficient * T^exponent
   int He[18], Hpe[18];
   Real Rc[9];             // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1)
-  int pq[176];            // upper triangle of the 18x18 block, packed: see init_tables()
   // per knot, both sweeps
   Real tp[8];             // powers of T
   Real z[kXS];
@@ -533,20 +532,6 @@ struct Wave {
         if (B.k.exact_dt) d = (double)(i - ctrl_off(cr)) * v;  // non-parity: exact d/dT
         L.WbE[e] = (Real)(v * eps);
         L.WdE[e] = (Real)(d * eps);
-      }
-#pragma unroll 1
-      for (int e = lane; e < 176; e += 64) {
-        // e -> (p,q), p <= q < 18, row-major over the upper triangle (171 entries), packed with
-        // everything phase H derives from it: p:5 q:5 i:3 d:2 i2:3 d2:2 sidx:3 (d==d2):1
-        int p = 0, rem = e;
-        while (p < 18 && rem >= 18 - p) {
-          rem -= 18 - p;
-          p++;
-        }
-        const int q = p + rem, i = p / 3, d = p % 3, i2 = q / 3, d2 = q % 3;
-        const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
-        const int sidx = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);  // xx,xy,xz,yy,yz,zz
-        L.pq[e < 176 ? e : 0] = (e < 171) ? (p | (q << 5) | (i << 10) | (d << 13) | (i2 << 15) | (d2 << 18) | (sidx << 20) | ((d == d2) << 23)) : L.pq[0];
       }
       if (lane < 18) {  // [F|G] (DDP:862-871) and [F'|G'] (DDP:930-935): coefficient and exponent of T
         int c = lane / 6, i = lane % 6;
@@ -907,24 +892,29 @@ struct Wave {
       WSYNC();
       DDP_MARK("B_T2");
       // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u (all lanes run all roles, clamped)
+      Real pw[6];  // T^j as wave-uniform operands
+#pragma unroll
+      for (int j = 0; j < 6; j++) pw[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(T, T2, T4, j));
       LANES {
         {
           const int l45 = lane < 45 ? lane : 44;
           const int cr = l45 / 3, d = l45 % 3, o = ctrl_off(cr);
-          Real v = 0, dv = 0, z6[6], we6[6], wd6[6], tp6[6];
+          // summed over the exponent j = i - o (see fwd_pass, phase T): uniform powers, no table reads
+          Real v = 0, dv = 0, z6[6], wb6[6], wd6[6];
 #pragma unroll
-          for (int i = 0; i < 6; i++) {
-            const int e = i - o - 1;
-            z6[i] = L.z[3 * i + d];
-            we6[i] = L.We[cr * 6 + i];
-            wd6[i] = L.WdE[cr * 6 + i];
-            tp6[i] = L.tp[e < 0 ? 0 : e];  // WdE is 0 where e < 0
+          for (int j = 0; j < 6; j++) {
+            const bool on = (j < 4) || (j + o < 6);  // o <= 2
+            const int i = on ? j + o : 5;
+            const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[cr * 6 + i];
+            z6[j] = L.z[3 * i + d];
+            wb6[j] = on ? wbv : (Real)0;
+            wd6[j] = on ? wdv : (Real)0;
           }
           DDP_LOADS_ISSUED();
 #pragma unroll
-          for (int i = 0; i < 6; i++) {
-            v += we6[i] * z6[i];
-            dv += wd6[i] * tp6[i] * z6[i];
+          for (int j = 0; j < 6; j++) {
+            v += (wb6[j] * pw[j]) * z6[j];  // We[cr][i] = WbE * T^j, exactly as phase T1 forms it
+            dv += wd6[j] * pw[j < 1 ? 0 : j - 1] * z6[j];
           }
           L.val[l45] = v;
           L.dval[l45] = dv;
@@ -1071,57 +1061,32 @@ struct Wave {
       WSYNC();
       DDP_MARK("B_H");
       // ---- H: assemble the 19x19 system  Hzz = Z'VZ + quu -/+ A'DA,  Hz = qz + Z'Vx + A'g
+      // The 18x18 block, p <= q.  A lane owns one (i, i2 >= i) pair of control points and one axis d and
+      // walks the three axes d2 of the column: the twelve We operands, their products and the three H
+      // operands are loaded once for three entries, and the velocity / acceleration rows (which only touch
+      // d2 == d) need no second pass over the stored block.
       LANES {
-#pragma unroll
-        for (int pass = 0; pass < 3; pass++) {  // the 18x18 block, p <= q: 171 entries, idle lanes redo the last
-          const int e = (lane + 64 * pass < 171) ? lane + 64 * pass : 170;
-          const int w = L.pq[e];
-          const int p = w & 31, q = (w >> 5) & 31, i = (w >> 10) & 7, d = (w >> 13) & 3;
-          const int i2 = (w >> 15) & 7, sidx = (w >> 20) & 7, dd = (w >> 23) & 1;
-          Acc ada = 0, zvz = 0;
-          Real w1[6], w2[6], hh3[3];
-          Acc sp6[6], vz3[3];
+        const int l62 = lane < 63 ? lane : 62;  // lane 63 redoes lane 62
+        const int pr = l62 / 3, d = l62 % 3;
+        const int i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
+        const int i2 = i + pr - (6 * i - (i * (i - 1)) / 2);
+        const int p = 3 * i + d;
+        Acc ww[6], adv = 0;
+        Real hh3[3];
+        {
+          Real w1[6], w2[6];
 #pragma unroll
           for (int cr = 0; cr < 6; cr++) {
             w1[cr] = L.We[cr * 6 + i];
             w2[cr] = L.We[cr * 6 + i2];
-            sp6[cr] = L.Sp[cr * 6 + sidx];
           }
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            hh3[c] = L.H[c * 6 + i];
-            vz3[c] = L.VZ[(3 * c + d) * 19 + q];
-          }
-          const bool hasq = (i >= 3 && dd);
-          const Real rc1 = L.Rc[hasq ? (i - 3) * 3 + (i2 - 3) : 0], tp1 = L.tp[hasq ? i + i2 - 5 : 0];
+          for (int c = 0; c < 3; c++) hh3[c] = L.H[c * 6 + i];
           DDP_LOADS_ISSUED();
 #pragma unroll
-          for (int cr = 0; cr < 6; cr++) ada += w1[cr] * w2[cr] * sp6[cr];
-#pragma unroll
-          for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
-          const Acc quu = hasq ? wsn * rc1 * tp1 : (Acc)0;
-          const Acc v = zvz + quu + sig * ada;
-          // Hxx | Hxu | Huu are consecutive members: element offsets from Hxx[0] (81, 171), integer selects
-          Acc* Hb = L.Hxx;
-          const int oxx = p * 9 + q, oxu = 81 + p * 10 + (q - 9), ouu = 171 + (p - 9) * 10 + (q - 9);
-          const int txx = q * 9 + p, tuu = 171 + (q - 9) * 10 + (p - 9);
-          const int o1 = q < 9 ? oxx : (p < 9 ? oxu : ouu);
-          const int o2 = q < 9 ? txx : (p < 9 ? oxu : tuu);
-          Hb[o1] = v;
-          Hb[o2] = v;
+          for (int cr = 0; cr < 6; cr++) ww[cr] = w1[cr] * w2[cr];
         }
-      }
-      WSYNC();
-      LANES {
-        if (lane < 63) {  // velocity / acceleration rows only touch entries with d == d2: 21 (i,i2) pairs x 3 axes
-          const int pr = lane / 3, d = lane % 3;
-          int i = 0, rem = pr;
-          while (rem >= 6 - i) {
-            rem -= 6 - i;
-            i++;
-          }
-          const int i2 = i + rem, p = 3 * i + d, q = 3 * i2 + d;
-          Acc ada = 0;
+        {
           Real w1[9], w2[9];
           Acc dl9[9];
 #pragma unroll
@@ -1132,16 +1097,41 @@ struct Wave {
           }
           DDP_LOADS_ISSUED();
 #pragma unroll
-          for (int cr = 0; cr < 9; cr++) ada += w1[cr] * w2[cr] * dl9[cr];
-          ada *= sig;
+          for (int cr = 0; cr < 9; cr++) adv += w1[cr] * w2[cr] * dl9[cr];
+          adv *= sig;
+        }
+        const bool hasq = i >= 3;
+        const Real rc1 = L.Rc[hasq ? (i - 3) * 3 + (i2 - 3) : 0], tp1 = L.tp[hasq ? i + i2 - 5 : 0];
+#pragma unroll
+        for (int d2 = 0; d2 < 3; d2++) {
+          const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
+          const int sidx = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);  // xx,xy,xz,yy,yz,zz
+          const int q = 3 * i2 + d2;
+          Acc sp6[6], vz3[3];
+#pragma unroll
+          for (int cr = 0; cr < 6; cr++) sp6[cr] = L.Sp[cr * 6 + sidx];
+#pragma unroll
+          for (int c = 0; c < 3; c++) vz3[c] = L.VZ[(3 * c + d) * 19 + q];
+          DDP_LOADS_ISSUED();
+          Acc ada = 0, zvz = 0;
+#pragma unroll
+          for (int cr = 0; cr < 6; cr++) ada += ww[cr] * sp6[cr];
+#pragma unroll
+          for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
+          const bool dd = d2 == d;
+          const Acc quu = (hasq && dd) ? wsn * rc1 * tp1 : (Acc)0;
+          Acc v = zvz + quu + sig * ada;
+          v = dd ? v + adv : v;
+          // Hxx | Hxu | Huu are consecutive members: element offsets from Hxx[0] (81, 171), integer selects
           Acc* Hb = L.Hxx;
           const int oxx = p * 9 + q, oxu = 81 + p * 10 + (q - 9), ouu = 171 + (p - 9) * 10 + (q - 9);
           const int txx = q * 9 + p, tuu = 171 + (q - 9) * 10 + (p - 9);
           const int o1 = q < 9 ? oxx : (p < 9 ? oxu : ouu);
           const int o2 = q < 9 ? txx : (p < 9 ? oxu : tuu);
-          const Acc v = Hb[o1] + ada;
-          Hb[o1] = v;
-          Hb[o2] = v;
+          if (p <= q) {  // i == i2: the lower triangle of the diagonal block belongs to the lane of the other axis
+            Hb[o1] = v;
+            Hb[o2] = v;
+          }
         }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
           const int p = lane < 18 ? lane : lane - 18;
