@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,6 +51,71 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate(Batch<St> B, in
   W.init_tables();
   W.iterate(n_iters);
   W.store_state();
+}
+
+// The same loop, dynamically scheduled.  A launch of `batch` one-wave workgroups over the 256 x 12
+// resident slots leaves a tail: the last batch - 3072 trajectories run alone on an almost empty chip.
+// Here a resident set of persistent waves draws TICKETS instead: ticket t = (epoch e, trajectory b) =
+// (t / batch, t % batch) is `chunk` trips of the outer loop of trajectory b.  Between iterations a
+// trajectory lives entirely in HBM (iterate buffers, TrajState, filter), so consecutive chunks of one
+// trajectory may run on different CUs / XCDs; chunk e waits for chunk e-1 through done_epoch[b]
+// (agent-scope release / acquire).  The holder of an earlier ticket is always resident and running, so
+// the wait cannot deadlock; a spin limit turns a scheduling bug into an error code instead of a hang.
+constexpr int kDoneBit = 1 << 30;  // in done_epoch[b]: the trajectory has left the outer loop
+struct Sched {
+  unsigned* ticket;   // [1] next ticket
+  int* done_epoch;    // [batch] chunks completed per trajectory
+  int* err;           // [1] set to 1 when the spin limit is hit
+  int chunk;
+};
+// Draws the next ticket and waits for the previous chunk of its trajectory.  Returns the ticket, -1
+// when none are left, -2 when the ticket's trajectory has already finished (kDoneBit in done_epoch).  Out of line and free of early exits on purpose: inlined into the (huge) iterate
+// loop the structuriser turned the nested uniform loops into exec-masked ones.
+__device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsigned total) {
+  unsigned tv = 0;
+  if (threadIdx.x == 0) tv = __hip_atomic_fetch_add(S.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
+  if (t >= total) return -1;
+  const int e = (int)(t / nb), b = (int)(t - (unsigned)e * nb);
+  int ready = (e == 0) ? 1 : 0, have = 0;
+  for (int spins = 0; !ready && spins < (1 << 22); spins++) {
+    int hv = 0;
+    if (threadIdx.x == 0) hv = __hip_atomic_load(&S.done_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    have = __builtin_amdgcn_readfirstlane(hv);
+    ready = (have >= e) ? 1 : 0;
+    if (!ready) __builtin_amdgcn_s_sleep(32);
+  }
+  if (!ready && threadIdx.x == 0) *S.err = 1;  // a scheduling bug: reported by direct_ddp_finish, never a hang
+  if (have >= kDoneBit) return -2;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return (int)t;
+}
+template <typename St, int RPL>
+__global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B, int n_iters, Sched S) {
+  __shared__ WaveLds<Cmp, St, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, 0);
+  W.init_tables();
+  const unsigned nb = (unsigned)B.B;
+  const unsigned n_epochs = (unsigned)((n_iters + S.chunk - 1) / S.chunk);
+  const unsigned total = nb * n_epochs;
+#pragma unroll 1
+  for (;;) {
+    const int t = __builtin_amdgcn_readfirstlane(next_ticket(S, nb, total));
+    if (t == -1) break;
+    if (t == -2) continue;
+    const int e = __builtin_amdgcn_readfirstlane((int)((unsigned)t / nb));
+    const int b = __builtin_amdgcn_readfirstlane(t - e * (int)nb);
+    W.b = b;
+    W.load_state();
+    if (!__builtin_amdgcn_readfirstlane(lds.st.done)) {
+      const int left = n_iters - e * S.chunk;
+      W.iterate(left < S.chunk ? left : S.chunk);
+      W.store_state();
+    }
+    const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) __hip_atomic_store(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // stepwise interface: mode 1 = one backwardpass(), 2 = one forwardpass()
@@ -169,6 +235,10 @@ struct direct_ddp_handle_s {
   } o = {};
   int *best_idx = nullptr;
   double* best_cost = nullptr;
+  // dynamic scheduling of k_iterate_dyn: [0] ticket, [1] error flag, [2..] done_epoch[max_batch]
+  int* sched = nullptr;
+  int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device
+  bool dynamic = true;
   // current batch
   int B = 0;
   bool begun = false;
@@ -229,10 +299,34 @@ static void launch_begin_t(direct_ddp_handle_t h) {
   RPL_LAUNCH(h, k_begin, Real, h->B, Bt);
 }
 template <typename Real>
+static int resident_slots(direct_ddp_handle_t h, int n_cu) {
+  int per_cu = 0;
+  hipError_t e;
+  if (h->rpl <= 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 2>, 64, 0);
+  else if (h->rpl == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 3>, 64, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 4>, 64, 0);
+  return (e == hipSuccess && per_cu > 0) ? per_cu * n_cu : 0;
+}
+template <typename Real>
 static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
   auto Bt = make_batch<Real>(h, h->cur_in, h->params);
-  if (mode == 0) RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n);
-  else RPL_LAUNCH(h, k_pass, Real, h->B, Bt, mode);
+  if (mode == 0) {
+    // the static launch is already tail-free when every trajectory is resident at once
+    if (h->dynamic && h->sched_slots > 0 && h->B > h->sched_slots) {
+      Sched S;
+      S.ticket = (unsigned*)h->sched;
+      S.err = h->sched + 1;
+      S.done_epoch = h->sched + 2;
+      S.chunk = 1;
+      if (const char* ev = getenv("DIRECT_DDP_CHUNK")) S.chunk = atoi(ev) > 0 ? atoi(ev) : 1;
+      (void)hipMemsetAsync(h->sched, 0, (size_t)(2 + h->B) * sizeof(int), h->stream);
+      RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
+    } else {
+      RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n);
+    }
+  } else {
+    RPL_LAUNCH(h, k_pass, Real, h->B, Bt, mode);
+  }
 }
 template <typename Real>
 static void launch_field_t(direct_ddp_handle_t h, int field, int set) {
@@ -304,10 +398,17 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->o.opterr, B * r); A(&h->o.mu, B * r);
   A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
   A(&h->best_idx, 16); A(&h->best_cost, 16);
+  A(&h->sched, (B + 2) * sizeof(int));
+  h->dynamic = !(cfg->reserved & DIRECT_FLAG_STATIC_SCHEDULE);
+  if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
+  h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
+                                            : resident_slots<float>(h, prop.multiProcessorCount);
   h->fieldbuf_bytes = B * nm * (size_t)std::max(ncm, 100) * r + B * 16 * r + B * 9 * r;
   A(&h->fieldbuf, h->fieldbuf_bytes);
   if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
     st = fail(DIRECT_ERR_DEVICE, "hipEventCreate failed");
+  if (st == DIRECT_OK && hipMemset(h->sched, 0, (B + 2) * sizeof(int)) != hipSuccess)
+    st = fail(DIRECT_ERR_DEVICE, "hipMemset failed");
   if (st != DIRECT_OK) {
     direct_ddp_destroy(h);
     return st;
@@ -433,7 +534,10 @@ static direct_status_t launch_finish(direct_ddp_handle_t h, direct_ddp_batch_out
     HIP_TRY(dn(out->opterr, h->o.opterr, B * r)); HIP_TRY(dn(out->mu, h->o.mu, B * r));
     HIP_TRY(dn(out->bez, h->o.bez, B * nm * 18 * r)); HIP_TRY(dn(out->poly, h->o.poly, B * nm * 18 * r));
     HIP_TRY(dn(out->T, h->o.T, B * nm * r));
+    int sched_err = 0;
+    HIP_TRY(hipMemcpyAsync(&sched_err, h->sched + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (sched_err) return fail(DIRECT_ERR_DEVICE, "ticket scheduler of k_iterate hit its spin limit; results are incomplete");
   }
   return DIRECT_OK;
 }

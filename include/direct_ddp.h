@@ -124,8 +124,13 @@ typedef struct {
   int32_t max_batch;
   int32_t n_seg_max;
   int32_t p_max;
-  int32_t reserved;
+  int32_t reserved;      /* flags: DIRECT_FLAG_* (0 = defaults) */
 } direct_ddp_config_t;
+
+/* Launch k_iterate as one workgroup per trajectory instead of the default ticket scheduler (persistent
+ * waves drawing (trajectory, iteration) tickets: no tail when batch > resident waves).  Results are
+ * identical; the environment variable DIRECT_DDP_SCHED=static|dynamic overrides the flag. */
+#define DIRECT_FLAG_STATIC_SCHEDULE 1
 
 typedef struct direct_ddp_handle_s* direct_ddp_handle_t;
 

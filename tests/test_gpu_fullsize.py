@@ -171,3 +171,20 @@ def test_device_memory_interface_matches_host_interface(built, free_batch):
     assert np.array_equal(o["bez"].cpu().numpy(), want.bez)
     assert np.array_equal(o["T"].cpu().numpy(), want.T)
     s.close()
+
+
+def test_ticket_scheduler_is_bitwise_equal_to_one_workgroup_per_trajectory(built, corridor_batch, monkeypatch):
+    """k_iterate_dyn (persistent waves drawing (trajectory, iteration) tickets; the default when the batch
+    exceeds the resident waves) against k_iterate (one workgroup per trajectory): a trajectory's
+    iterations run on different CUs / XCDs, the arithmetic and every discrete decision must not change."""
+    res = {}
+    for mode in ("static", "dynamic"):
+        monkeypatch.setenv("DIRECT_DDP_SCHED", mode)
+        s = solver.DdpSolver(B, N, corridor_batch.p_max, np.float32)
+        g0, g1 = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=30), corridor_batch.astype(np.float32))
+        res[mode] = (g0, g1)
+        s.close()
+    for a, b in zip(res["static"], res["dynamic"]):
+        for f in ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert res["dynamic"][1].iter_used.max() > 1
