@@ -40,6 +40,7 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define DDP_LOADS_ISSUED() ((void)0)
 #define DDP_PIN(x) ((void)0)
 #define DDP_OPAQUE_S(x) ((void)0)
+#define DDP_UMUL24(a, b) ((a) * (b))
 #define DDP_MARK(name)
 #else
 #include <hip/hip_runtime.h>
@@ -87,6 +88,8 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 // select between two kernel-argument fields is turned into ONE lane-indexed vector load from the kernarg
 // segment, i.e. a full memory round trip (and a vmcnt(0) that also drains the prefetch) in the row loop.
 #define DDP_OPAQUE_S(x) asm("" : "+s"(x))
+#define DDP_UMUL24(a, b) __umul24(a, b)  // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
+
 #if defined(DDP_MARKS)  // phase markers in the .s for static instruction accounting (tools/phase_count.py)
 #define DDP_MARK(name) asm volatile("; DDP_MARK " name ::: "memory")
 #elif defined(DDP_TIMING)  // per-phase cycle accounting with s_memtime (tools/phase_timing.py); debug builds only
@@ -128,6 +131,7 @@ __device__ __forceinline__ void phase_tick(const char* name) {
 __device__ __forceinline__ int opaque_lane() {
   int l = (int)threadIdx.x;
   asm volatile("" : "+v"(l));
+  __builtin_assume(l >= 0 && l < 64);  // range for the index arithmetic (24-bit multiplies, unsigned division)
   return l;
 }
 __device__ __forceinline__ float readlane_real(float v, int src) {
@@ -432,11 +436,21 @@ struct Wave {
 
   DDP_DEV Wave(const Batch<St>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
 
+  // Knot (b, k) of the [B][nmax(+1)] arrays; k may differ between lanes.
   DDP_DEV St* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * kXS; }
   DDP_DEV St* Sp_(St* base, int k) const { return base + ((size_t)b * B.nmax + k) * B.ncs; }
   DDP_DEV const St* planes_(int k) const { return B.planes + ((size_t)b * B.nmax + k) * B.pmax * 4; }
   DDP_DEV int np_(int k) const { return B.n_planes[(size_t)b * B.nmax + k]; }
   DDP_DEV St* KUp(int k) const { return B.KU + ((size_t)b * B.nmax + k) * 100; }
+  // The same for a WAVE-UNIFORM k (the sweeps).  The 32-bit row index is forced into an SGPR so that
+  // every 64-bit address product stays on the scalar unit (under SGPR pressure `b` ends up in a VGPR and
+  // each address would otherwise cost several quarter-rate v_mad_u64_u32).
+  DDP_DEV size_t rowU(int k) const { return (size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k); }
+  DDP_DEV St* XpU(int buf, int k) const { return B.X[buf] + (size_t)(unsigned)DDP_UNIFORM_I(b * (B.nmax + 1) + k) * kXS; }
+  DDP_DEV St* SpU(St* base, int k) const { return base + rowU(k) * B.ncs; }
+  DDP_DEV const St* planesU(int k) const { return B.planes + rowU(k) * (B.pmax * 4); }
+  DDP_DEV int npU(int k) const { return B.n_planes[rowU(k)]; }
+  DDP_DEV St* KUpU(int k) const { return B.KU + rowU(k) * 100; }
   // Knot-record access.  Positions reach hundreds of metres while a barrier step must resolve
   // ~1e-7 of the log-cost, so with float storage the three position words are kept as an unevaluated
   // hi + lo pair (words a and 19 + a); every other entry is O(1) and a single word suffices.
@@ -460,17 +474,17 @@ struct Wave {
     St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
   DDP_DEV void prefetch(Pre& p, int lane, int buf, int k, int P, bool fwd, int infeas) const {
-    const St* rec = Xp(buf, k);
+    const St* rec = XpU(buf, k);
     p.zh = rec[lane < 19 ? lane : 18];
     p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 3 ? lane : 2)] : (St)0;  // see ldx()
-    const St* pk = planes_(k);
+    const St* pk = planesU(k);
     const int pend = 4 * P - 1;
     p.pl[0] = pk[lane < pend ? lane : pend];
     p.pl[1] = pk[lane + 64 < pend ? lane + 64 : pend];
-    const St* sk = Sp_(B.S[buf], k);
-    const St* yk = Sp_(B.Y[buf], k);
-    const St* ksk = Sp_(B.KS, k);
-    const St* kyk = Sp_(B.KY, k);
+    const St* sk = SpU(B.S[buf], k);
+    const St* yk = SpU(B.Y[buf], k);
+    const St* ksk = SpU(B.KS, k);
+    const St* kyk = SpU(B.KY, k);
     for (int i = 0; i < RPL; i++) {
       const int r = row_r(i, lane, P);
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0 and are masked in commit_rows()
@@ -482,7 +496,7 @@ struct Wave {
       }
     }
     if (fwd) {
-      const St* ku = KUp(k);
+      const St* ku = KUpU(k);
       p.ku[0] = ku[lane];
       p.ku[1] = ku[lane + 64 < 100 ? lane + 64 : 99];
     }
@@ -578,8 +592,8 @@ struct Wave {
     const int rp = last ? 64 * (RPL - 1) + lane - 55 : lane + 64 * slot;
     const bool pv = rp >= 0 && rp < 6 * P;
     const int rq = pv ? rp : 0;
-    const int j = (int)(((unsigned)rq * kInvP[P]) >> 16);  // rq / P: the control point
-    const Real* n = &L.pl[4 * (rq - j * P)];
+    const int j = (int)(DDP_UMUL24((unsigned)rq, kInvP[P]) >> 16);  // rq / P: the control point
+    const Real* n = &L.pl[4 * (rq - (int)DDP_UMUL24((unsigned)j, (unsigned)P))];
     k.n0 = n[0];
     k.n1 = n[1];
     k.n2 = n[2];
@@ -831,18 +845,18 @@ struct Wave {
     LANES {
 #pragma unroll 1
       for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Acc)B.k.w_term : (Acc)0;
-      if (lane < 9) L.Vx[lane] = (Acc)B.k.w_term * (Acc)(ldx(Xp(buf, N), lane) - (Real)B.xd[(size_t)b * 9 + lane]);
+      if (lane < 9) L.Vx[lane] = (Acc)B.k.w_term * (Acc)(ldx(XpU(buf, N), lane) - (Real)B.xd[(size_t)b * 9 + lane]);
     }
     WSYNC();
+    // opterr = max(|Qu|, |r|, |c + y|) over the sweep (DDP:641): one running maximum per lane is enough
     PLV(Real, e_mu);
-    PLV(Real, e_c);
-    LANES { LV(e_mu) = 0; LV(e_c) = 0; }
+    LANES { LV(e_mu) = 0; }
     Acc qu_err = 0;
 
     // plane counts run two knots ahead of the sweep (the prefetch of knot k-1 needs P(k-1) for its
     // addresses: loading it on the spot would expose one HBM round trip per knot)
-    int Pn = DDP_UNIFORM_I(np_(N - 1));
-    int Pnn = np_(N > 1 ? N - 2 : 0);
+    int Pn = DDP_UNIFORM_I(npU(N - 1));
+    int Pnn = npU(N > 1 ? N - 2 : 0);
     PLV(Pre, pre);
     LANES { prefetch(LV(pre), lane, buf, N - 1, Pn, false, infeas); }
 #pragma unroll 1
@@ -871,7 +885,7 @@ struct Wave {
       const Real T = (Real)RDLANE_M(pre, zh, 18);
       if (k > 0) {
         Pn = DDP_UNIFORM_I(Pnn);
-        Pnn = np_(k > 1 ? k - 2 : 0);
+        Pnn = npU(k > 1 ? k - 2 : 0);
         LANES { prefetch(LV(pre), lane, buf, k - 1, Pn, false, infeas); }
       }
       DDP_MARK("B_T1");
@@ -961,8 +975,7 @@ struct Wave {
             Real yinv = frcp(y);
             D = s * yinv;
             g = s + yinv * rv;
-            LV(e_mu) = fmax(LV(e_mu), in ? fabs(rm) : (Real)0);
-            LV(e_c) = fmax(LV(e_c), in ? fabs(c + y) : (Real)0);
+            LV(e_mu) = fmax(LV(e_mu), in ? fmax(fabs(rm), fabs(c + y)) : (Real)0);
           } else {  // DDP:583-587, 601
             rv = s * c + mu;
             Real cinv = frcp(c);
@@ -1084,22 +1097,28 @@ struct Wave {
           for (int c = 0; c < 3; c++) hh3[c] = L.H[c * 6 + i];
           DDP_LOADS_ISSUED();
 #pragma unroll
-          for (int cr = 0; cr < 6; cr++) ww[cr] = w1[cr] * w2[cr];
+          for (int cr = 0; cr < 6; cr++) {
+            ww[cr] = w1[cr] * w2[cr];
+            DDP_PIN(ww[cr]);
+          }
         }
-        {
-          Real w1[9], w2[9];
-          Acc dl9[9];
 #pragma unroll
-          for (int cr = 0; cr < 9; cr++) {
-            w1[cr] = L.We[(cr + 6) * 6 + i];
-            w2[cr] = L.We[(cr + 6) * 6 + i2];
-            dl9[cr] = L.dl[cr * 3 + d];
+        for (int part = 0; part < 3; part++) {  // three batches of nine operands keep the live set small
+          Real w1[3], w2[3];
+          Acc dl3[3];
+#pragma unroll
+          for (int c3 = 0; c3 < 3; c3++) {
+            const int cr = 3 * part + c3;
+            w1[c3] = L.We[(cr + 6) * 6 + i];
+            w2[c3] = L.We[(cr + 6) * 6 + i2];
+            dl3[c3] = L.dl[cr * 3 + d];
           }
           DDP_LOADS_ISSUED();
 #pragma unroll
-          for (int cr = 0; cr < 9; cr++) adv += w1[cr] * w2[cr] * dl9[cr];
-          adv *= sig;
+          for (int c3 = 0; c3 < 3; c3++) adv += w1[c3] * w2[c3] * dl3[c3];
+          DDP_PIN(adv);  // or the FMAs sink below the later batches' loads and all 27 operands stay live
         }
+        adv *= sig;
         const bool hasq = i >= 3;
         const Real rc1 = L.Rc[hasq ? (i - 3) * 3 + (i2 - 3) : 0], tp1 = L.tp[hasq ? i + i2 - 5 : 0];
 #pragma unroll
@@ -1123,11 +1142,10 @@ struct Wave {
           Acc v = zvz + quu + sig * ada;
           v = dd ? v + adv : v;
           // Hxx | Hxu | Huu are consecutive members: element offsets from Hxx[0] (81, 171), integer selects
+          // [Hxu; Huu] is one 19x10 block behind Hxx: entry (p, q >= 9) sits at 81 + 10 p + (q - 9)
           Acc* Hb = L.Hxx;
-          const int oxx = p * 9 + q, oxu = 81 + p * 10 + (q - 9), ouu = 171 + (p - 9) * 10 + (q - 9);
-          const int txx = q * 9 + p, tuu = 171 + (q - 9) * 10 + (p - 9);
-          const int o1 = q < 9 ? oxx : (p < 9 ? oxu : ouu);
-          const int o2 = q < 9 ? txx : (p < 9 ? oxu : tuu);
+          const int o1 = q < 9 ? p * 9 + q : p * 10 + q + 72;
+          const int o2 = q < 9 ? q * 9 + p : (p < 9 ? o1 : q * 10 + p + 72);
           if (p <= q) {  // i == i2: the lower triangle of the diagonal block belongs to the lane of the other axis
             Hb[o1] = v;
             Hb[o2] = v;
@@ -1292,8 +1310,8 @@ struct Wave {
       DDP_MARK("B_R2");
       // ---- R2: slack / dual gains per row; V recursion; gains to HBM
       LANES {
-        St* ksg = Sp_(B.KS, k);
-        St* kyg = Sp_(B.KY, k);
+        St* ksg = SpU(B.KS, k);
+        St* kyg = SpU(B.KY, k);
         for (int i = 0; i < RPL; i++) {
           const RowK<Real> rk = row_slot(i, lane, P);
           const int r = rk.r;
@@ -1312,10 +1330,10 @@ struct Wave {
             if (r >= 0) ksg[r] = ks;
           }
         }
-        KUp(k)[lane] = (St)L.KU[lane];
+        KUpU(k)[lane] = (St)L.KU[lane];
         {
           const int e2 = lane + 64 < 100 ? lane + 64 : 99;
-          KUp(k)[e2] = (St)L.KU[e2];
+          KUpU(k)[e2] = (St)L.KU[e2];
         }
         // Value-function recursion (DDP:626-628).  With [y | Y] = L^-1 [Hu | Hux], LL' = Huu + lam I and
         // [ku | Ku] = -(Huu + lam I)^-1 [Hu | Hux] the reference's
@@ -1365,10 +1383,9 @@ struct Wave {
       WSYNC();
     }
     DDP_MARK("B_END");
-    double mu_err = WAVE_MAX_D(e_mu);
-    double c_err = infeas ? WAVE_MAX_D(e_c) : 0.0;
+    const double mu_err = WAVE_MAX_D(e_mu);
     st.bp_failed = 0;
-    st.opterr = fmax(fmax((double)qu_err, c_err), mu_err);  // DDP:641
+    st.opterr = fmax((double)qu_err, mu_err);  // DDP:641
     return 1;
   }
 
@@ -1397,14 +1414,14 @@ struct Wave {
       PLV(int, nviol);
       LANES {
         LV(plog).init(); LV(serr) = 0; LV(nviol) = 0;
-        if (lane < 9) L.xn[lane] = ldx(Xp(cur, 0), lane);
+        if (lane < 9) L.xn[lane] = ldx(XpU(cur, 0), lane);
       }
       WSYNC();
       double qsum = 0.0;
       int failed = 0;
       neg = 0;
-      int Pn = DDP_UNIFORM_I(np_(0));
-      int Pnn = np_(N > 1 ? 1 : 0);
+      int Pn = DDP_UNIFORM_I(npU(0));
+      int Pnn = npU(N > 1 ? 1 : 0);
       PLV(Pre, pre);
       LANES { prefetch(LV(pre), lane, cur, 0, Pn, true, infeas); }
 #pragma unroll 1
@@ -1431,7 +1448,7 @@ struct Wave {
         const Real To = (Real)RDLANE_M(pre, zh, 18);
         if (k + 1 < N) {
           Pn = DDP_UNIFORM_I(Pnn);
-          Pnn = np_(k + 2 < N ? k + 2 : k + 1);
+          Pnn = npU(k + 2 < N ? k + 2 : k + 1);
           LANES { prefetch(LV(pre), lane, cur, k + 1, Pn, true, infeas); }
         }
         WSYNC();
@@ -1539,8 +1556,8 @@ struct Wave {
         PLV(int, bad);
         LANES {
           LV(bad) = 0;
-          St* sn = Sp_(B.S[nxt], k);
-          St* yn = Sp_(B.Y[nxt], k);
+          St* sn = SpU(B.S[nxt], k);
+          St* yn = SpU(B.Y[nxt], k);
           for (int i = 0; i < RPL; i++) {
             // branch-free rows: empty slots alias row 0, their stores / reductions are masked
             const RowK<Real> rk = row_slot(i, lane, P);
@@ -1571,7 +1588,7 @@ struct Wave {
             LV(nviol) += (in && cn >= (Real)2.0e-4) ? 1 : 0;
           }
           LV(plog).norm();
-          if (lane < 19) stx(Xp(nxt, k), lane, L.zn[lane]);
+          if (lane < 19) stx(XpU(nxt, k), lane, L.zn[lane]);
           if (lane < 9) L.xn[lane] = L.xnx[lane];
         }
         failed = WAVE_ANY(bad);
@@ -1582,7 +1599,7 @@ struct Wave {
       if (failed) continue;
       LANES {
         if (lane < 9) {
-          stx(Xp(nxt, N), lane, L.xn[lane]);
+          stx(XpU(nxt, N), lane, L.xn[lane]);
           L.z[lane] = L.xn[lane] - B.xd[(size_t)b * 9 + lane];
         }
       }
