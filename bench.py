@@ -30,25 +30,48 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 FIXED_ITERS = 20
 
 
+def usable_cpus():
+    """Host threads this process may actually run on: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(batch1, params, sample):
     """The oracle ("port": Eigen-free restatement of the reference, the original cannot be built
-    here) on a bounded sample of the same workload, OpenMP over all host cores."""
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    here) on a bounded sample of the same workload, OpenMP over the usable host cores.  Two thread
+    counts are tried (all usable threads, and half of them in case they are SMT siblings); the better
+    one is reported with the thread count it used."""
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "threads")
     from oracle import refapi
     refapi.build()
     sub = batch1.select(np.arange(sample))
-    n_threads = os.cpu_count() or 1
-    refapi.solve_batch(params, sub.select(np.arange(min(sample, 2 * n_threads))), n_threads=n_threads)  # warm up threads + arenas
-    t = time.perf_counter()
-    res, _ = refapi.solve_batch(params, sub, n_threads=n_threads)
-    dt = time.perf_counter() - t
+    usable = usable_cpus()
+    refapi.solve_batch(params, sub.select(np.arange(min(sample, 2 * usable))), n_threads=usable)  # warm up threads + arenas
+    best = None
+    for nt in sorted({usable, max(1, usable // 2)}, reverse=True):
+        t = time.perf_counter()
+        res, _ = refapi.solve_batch(params, sub, n_threads=nt)
+        dt = time.perf_counter() - t
+        v = float(res.fwd_passes.sum() / dt)
+        if best is None or v > best[0]:
+            best = (v, nt, dt)
     t1 = time.perf_counter()
     res1, _ = refapi.solve_batch(params, sub.select(np.arange(min(8, sample))), n_threads=1)
     dt1 = time.perf_counter() - t1
-    return {"value": float(res.fwd_passes.sum() / dt), "unit": "iter/s", "cores": int(n_threads), "kind": "port",
+    return {"value": best[0], "unit": "iter/s", "cores": int(best[1]), "kind": "port",
             "sample": "%d of the %d corridors of rank 0's batch, same fixed-%d-iteration phase-1 solve, fp64, "
-                      "OpenMP schedule(dynamic,1); %.1f s wall" % (sample, batch1.batch, FIXED_ITERS, dt),
+                      "OpenMP schedule(dynamic,1), %d threads (host reports %d CPUs, %d usable); %.1f s wall"
+                      % (sample, batch1.batch, FIXED_ITERS, best[1], os.cpu_count() or 1, usable, best[2]),
             "single_thread_value": float(res1.fwd_passes.sum() / dt1)}
 
 
@@ -181,11 +204,11 @@ def main():
                        "storage_dtype": args.dtype},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
-                         "kernel": "k_iterate", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "kernel": "k_iterate_dyn (ticket-scheduled k_iterate)", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "iters_per_step_rank0": iters_step, "best_cost": bc, "best_index": bidx, "gather_ms": gather_ms,
         }
         if not args.no_cpu_baseline and world == 1:
-            sample = args.cpu_sample or max(512, 8 * (os.cpu_count() or 1))
+            sample = args.cpu_sample or max(512, 8 * usable_cpus())
             line["cpu_baseline"] = cpu_baseline(batch1.astype(np.float64), params, min(sample, B))
         print(json.dumps(line))
     s.close()
