@@ -240,7 +240,7 @@ struct TrajState {
   int rtn, iter, done, nfilter;
   int infeas, infeas_ref, line_failed, bp_no_upd;
   int no_upd, fwd_passes, cur, viol;
-  int neg_time, nseg, nc0, pad;
+  int neg_time, nseg, nc0, npos;  // npos: rows with c > 0 in the last evaluation sweep (DDP:255-269)
 };
 
 // ---- device-resident batch (all pointers are device memory) -----------------------------------
@@ -256,6 +256,7 @@ struct Batch {
   const Real* planes;
   const Real* init_bez;
   const Real* init_poly;
+  const Real* seeds;     // [B][nmax][3] Polytope.seed_coord (line-init only)
   const uint8_t* infeas_in;
   Real* X[2];   // [B][nmax+1][kXS]: x_k (9), u_k (10), position low words (3), pad
   Real* S[2];   // [B][nmax][ncs]
@@ -679,7 +680,8 @@ struct Wave {
     PLV(Real, slog);
     PLV(Real, serr);
     PLV(int, nviol);
-    LANES { LV(plog).init(); LV(serr) = 0; LV(nviol) = 0; }
+    PLV(int, npos);
+    LANES { LV(plog).init(); LV(serr) = 0; LV(nviol) = 0; LV(npos) = 0; }
     const int infeas = DDP_UNIFORM_I(st.infeas);
     double qsum = 0.0;
     int neg = 0;
@@ -718,6 +720,7 @@ struct Wave {
               LV(plog).mul(-c);
             }
             if (c >= (Real)2.0e-4) LV(nviol)++;
+            if (c > (Real)0) LV(npos)++;
           }
         }
         LV(plog).norm();
@@ -737,6 +740,7 @@ struct Wave {
     st.sumlog = WAVE_SUM_D(slog);
     st.errsum = WAVE_SUM_D(serr);
     st.viol = WAVE_SUM_I(nviol);
+    st.npos = WAVE_SUM_I(npos);
     st.neg_time = neg;
   }
 
@@ -758,7 +762,67 @@ struct Wave {
     st.fp_failed = 0;
   }
 
-  // ---- setup (DDP:104-286 without line-init) ----------------------------------------------------
+  // ---- line initialisation (DDP:194-248): per segment the quintic that joins the polytope seeds at
+  // rest, its duration doubled (at most 5 times) until every constraint of the segment is negative.
+  DDP_DEV void line_init() {
+    const St* T0 = B.T0 + (size_t)b * B.nmax;
+    for (int l = 0; l < N; l++) {
+      const int P = np_(l);
+      Real pa[3], pn[3];
+      for (int d = 0; d < 3; d++) {
+        pa[d] = (l == 0) ? (Real)B.x0[(size_t)b * 9 + d] : (Real)B.seeds[((size_t)b * B.nmax + l) * 3 + d];
+        pn[d] = (l == N - 1) ? (Real)B.xd[(size_t)b * 9 + d] : (Real)B.seeds[((size_t)b * B.nmax + l + 1) * 3 + d];
+      }
+      LANES { for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(l)[e]; }
+      Real Tk = (Real)T0[l];
+      int vio = 1, cnt = 0;
+      while (vio && cnt <= 4) {
+        const Real Tk2 = Tk * Tk, Tk3 = Tk2 * Tk, Tk4 = Tk3 * Tk, Tk5 = Tk4 * Tk;
+        // u = G^-1 (x_next - F x) with x = [pa; 0; 0], x_next = [pn; 0; 0]: only the first column of G^-1 acts
+        const Real g0 = (Real)10.0 / Tk3, g1 = (Real)-15.0 / Tk4, g2 = (Real)6.0 / Tk5;
+        LANES {
+          if (lane < 19) {
+            const int a = lane / 3, d = lane % 3;
+            Real v = 0;
+            if (lane < 3) v = pa[d];
+            else if (lane >= 9 && lane < 18) v = (a == 3 ? g0 : (a == 4 ? g1 : g2)) * (pn[d] - pa[d]);
+            else if (lane == 18) v = Tk;
+            L.z[lane] = v;
+          }
+          if (lane < 8) L.tp[lane] = powi(Tk, lane);
+        }
+        WSYNC();
+        LANES {
+          if (lane < 45) L.val[lane] = ctrl_val(L.z, L.tp, lane / 3, lane % 3);
+          else if (lane == 63) L.val[45] = Tk;
+        }
+        WSYNC();
+        PLV(int, bad);
+        LANES {
+          LV(bad) = 0;
+          for (int i = 0; i < RPL; i++) {
+            const RowK<Real> rk = row_slot(i, lane, P);
+            if (rk.r >= 0 && !(row_c(L.val, rk) < (Real)0)) LV(bad) = 1;
+          }
+        }
+        if (WAVE_ANY(bad)) {
+          Tk = (Real)2 * Tk;
+          cnt++;
+        } else {
+          vio = 0;
+        }
+        WSYNC();
+      }
+      // the coefficients of the last trial stay, the duration is the (possibly doubled once more) Tk
+      LANES {
+        if (lane >= 9 && lane < 18) Xp(0, l)[lane] = (St)L.z[lane];
+        if (lane == 18) Xp(0, l)[18] = (St)Tk;
+      }
+      WSYNC();
+    }
+  }
+
+  // ---- setup (DDP:104-286) -----------------------------------------------------------------------
   DDP_DEV void begin() {
     N = B.n_seg[b];
     st.nseg = N;
@@ -790,6 +854,7 @@ struct Wave {
         u[9] = (St)T;
       }
     }
+    if (!B.k.zero_init && B.k.line_init) line_init();
     for (int k = 0; k < N; k++) {  // s = 0.1, y = 0.01 (DDP:150-151)
       const int nc = 6 * np_(k) + 55;
       LANES {
@@ -804,11 +869,15 @@ struct Wave {
     }
     WSYNC();
     eval_sweep(0, true);
+    if (B.k.line_init && st.npos == 0 && st.infeas) {  // DDP:255-269: the straight lines are already feasible
+      st.infeas = 0;
+      eval_sweep(0, false);  // the barrier sums of the feasible mode (the roll itself is unchanged)
+    }
     st.prev_cost = st.cost;
     st.nc0 = 6 * np_(0) + 55;
     st.mu = st.cost / (double)N / (double)st.nc0;  // DDP:281 (quirk Q6)
     reset_filter();
-    st.reg = 0;
+    st.reg = B.k.line_init ? 10 : 0;  // DDP:283-286
     st.bp_failed = 0;
     st.opterr = 0.0;
     st.stepsize = 0.0;

@@ -219,6 +219,7 @@ struct direct_ddp_handle_s {
   // device buffers
   void *x0 = nullptr, *xd = nullptr, *T0 = nullptr, *planes = nullptr, *init_bez = nullptr, *T_next = nullptr;
   void* init_poly = nullptr;
+  void* seeds = nullptr;
   int32_t *n_seg = nullptr, *n_planes = nullptr;
   uint8_t *infeas_in = nullptr, *infeas_next = nullptr;
   void *X[2] = {nullptr, nullptr}, *S[2] = {nullptr, nullptr}, *Y[2] = {nullptr, nullptr};
@@ -270,6 +271,7 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   B.n_seg = in.n_seg; B.x0 = (const Real*)in.x0; B.xd = (const Real*)in.xd; B.T0 = (const Real*)in.T0;
   B.n_planes = in.n_planes; B.planes = (const Real*)in.planes; B.init_bez = (const Real*)in.init_bez;
   B.init_poly = (const Real*)in.init_poly;
+  B.seeds = (const Real*)in.seeds;
   B.infeas_in = in.infeas_in;
   for (int i = 0; i < 2; i++) {
     B.X[i] = (Real*)h->X[i]; B.S[i] = (Real*)h->S[i]; B.Y[i] = (Real*)h->Y[i];
@@ -386,6 +388,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   auto A = [&](auto pp, size_t bytes) { if (st == DIRECT_OK) st = dalloc(h, pp, bytes); };
   A(&h->x0, B * 9 * r); A(&h->xd, B * 9 * r); A(&h->T0, B * nm * r); A(&h->T_next, B * nm * r);
   A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r); A(&h->init_poly, B * nm * 18 * r);
+  A(&h->seeds, B * nm * 3 * r);
   A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B); A(&h->infeas_next, B);
   for (int i = 0; i < 2; i++) {
     A(&h->X[i], B * (nm + 1) * kXS * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
@@ -440,7 +443,6 @@ static direct_status_t check_params(const direct_ddp_params_t* p) {
   if (p->time_power != 1 && p->time_power != 2)
     return fail(DIRECT_ERR_INVALID, "time_power must be 1 or 2 (computeq has no other branch, ddp_optimizer.cpp:1294-1305)");
   if (p->iter_max < 0) return fail(DIRECT_ERR_INVALID, "iter_max < 0");
-  if (p->line_init) return fail(DIRECT_ERR_UNSUPPORTED, "line_init_flag is not implemented on the device path yet");
   return DIRECT_OK;
 }
 
@@ -453,7 +455,9 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
     return fail(DIRECT_ERR_INVALID, "n_seg_max / p_max differ from the handle's configuration");
   if (!in->n_seg || !in->x0 || !in->xd || !in->T0 || !in->n_planes || !in->planes)
     return fail(DIRECT_ERR_INVALID, "null input array");
-  if (!p->zero_init && !in->init_bez && !in->init_poly)
+  if (p->line_init && !p->zero_init && !in->seeds)
+    return fail(DIRECT_ERR_INVALID, "line_init needs the polytope seeds (direct_ddp_batch_in_t.seeds)");
+  if (!p->zero_init && !p->line_init && !in->init_bez && !in->init_poly)
     return fail(DIRECT_ERR_INVALID, "init_bez (or init_poly) required unless zero_init");
   HIP_TRY(hipSetDevice(h->device));
   const size_t B = in->batch, nm = h->nmax, r = h->rsz;
@@ -476,6 +480,7 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
     HIP_TRY(up(h->planes, in->planes, B * nm * h->pmax * 4 * r)); d.planes = h->planes;
     if (in->init_bez) { HIP_TRY(up(h->init_bez, in->init_bez, B * nm * 18 * r)); d.init_bez = h->init_bez; }
     if (in->init_poly) { HIP_TRY(up(h->init_poly, in->init_poly, B * nm * 18 * r)); d.init_poly = h->init_poly; }
+    if (in->seeds) { HIP_TRY(up(h->seeds, in->seeds, B * nm * 3 * r)); d.seeds = h->seeds; }
     if (in->infeas_in) { HIP_TRY(up(h->infeas_in, in->infeas_in, B)); d.infeas_in = h->infeas_in; }
   }
   if (!in->infeas_in) {

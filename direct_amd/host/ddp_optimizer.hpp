@@ -128,7 +128,7 @@ class ddpTrajOptimizer {
         seeds[((size_t)b * nm + k) * 3 + 0] = pl.seed_coord.x;
         seeds[((size_t)b * nm + k) * 3 + 1] = pl.seed_coord.y;
         seeds[((size_t)b * nm + k) * 3 + 2] = pl.seed_coord.z;
-        if (!zero_init_flag)
+        if (!zero_init_flag && !line_init_flag)  // line-init builds its own start from the seeds (DDP:194-248)
           for (int q = 0; q < 18; q++) bez[((size_t)b * nm + k) * 18 + q] = initbezCoeff[b](k, q);
       }
     }

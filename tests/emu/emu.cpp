@@ -17,7 +17,7 @@ template <typename Real>   // Real = storage type here; the compute type is chos
 struct Emu {
   Batch<Real> B;
   int compute64 = 0;
-  std::vector<Real> x0, xd, T0, planes, init_bez, init_poly, X0, X1, S0, S1, Y0, Y1, KU, KS, KY;
+  std::vector<Real> x0, xd, T0, planes, init_bez, init_poly, seeds, X0, X1, S0, S1, Y0, Y1, KU, KS, KY;
   std::vector<int32_t> n_seg, n_planes;
   std::vector<uint8_t> infeas_in;
   std::vector<double> filt;
@@ -67,6 +67,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   cp(E->planes, in->planes, (size_t)B * nm * pm * 4);
   if (in->init_bez) cp(E->init_bez, in->init_bez, (size_t)B * nm * 18);
   if (in->init_poly) cp(E->init_poly, in->init_poly, (size_t)B * nm * 18);
+  if (in->seeds) cp(E->seeds, in->seeds, (size_t)B * nm * 3);
   E->infeas_in.assign(B, (uint8_t)p->infeas);
   if (in->infeas_in) E->infeas_in.assign(in->infeas_in, in->infeas_in + B);
   size_t nx = (size_t)B * (nm + 1) * kXS, ns = (size_t)B * nm * ncm;
@@ -79,6 +80,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   Bt.n_planes = E->n_planes.data(); Bt.planes = E->planes.data();
   Bt.init_bez = in->init_bez ? E->init_bez.data() : nullptr;
   Bt.init_poly = in->init_poly ? E->init_poly.data() : nullptr;
+  Bt.seeds = in->seeds ? E->seeds.data() : nullptr;
   Bt.infeas_in = E->infeas_in.data();
   Bt.X[0] = E->X0.data(); Bt.X[1] = E->X1.data(); Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data();
   Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();

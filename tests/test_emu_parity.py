@@ -104,3 +104,29 @@ def test_fixed_iteration_mode_and_resume():
     assert np.array_equal(ra.bez, rb.bez) and np.array_equal(ra.cost, rb.cost)
     r, _ = refapi.solve_batch(p, b1)
     assert np.abs(ra.cost / r.cost - 1).max() < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["free", "corridor"])
+def test_line_initialisation_matches_oracle(kind):
+    """line_init_flag = true (DDP:194-248, 255-269, 283-286, 398-409): straight quintics between the
+    polytope seeds with duration doubling, reg = 10, the line-init exit rules."""
+    batch = problems.make_batch(kind, 3, 6, seed=33)
+    # make some first durations too short so that the doubling loop has to act
+    batch.T0[1] *= 0.35
+    batch.T0[2] *= 0.1
+    p = abi.phase1_params(line_init=1, infeas=1, iter_max=40)
+    e = emuapi.EmuSolver(p, batch)
+    r = [refapi.Stepper(p, batch, i) for i in range(3)]
+    for i in range(3):
+        assert helpers.rel(e.get(abi.FIELD_U)[i], r[i].get(abi.FIELD_U)) < 1e-12
+        assert helpers.rel(e.get(abi.FIELD_X)[i], r[i].get(abi.FIELD_X)) < 1e-12
+        se, sr = e.scalars(), r[i].scalars()
+        assert int(se["infeas"][i]) == int(sr["infeas"]) and int(se["reg"][i]) == int(sr["reg"]) == 10
+        assert abs(se["cost"][i] / sr["cost"] - 1) < 1e-11 and abs(se["mu"][i] / sr["mu"] - 1) < 1e-11
+    assert not np.allclose(e.get(abi.FIELD_U)[2][:, 9], batch.T0[2])  # durations were doubled
+    g = emuapi.solve_batch(p, batch)
+    o, _ = refapi.solve_batch(p, batch)
+    assert (g.rtn == o.rtn).all() and (g.iter_used == o.iter_used).all()
+    assert (g.line_failed_out == o.line_failed_out).all() and (g.infeas_out == o.infeas_out).all()
+    assert np.abs(g.cost / o.cost - 1).max() < 1e-8
+    assert helpers.rel(g.T, o.T) < 1e-8

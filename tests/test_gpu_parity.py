@@ -139,9 +139,10 @@ def test_error_paths(built):
     with pytest.raises(solver.DirectError) as e:
         s.solve(abi.phase0_params(time_power=3), batch)
     assert e.value.status == abi.DIRECT_ERR_INVALID
+    noseeds = abi.HostBatch(batch.n_seg, batch.x0, batch.xd, batch.T0, batch.n_planes, batch.planes, dtype=np.float32)
     with pytest.raises(solver.DirectError) as e:
-        s.solve(abi.phase0_params(line_init=1), batch)
-    assert e.value.status == abi.DIRECT_ERR_UNSUPPORTED
+        s.solve(abi.phase1_params(line_init=1), noseeds)   # line-init needs the polytope seeds
+    assert e.value.status == abi.DIRECT_ERR_INVALID
     with pytest.raises(solver.DirectError) as e:
         s.solve(abi.phase1_params(), batch)          # warm start without init_bez / init_poly
     assert e.value.status == abi.DIRECT_ERR_INVALID
@@ -178,3 +179,27 @@ def test_cpp_host_shim_two_phase_plan(built, tmp_path):
                            "-Wl,-rpath," + os.path.join(root, "direct_amd/lib") + ":" + os.path.join(root, "oracle") + ":/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("kind", ["free", "corridor"])
+def test_line_initialisation_matches_oracle(built, kind):
+    """line_init_flag = true (DDP:194-248, 255-269, 283-286, 398-409) through the C-ABI, fp64."""
+    batch = problems.make_batch(kind, 6, 7, seed=33)
+    batch.T0[1] *= 0.35
+    batch.T0[2] *= 0.1
+    p = abi.phase1_params(line_init=1, infeas=1, iter_max=40)
+    s = make_solver(batch, np.float64)
+    s.begin(p, batch)
+    for i in range(batch.batch):
+        r = refapi.Stepper(p, batch, i)
+        assert helpers.rel(s.get(abi.FIELD_U)[i], r.get(abi.FIELD_U)) < 1e-12
+        assert helpers.rel(s.get(abi.FIELD_X)[i], r.get(abi.FIELD_X)) < 1e-12
+        sc, sr = s.scalars(), r.scalars()
+        assert int(sc["infeas"][i]) == int(sr["infeas"]) and int(sc["reg"][i]) == 10
+        assert abs(sc["cost"][i] / sr["cost"] - 1) < 1e-11
+    g = s.solve(p, batch)
+    o, _ = refapi.solve_batch(p, batch)
+    assert (g.rtn == o.rtn).all() and (g.iter_used == o.iter_used).all()
+    assert (g.line_failed_out == o.line_failed_out).all() and (g.infeas_out == o.infeas_out).all()
+    assert np.abs(g.cost / o.cost - 1).max() < 1e-8
+    s.close()
