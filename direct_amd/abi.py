@@ -66,6 +66,21 @@ class BatchOut(C.Structure):
     ]
 
 
+class SampleIn(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("n_seg_max", C.c_int32), ("capacity", C.c_int32), ("derivs", C.c_int32),
+        ("mem", C.c_int32),
+        ("n_seg", C.c_void_p), ("bez", C.c_void_p), ("T", C.c_void_p), ("dt", C.c_double),
+    ]
+
+
+class SampleOut(C.Structure):
+    _fields_ = [
+        ("count", C.c_void_p), ("seg_first", C.c_void_p), ("pos", C.c_void_p), ("vel", C.c_void_p),
+        ("acc", C.c_void_p), ("length", C.c_void_p), ("vmax", C.c_void_p), ("amax", C.c_void_p),
+    ]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32),

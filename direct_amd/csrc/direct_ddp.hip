@@ -14,6 +14,7 @@
 
 #include "../../include/direct_ddp.h"
 #include "ddp_wave.h"
+#include "traj_sample.h"
 
 using namespace direct;
 
@@ -213,7 +214,8 @@ struct direct_ddp_handle_s {
   int dtype = 0, device = 0, max_batch = 0, nmax = 0, pmax = 0, ncs = 0, rpl = 2, fcap = 0;
   size_t rsz = 4;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  bool sample_timed = false;
   int n_launches = 0;
   bool timed = false;
   // device buffers
@@ -356,6 +358,74 @@ static void launch_finish_t(direct_ddp_handle_t h, const direct_ddp_batch_out_t*
   RPL_LAUNCH(h, k_finish, Real, h->B, Bt, O);
 }
 
+// direct_traj_sample_batch for one storage type: host arrays are staged through temporary device buffers
+template <typename Real>
+static direct_status_t sample_t(direct_ddp_handle_t h, const direct_sample_in_t* in, direct_sample_out_t* out) {
+  const size_t B = in->batch, nm = in->n_seg_max, cap = in->capacity, r = sizeof(Real);
+  const bool host = in->mem == DIRECT_MEM_HOST;
+  SampleArgs<Real> A;
+  A.batch = in->batch; A.nmax = in->n_seg_max; A.capacity = in->capacity; A.derivs = in->derivs; A.dt = in->dt;
+  std::vector<void*> tmp;
+  auto dev = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    tmp.push_back(q);
+    return q;
+  };
+  auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); };
+  auto in_arr = [&](const void* src, size_t bytes) -> const void* {
+    if (!host) return src;
+    void* q = dev(bytes);
+    if (q && hipMemcpyAsync(q, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) return nullptr;
+    return q;
+  };
+  // staged outputs are zero-filled: entries past `count` then read 0 on the host (device-resident
+  // output arrays are left untouched past `count`)
+  auto out_arr = [&](void* dst, size_t bytes) -> void* {
+    if (!host || !dst) return dst;
+    void* q = dev(bytes);
+    if (q && hipMemsetAsync(q, 0, bytes, h->stream) != hipSuccess) return nullptr;
+    return q;
+  };
+  A.n_seg = (const int32_t*)in_arr(in->n_seg, B * 4);
+  A.bez = (const Real*)in_arr(in->bez, B * nm * 18 * r);
+  A.T = (const Real*)in_arr(in->T, B * nm * r);
+  A.count = (int32_t*)out_arr(out->count, B * 4);
+  A.seg_first = (int32_t*)out_arr(out->seg_first, B * nm * 4);
+  A.pos = (Real*)out_arr(out->pos, B * cap * 3 * r);
+  A.vel = (Real*)out_arr(out->vel, B * cap * 3 * r);
+  A.acc = (Real*)out_arr(out->acc, B * cap * 3 * r);
+  A.length = (Real*)out_arr(out->length, B * r);
+  A.vmax = (Real*)out_arr(out->vmax, B * r);
+  A.amax = (Real*)out_arr(out->amax, B * r);
+  if (!A.n_seg || !A.bez || !A.T || !A.count || !A.pos || (out->vel && !A.vel) || (out->acc && !A.acc)) {
+    cleanup();
+    return fail(DIRECT_ERR_DEVICE, "staging buffers for direct_traj_sample_batch");
+  }
+  (void)hipEventRecord(h->ev2, h->stream);
+  hipLaunchKernelGGL(k_sample<Real>, dim3(in->batch), dim3(64), 0, h->stream, A);
+  (void)hipEventRecord(h->ev3, h->stream);
+  h->sample_timed = true;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && host) {
+    auto dn = [&](void* dst, const void* src, size_t bytes) {
+      return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+    };
+    if (e == hipSuccess) e = dn(out->count, A.count, B * 4);
+    if (e == hipSuccess) e = dn(out->seg_first, A.seg_first, B * nm * 4);
+    if (e == hipSuccess) e = dn(out->pos, A.pos, B * cap * 3 * r);
+    if (e == hipSuccess) e = dn(out->vel, A.vel, B * cap * 3 * r);
+    if (e == hipSuccess) e = dn(out->acc, A.acc, B * cap * 3 * r);
+    if (e == hipSuccess) e = dn(out->length, A.length, B * r);
+    if (e == hipSuccess) e = dn(out->vmax, A.vmax, B * r);
+    if (e == hipSuccess) e = dn(out->amax, A.amax, B * r);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
+  if (host) { (void)hipStreamSynchronize(h->stream); cleanup(); }
+  if (e != hipSuccess) return fail(DIRECT_ERR_DEVICE, std::string("direct_traj_sample_batch: ") + hipGetErrorString(e));
+  return DIRECT_OK;
+}
+
 extern "C" {
 
 int32_t direct_ddp_abi_version(void) { return DIRECT_DDP_ABI_VERSION; }
@@ -408,7 +478,8 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
                                             : resident_slots<float>(h, prop.multiProcessorCount);
   h->fieldbuf_bytes = B * nm * (size_t)std::max(ncm, 100) * r + B * 16 * r + B * 9 * r;
   A(&h->fieldbuf, h->fieldbuf_bytes);
-  if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
+  if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+                          hipEventCreate(&h->ev2) != hipSuccess || hipEventCreate(&h->ev3) != hipSuccess))
     st = fail(DIRECT_ERR_DEVICE, "hipEventCreate failed");
   if (st == DIRECT_OK && hipMemset(h->sched, 0, (B + 2) * sizeof(int)) != hipSuccess)
     st = fail(DIRECT_ERR_DEVICE, "hipMemset failed");
@@ -428,6 +499,8 @@ direct_status_t direct_ddp_destroy(direct_ddp_handle_t h) {
   if (h->filt) (void)hipFree(h->filt);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->ev3) (void)hipEventDestroy(h->ev3);
   delete h;
   return DIRECT_OK;
 }
@@ -750,6 +823,25 @@ direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const i
       T_out[(size_t)b * n_seg_max + k] = t;
     }
   }
+  return DIRECT_OK;
+}
+
+direct_status_t direct_traj_sample_batch(direct_ddp_handle_t h, const direct_sample_in_t* in, direct_sample_out_t* out) {
+  if (!h || !in || !out) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (in->batch <= 0 || in->n_seg_max <= 0 || in->capacity <= 0 || in->derivs < 0 || in->derivs > 2)
+    return fail(DIRECT_ERR_INVALID, "bad sizes");
+  if (!(in->dt > 0.0)) return fail(DIRECT_ERR_INVALID, "dt must be positive");
+  if (!in->n_seg || !in->bez || !in->T || !out->count || !out->pos) return fail(DIRECT_ERR_INVALID, "null array");
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->dtype == DIRECT_F64) return sample_t<double>(h, in, out);
+  return sample_t<float>(h, in, out);
+}
+
+direct_status_t direct_traj_sample_last_ms(direct_ddp_handle_t h, float* ms) {
+  if (!h || !ms) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->sample_timed) return fail(DIRECT_ERR_INVALID, "no sampling launch to time");
+  HIP_TRY(hipEventSynchronize(h->ev3));
+  HIP_TRY(hipEventElapsedTime(ms, h->ev2, h->ev3));
   return DIRECT_OK;
 }
 

@@ -23,7 +23,7 @@ EXPORTS = (
     "direct_ddp_set_stream", "direct_ddp_solve_batch", "direct_ddp_plan_batch", "direct_time_allocation",
     "direct_ddp_begin", "direct_ddp_backward_pass", "direct_ddp_forward_pass", "direct_ddp_iterate",
     "direct_ddp_finish", "direct_ddp_get_field", "direct_ddp_set_field", "direct_ddp_last_kernel_ms",
-    "direct_ddp_best_cost",
+    "direct_ddp_best_cost", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
 )
 
 
@@ -59,6 +59,8 @@ def lib():
         L.direct_ddp_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.direct_ddp_best_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p]
+        L.direct_traj_sample_batch.argtypes = [C.c_void_p] * 3
+        L.direct_traj_sample_last_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.direct_time_allocation.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         _LIB = L
@@ -190,6 +192,39 @@ class DdpSolver:
     def plan_device(self, params0, params1, cin, cout0, cout1):
         _check(lib().direct_ddp_plan_batch(self.h, C.addressof(params0), C.addressof(params1), C.addressof(cin),
                                            None if cout0 is None else C.addressof(cout0), C.addressof(cout1)))
+
+    def sample(self, n_seg, bez, T, dt, capacity, derivs=2):
+        """Batched output sampling (direct_traj_sample_batch; teach_repeat_planner.cpp:1551-1566 over
+        utils/bezier_base.h:77-127).  Host numpy arrays in, dict of numpy arrays out."""
+        n_seg = np.ascontiguousarray(n_seg, np.int32)
+        bez = np.ascontiguousarray(bez, self.np_dtype)
+        T = np.ascontiguousarray(T, self.np_dtype)
+        B, nm = T.shape
+        assert bez.shape == (B, nm, 18)
+        o = dict(count=np.zeros(B, np.int32), seg_first=np.zeros((B, nm), np.int32),
+                 pos=np.zeros((B, capacity, 3), self.np_dtype), length=np.zeros(B, self.np_dtype))
+        if derivs >= 1:
+            o["vel"] = np.zeros((B, capacity, 3), self.np_dtype)
+            o["vmax"] = np.zeros(B, self.np_dtype)
+        if derivs >= 2:
+            o["acc"] = np.zeros((B, capacity, 3), self.np_dtype)
+            o["amax"] = np.zeros(B, self.np_dtype)
+        cin, cout = abi.SampleIn(), abi.SampleOut()
+        cin.batch, cin.n_seg_max, cin.capacity, cin.derivs, cin.mem = B, nm, capacity, derivs, abi.MEM_HOST
+        cin.n_seg, cin.bez, cin.T, cin.dt = n_seg.ctypes.data, bez.ctypes.data, T.ctypes.data, float(dt)
+        for k, v in o.items():
+            setattr(cout, k, v.ctypes.data)
+        _check(lib().direct_traj_sample_batch(self.h, C.addressof(cin), C.addressof(cout)))
+        return o
+
+    def sample_device(self, cin, cout):
+        """direct_traj_sample_batch with caller-built structs (device-resident arrays)."""
+        _check(lib().direct_traj_sample_batch(self.h, C.addressof(cin), C.addressof(cout)))
+
+    def sample_last_ms(self):
+        ms = C.c_float()
+        _check(lib().direct_traj_sample_last_ms(self.h, C.addressof(ms)))
+        return ms.value
 
     def best_cost(self, cost, rtn, mem=abi.MEM_HOST, batch=None):
         """(index, cost) of the cheapest trajectory with rtn >= 0.  cost/rtn: numpy arrays or raw pointers."""

@@ -164,6 +164,43 @@ direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const i
                                        const double* seeds, double max_vel, double max_acc,
                                        double* T_out);
 
+/* ---- output sampling (the step right after the path) ----------------------------------
+ * Batched form of the sampling loops of the caller's visualisation / audit helpers
+ * (teach_repeat_planner.cpp:1380-1394, 1440-1455, 1493-1508, 1551-1566) over
+ * Bernstein::getPosFromBezier / getVel / getAcc (utils/bezier_base.h:77-127):
+ *   for every segment i:  for (double t = 0.0; t < 1.0; t += dt / T_i)
+ *     pos = T_i * getPosFromBezier(bez, t, i);  vel = getVel(bez, i, t);  acc = getAcc(bez, i, t) / T_i
+ *     traj_len += |pos - previous pos|
+ * The sample times reproduce the reference's accumulation of t exactly, so count is the reference's.
+ * Real = the handle's dtype; arithmetic is double.  All arrays of `in` and `out` live where `mem` says. */
+typedef struct {
+  int32_t batch, n_seg_max;
+  int32_t capacity;          /* points per trajectory the output arrays hold */
+  int32_t derivs;            /* 0: positions; 1: + velocities; 2: + accelerations */
+  int32_t mem;               /* direct_mem_t */
+  const int32_t* n_seg;      /* [batch] */
+  const void* bez;           /* [batch][n_seg_max][18] getBezCoeff() layout (time-scaled control points) */
+  const void* T;             /* [batch][n_seg_max] getPolyTime() */
+  double dt;                 /* sample period [s] (> 0): 0.1 and 0.2 in the reference's helpers */
+} direct_sample_in_t;
+
+typedef struct {
+  int32_t* count;            /* [batch] points the loop produces (only the first `capacity` are stored);
+                                -1 when a duration is negative (the reference returns, TRP:1552-1555) */
+  int32_t* seg_first;        /* [batch][n_seg_max] index of each segment's first point, or NULL */
+  void* pos;                 /* [batch][capacity][3] */
+  void* vel;                 /* [batch][capacity][3] or NULL */
+  void* acc;                 /* [batch][capacity][3] or NULL */
+  void* length;              /* [batch] traj_len, or NULL */
+  void* vmax;                /* [batch] max over samples and axes of |vel| (derivs >= 1), or NULL */
+  void* amax;                /* [batch] max over samples and axes of |acc| (derivs >= 2), or NULL */
+} direct_sample_out_t;
+
+direct_status_t direct_traj_sample_batch(direct_ddp_handle_t h, const direct_sample_in_t* in,
+                                         direct_sample_out_t* out);
+/* HIP-event time of the last direct_traj_sample_batch kernel on the handle's stream [ms] */
+direct_status_t direct_traj_sample_last_ms(direct_ddp_handle_t h, float* ms);
+
 /* ---- stepwise interface (per-pass parity tests and profiling) ------------------------ */
 /* begin: setup + initialroll + mu/filter/reg reset (ddp_optimizer.cpp:42-286). */
 direct_status_t direct_ddp_begin(direct_ddp_handle_t h, const direct_ddp_params_t* params,

@@ -1547,3 +1547,68 @@ int direct_ref_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ---- output sampling (test infrastructure, like everything in this file) -----------------------
+ * Literal restatement of the caller's sampling loop (teach_repeat_planner.cpp:1551-1566; the same loop
+ * with dt = 0.1 at :1380-1394, :1440-1455, :1493-1508) over Bernstein::getPosFromBezier, getVel and
+ * getAcc (global_planner/include/global_planner/utils/bezier_base.h:77-127): pow() per term, the
+ * reference's order of the products, sequential traj_len.  acc is divided by T_i to give SI units (the
+ * reference's getAcc leaves that to its caller).  Returns the number of points the loop produces, -1
+ * when a duration is negative (TRP:1552-1555).  Arrays may be NULL except pos. */
+static double bern_C(int n, int k) {
+  static const double t5[6] = {1, 5, 10, 10, 5, 1}, t4[5] = {1, 4, 6, 4, 1}, t3[4] = {1, 3, 3, 1};
+  return n == 5 ? t5[k] : (n == 4 ? t4[k] : t3[k]);
+}
+int direct_ref_sample(int n_seg, const double* bez, const double* T, double dt, int capacity, int derivs,
+                      int* seg_first, double* pos, double* vel, double* acc, double* length, double* vmax,
+                      double* amax) {
+  const int order = 5, n1 = 6;
+  int count = 0;
+  double traj_len = 0.0, pre[3] = {0, 0, 0}, vm = 0.0, am = 0.0;
+  for (int i = 0; i < n_seg; i++)
+    if (T[i] < 0) return -1;
+  for (int i = 0; i < n_seg; i++) {
+    const double* c = bez + (size_t)i * 18;
+    if (seg_first) seg_first[i] = count;
+    for (double t = 0.0; t < 1.0; t += dt / T[i], count += 1) {
+      double cur[3], v[3] = {0, 0, 0}, a[3] = {0, 0, 0};
+      for (int d = 0; d < 3; d++) {
+        double ret = 0.0;
+        for (int j = 0; j < n1; j++) ret += bern_C(5, j) * c[d * n1 + j] * pow(t, j) * pow(1 - t, order - j);
+        cur[d] = T[i] * ret;
+        if (derivs >= 1) {
+          double r = 0.0;
+          for (int j = 0; j < n1 - 1; j++)
+            r += bern_C(4, j) * order * (c[d * n1 + j + 1] - c[d * n1 + j]) * pow(t, j) * pow(1 - t, order - j - 1);
+          v[d] = r;
+          if (fabs(r) > vm) vm = fabs(r);
+        }
+        if (derivs >= 2) {
+          double r = 0.0;
+          for (int j = 0; j < n1 - 2; j++)
+            r += bern_C(3, j) * order * (order - 1) * (c[d * n1 + j + 2] - 2 * c[d * n1 + j + 1] + c[d * n1 + j]) *
+                 pow(t, j) * pow(1 - t, order - j - 2);
+          a[d] = r / T[i];
+          if (fabs(a[d]) > am) am = fabs(a[d]);
+        }
+      }
+      if (count < capacity) {
+        for (int d = 0; d < 3; d++) {
+          pos[(size_t)count * 3 + d] = cur[d];
+          if (vel && derivs >= 1) vel[(size_t)count * 3 + d] = v[d];
+          if (acc && derivs >= 2) acc[(size_t)count * 3 + d] = a[d];
+        }
+      }
+      if (count) {
+        double dx = pre[0] - cur[0], dy = pre[1] - cur[1], dz = pre[2] - cur[2];
+        traj_len += sqrt(dx * dx + dy * dy + dz * dz);
+      }
+      for (int d = 0; d < 3; d++) pre[d] = cur[d];
+      if (!(dt / T[i] > 0)) { count += 1; break; } /* the reference would loop forever; the product takes one sample */
+    }
+  }
+  if (length) *length = traj_len;
+  if (vmax) *vmax = vm;
+  if (amax) *amax = am;
+  return count;
+}

@@ -200,5 +200,25 @@ def time_allocation(n_seg, start, goal, seeds, max_vel=2.0, max_acc=2.0):
     return T
 
 
+def sample_batch(n_seg, bez, T, dt, capacity, derivs=2):
+    """The caller's sampling loop (teach_repeat_planner.cpp:1551-1566) for every trajectory of a batch, fp64."""
+    n_seg = np.ascontiguousarray(n_seg, np.int32)
+    bez = np.ascontiguousarray(bez, np.float64)
+    T = np.ascontiguousarray(T, np.float64)
+    B, nm = T.shape
+    o = dict(count=np.zeros(B, np.int32), seg_first=np.zeros((B, nm), np.int32), pos=np.zeros((B, capacity, 3)),
+             vel=np.zeros((B, capacity, 3)), acc=np.zeros((B, capacity, 3)), length=np.zeros(B), vmax=np.zeros(B),
+             amax=np.zeros(B))
+    f = lib().direct_ref_sample
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 7
+    for b in range(B):
+        o["count"][b] = f(int(n_seg[b]), bez[b].ctypes.data, T[b].ctypes.data, float(dt), capacity, derivs,
+                          o["seg_first"][b].ctypes.data, o["pos"][b].ctypes.data, o["vel"][b].ctypes.data,
+                          o["acc"][b].ctypes.data, o["length"][b:].ctypes.data, o["vmax"][b:].ctypes.data,
+                          o["amax"][b:].ctypes.data)
+    return o
+
+
 def num_threads():
     return lib().direct_ref_num_threads()

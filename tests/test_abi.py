@@ -33,13 +33,14 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_struct_sizes_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(direct_ddp_params_t),sizeof(direct_ddp_batch_in_t),sizeof(direct_ddp_batch_out_t),'
-                   'sizeof(direct_ddp_config_t));return 0;}\n' % HEADER)
+                   'sizeof(direct_ddp_config_t),sizeof(direct_sample_in_t),sizeof(direct_sample_out_t));return 0;}\n' % HEADER)
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [C.sizeof(abi.Params), C.sizeof(abi.BatchIn), C.sizeof(abi.BatchOut), C.sizeof(abi.Config)]
+    assert sizes == [C.sizeof(abi.Params), C.sizeof(abi.BatchIn), C.sizeof(abi.BatchOut), C.sizeof(abi.Config),
+                     C.sizeof(abi.SampleIn), C.sizeof(abi.SampleOut)]
 
 
 def _has_gpu():

@@ -188,3 +188,35 @@ def test_ticket_scheduler_is_bitwise_equal_to_one_workgroup_per_trajectory(built
         for f in ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
             assert np.array_equal(getattr(a, f), getattr(b, f)), f
     assert res["dynamic"][1].iter_used.max() > 1
+
+
+def test_output_sampling_of_the_full_batch(built, free_batch):
+    """direct_traj_sample_batch on 4096 solved trajectories: size-independent properties of the samples
+    (the oracle is checked on a random subset)."""
+    s = solver.DdpSolver(B, N, free_batch.p_max, np.float32)
+    g0, g1 = s.plan(abi.phase0_params(), abi.phase1_params(), free_batch.astype(np.float32))
+    cap, dt = 4096, 0.2
+    d = s.sample(free_batch.n_seg, g1.bez, g1.T, dt, cap)
+    s.close()
+    cnt = d["count"]
+    assert (cnt > N).all() and (cnt <= cap).all()
+    assert np.abs(cnt - g1.T.astype(np.float64).sum(1) / dt).max() <= N + 1      # one partial step per segment
+    # every trajectory starts at its start position and its first sample of segment k+1 continues segment k
+    assert np.abs(d["pos"][:, 0] - free_batch.x0[:, :3]).max() < 1e-3
+    sf = d["seg_first"]
+    assert (np.diff(sf, axis=1) >= 1).all() and (sf[:, 0] == 0).all()
+    # samples are dt apart in time: consecutive points are at most vmax * dt (+ rounding) apart
+    idx = np.arange(cap)[None, :]
+    step = np.linalg.norm(np.diff(d["pos"].astype(np.float64), axis=1), axis=2)
+    valid = idx[:, 1:] < cnt[:, None]
+    assert (step[valid] <= np.sqrt(3.0) * (d["vmax"].astype(np.float64)[:, None] * dt + 1e-2).repeat(cap - 1, 1)[valid]).all()
+    # the polyline is at least as long as the start-goal distance minus the last partial step
+    chord = np.linalg.norm(free_batch.xd[:, :3] - free_batch.x0[:, :3], axis=1)
+    assert (d["length"] > 0.9 * chord).all() and np.allclose(d["length"], np.where(valid, step, 0).sum(1), rtol=1e-4)
+    # converged trajectories respect the velocity / acceleration bounds at the samples
+    ok = g1.rtn >= 0
+    assert (d["vmax"][ok] < 2.0 + 1e-2).all() and (d["amax"][ok] < 2.0 + 1e-2).all()
+    sub = np.random.default_rng(5).choice(B, 24, replace=False)
+    o = refapi.sample_batch(free_batch.n_seg[sub], g1.bez[sub], g1.T[sub], dt, cap)
+    assert (o["count"] == cnt[sub]).all()
+    assert helpers.rel(d["pos"][sub], o["pos"]) < 2e-6 and helpers.rel(d["length"][sub], o["length"]) < 2e-6

@@ -203,3 +203,33 @@ def test_line_initialisation_matches_oracle(built, kind):
     assert (g.line_failed_out == o.line_failed_out).all() and (g.infeas_out == o.infeas_out).all()
     assert np.abs(g.cost / o.cost - 1).max() < 1e-8
     s.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_output_sampling_matches_oracle(built, dtype):
+    """direct_traj_sample_batch (k_sample) against the oracle's literal sampling loop and the golden vectors."""
+    import os
+    for case in ("corridor_n8", "free_n5", "config1_n50"):
+        g = np.load(os.path.join(helpers.GOLDEN_DIR, "sample_" + case + ".npz"))
+        B, nm = g["T"].shape
+        s = solver.DdpSolver(B, nm, 6, dtype)
+        bez, T = g["bez"].astype(dtype), g["T"].astype(dtype)
+        d = s.sample(g["n_seg"], bez, T, float(g["dt"]), int(g["capacity"]))
+        o = refapi.sample_batch(g["n_seg"], bez, T, float(g["dt"]), int(g["capacity"]))   # same (rounded) inputs
+        tol = 1e-12 if dtype == np.float64 else 2e-6                                      # float: output rounding
+        assert (d["count"] == o["count"]).all() and (d["seg_first"] == o["seg_first"]).all()
+        for k in ("pos", "vel", "acc", "length", "vmax", "amax"):
+            assert helpers.rel(d[k], o[k]) < tol, (case, k)
+        if dtype == np.float64:
+            assert (d["count"] == g["count"]).all()
+            assert helpers.rel(d["pos"], g["pos"]) < 1e-12 and helpers.rel(d["length"], g["length"]) < 1e-12
+        # more than 64 samples in one segment (chunking), capacity clamp, negative duration
+        T2 = T.copy()
+        T2[0, 0] = 9.0
+        d2 = s.sample(g["n_seg"], bez, T2, 0.05, 100)
+        o2 = refapi.sample_batch(g["n_seg"], bez, T2, 0.05, 100)
+        assert (d2["count"] == o2["count"]).all() and d2["count"][0] > 180
+        assert helpers.rel(d2["pos"], o2["pos"]) < tol and helpers.rel(d2["length"], o2["length"]) < tol
+        T2[0, 1] = -1.0
+        assert s.sample(g["n_seg"], bez, T2, 0.05, 100)["count"][0] == -1
+        s.close()
