@@ -1867,6 +1867,16 @@ DDP_DEV void finish_wave(Wave<Real, St, RPL>& W, const OutPtrs<St>& O) {
       }
     }
   }
+  LANES {  // rows past the trajectory's last segment read zero (ragged batches)
+    for (int k = N + lane; k < B.nmax; k += 64) {
+      const size_t row = ((size_t)b * B.nmax + k) * 18;
+      if (O.T) O.T[(size_t)b * B.nmax + k] = (St)0;
+      for (int a = 0; a < 18; a++) {
+        if (O.poly) O.poly[row + a] = (St)0;
+        if (O.bez) O.bez[row + a] = (St)0;
+      }
+    }
+  }
   double jsum = WAVE_SUM_D(jc);
   PLV(Real, tn);
   LANES {

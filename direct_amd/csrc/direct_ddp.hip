@@ -15,6 +15,7 @@
 #include "../../include/direct_ddp.h"
 #include "ddp_wave.h"
 #include "traj_sample.h"
+#include "corridor_io.h"
 
 using namespace direct;
 
@@ -824,6 +825,64 @@ direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const i
     }
   }
   return DIRECT_OK;
+}
+
+size_t direct_corridor_wire_size(int32_t n_seg, const int32_t* n_planes) {
+  return (n_seg < 0 || !n_planes) ? 0 : corridor_wire_size(n_seg, n_planes);
+}
+
+direct_status_t direct_corridor_pack(int32_t path_id, int32_t n_seg, const int32_t* n_planes, const double* planes,
+                                     int32_t p_max, const double* seeds, const double* centers, uint8_t* buf,
+                                     size_t capacity, size_t* written) {
+  if (n_seg < 0 || p_max <= 0 || !n_planes || !planes || !seeds || !centers || !buf)
+    return fail(DIRECT_ERR_INVALID, "bad argument");
+  for (int k = 0; k < n_seg; k++)
+    if (n_planes[k] < 0 || n_planes[k] > p_max) return fail(DIRECT_ERR_INVALID, "n_planes out of range");
+  if (corridor_wire_size(n_seg, n_planes) > capacity) return fail(DIRECT_ERR_INVALID, "buffer too small");
+  const size_t n = corridor_pack(path_id, n_seg, n_planes, planes, p_max, seeds, centers, buf);
+  if (written) *written = n;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_corridor_unpack(const uint8_t* buf, size_t len, int32_t n_seg_max, int32_t p_max,
+                                       int32_t* path_id, int32_t* n_seg, int32_t* n_planes, double* planes,
+                                       double* seeds, double* centers, size_t* used) {
+  if (!buf || n_seg_max <= 0 || p_max <= 0 || !path_id || !n_seg || !n_planes || !planes || !seeds || !centers)
+    return fail(DIRECT_ERR_INVALID, "bad argument");
+  const int rc = corridor_unpack(buf, len, n_seg_max, p_max, path_id, n_seg, n_planes, planes, seeds, centers, used);
+  if (rc == 1) return fail(DIRECT_ERR_INVALID, "truncated or malformed msgs/corridor buffer");
+  if (rc == 2) return fail(DIRECT_ERR_UNSUPPORTED, "corridor exceeds n_seg_max polytopes or p_max facets");
+  return DIRECT_OK;
+}
+
+direct_status_t direct_corridor_replay_batch(int32_t n_rec, const int32_t* n_planes_rec, const double* planes_rec,
+                                             int32_t p_max, const double* seeds_rec, const double* centers_rec,
+                                             int32_t n_first, int32_t batch, double max_vel, double max_acc,
+                                             int32_t* n_seg, double* x0, double* xd, double* T0, int32_t* n_planes,
+                                             double* planes, double* seeds_out) {
+  if (n_rec <= 0 || p_max <= 0 || n_first < 1 || batch < 1 || !n_planes_rec || !planes_rec || !seeds_rec ||
+      !centers_rec || !n_seg || !x0 || !xd || !T0 || !n_planes || !planes || !seeds_out)
+    return fail(DIRECT_ERR_INVALID, "bad argument");
+  const int nm = n_first + batch - 1;
+  if (nm > n_rec) return fail(DIRECT_ERR_INVALID, "no enough recorded polyhedrons");  // TRP:802-804
+  std::vector<double> start((size_t)batch * 3), goal((size_t)batch * 3);
+  for (int b = 0; b < batch; b++) {
+    const int n = n_first + b;
+    n_seg[b] = n;
+    for (int q = 0; q < 9; q++) x0[(size_t)b * 9 + q] = xd[(size_t)b * 9 + q] = 0.0;
+    for (int d = 0; d < 3; d++) {  // TRP:810-811: _start_pt / _end_pt are polytope centers
+      start[(size_t)b * 3 + d] = x0[(size_t)b * 9 + d] = centers_rec[d];
+      goal[(size_t)b * 3 + d] = xd[(size_t)b * 9 + d] = centers_rec[(size_t)(n - 1) * 3 + d];
+    }
+    for (int k = 0; k < nm; k++) {
+      const bool in = k < n;
+      n_planes[(size_t)b * nm + k] = in ? n_planes_rec[k] : 1;
+      for (int d = 0; d < 3; d++) seeds_out[((size_t)b * nm + k) * 3 + d] = in ? seeds_rec[(size_t)k * 3 + d] : 0.0;
+      for (int j = 0; j < p_max * 4; j++)
+        planes[((size_t)b * nm + k) * p_max * 4 + j] = in ? planes_rec[(size_t)k * p_max * 4 + j] : 0.0;
+    }
+  }
+  return direct_time_allocation(batch, nm, n_seg, start.data(), goal.data(), seeds_out, max_vel, max_acc, T0);
 }
 
 direct_status_t direct_traj_sample_batch(direct_ddp_handle_t h, const direct_sample_in_t* in, direct_sample_out_t* out) {

@@ -24,6 +24,7 @@ EXPORTS = (
     "direct_ddp_begin", "direct_ddp_backward_pass", "direct_ddp_forward_pass", "direct_ddp_iterate",
     "direct_ddp_finish", "direct_ddp_get_field", "direct_ddp_set_field", "direct_ddp_last_kernel_ms",
     "direct_ddp_best_cost", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
+    "direct_corridor_wire_size", "direct_corridor_pack", "direct_corridor_unpack", "direct_corridor_replay_batch",
 )
 
 

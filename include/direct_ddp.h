@@ -30,6 +30,7 @@
 #ifndef DIRECT_DDP_H_
 #define DIRECT_DDP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -163,6 +164,34 @@ direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const i
                                        const double* start, const double* goal,
                                        const double* seeds, double max_vel, double max_acc,
                                        double* T_out);
+
+/* ---- corridor wire format and replay (the step right before the path) ------------------
+ * msgs/corridor (msgs/msg/corridor.msg, polyhedron.msg, facet3.msg) in ROS 1 serialisation, i.e. what the
+ * reference's recorder publishes and its replay reads (writeCorridorMsg / readCorridorMsg,
+ * teach_repeat_planner.cpp:354-410): little endian,
+ *   int32 path_id; uint32 n; n x { float64 center[3]; float64 seed_coord[3]; uint32 m; m x float64 (a,b,c,d) }.
+ * Host arrays, double precision; planes[k][p_max][4], seeds[k][3], centers[k][3]. */
+size_t direct_corridor_wire_size(int32_t n_seg, const int32_t* n_planes);
+/* writes direct_corridor_wire_size() bytes to buf */
+direct_status_t direct_corridor_pack(int32_t path_id, int32_t n_seg, const int32_t* n_planes, const double* planes,
+                                     int32_t p_max, const double* seeds, const double* centers, uint8_t* buf,
+                                     size_t capacity, size_t* written);
+/* DIRECT_ERR_INVALID: truncated / malformed buffer; DIRECT_ERR_UNSUPPORTED: more polytopes than n_seg_max
+ * or more facets than p_max.  *used = bytes consumed (messages may be concatenated in one buffer). */
+direct_status_t direct_corridor_unpack(const uint8_t* buf, size_t len, int32_t n_seg_max, int32_t p_max,
+                                       int32_t* path_id, int32_t* n_seg, int32_t* n_planes, double* planes,
+                                       double* seeds, double* centers, size_t* used);
+/* The replay protocol of corridorRecCallBack + fastTrajPlanning (teach_repeat_planner.cpp:308-352, 796-823):
+ * problem b = the first n_first + b polytopes of the recorded corridor, start = center of polytope 0, goal =
+ * center of the last one, at rest, durations from initTimeAllocation.  Fills the arrays of a
+ * direct_ddp_batch_in_t with n_seg_max = n_first + batch - 1 rows per problem (double precision, host):
+ * n_seg[batch], x0/xd[batch][9], T0[batch][n_seg_max], n_planes[batch][n_seg_max],
+ * planes[batch][n_seg_max][p_max][4], seeds_out[batch][n_seg_max][3]. */
+direct_status_t direct_corridor_replay_batch(int32_t n_rec, const int32_t* n_planes_rec, const double* planes_rec,
+                                             int32_t p_max, const double* seeds_rec, const double* centers_rec,
+                                             int32_t n_first, int32_t batch, double max_vel, double max_acc,
+                                             int32_t* n_seg, double* x0, double* xd, double* T0, int32_t* n_planes,
+                                             double* planes, double* seeds_out);
 
 /* ---- output sampling (the step right after the path) ----------------------------------
  * Batched form of the sampling loops of the caller's visualisation / audit helpers

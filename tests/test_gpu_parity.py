@@ -233,3 +233,21 @@ def test_output_sampling_matches_oracle(built, dtype):
         T2[0, 1] = -1.0
         assert s.sample(g["n_seg"], bez, T2, 0.05, 100)["count"][0] == -1
         s.close()
+
+
+def test_recorded_corridor_replay_in_one_batch(built):
+    """The benchmark replay of corridorRecCallBack (TRP:316-320: the first n polytopes, n = 2..64, one solver
+    run each) as ONE ragged batch through direct_ddp_plan_batch, against the oracle problem by problem."""
+    import os
+    from direct_amd import corridor_io
+    cor, _ = corridor_io.unpack(open(os.path.join(helpers.GOLDEN_DIR, "corridor_msg.bin"), "rb").read(), 64, 12)
+    batch = corridor_io.replay_batch(cor, n_first=2)
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    s = make_solver(batch, np.float64)
+    g0, g1 = s.plan(p0, p1, batch)
+    s.close()
+    r0, r1 = refapi.plan_batch(p0, p1, batch)
+    assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
+    assert (g1.rtn == r1.rtn).all() and (g1.iter_used == r1.iter_used).all()
+    assert np.abs(g1.cost / r1.cost - 1).max() < 1e-6 and helpers.rel(g1.T, r1.T) < 1e-6
+    assert helpers.rel(g1.bez, r1.bez) < 1e-5
