@@ -50,3 +50,28 @@ def check_result(res, g, prefix, tol, exact_iters=True, T_tol=None, bez_tol=None
     assert rel(res.poly, g[prefix + "poly"]) < bez_tol
     assert rel(res.jerk_cost, g[prefix + "jerk_cost"]) < 10 * bez_tol
     assert (res.infeas_out == g[prefix + "infeas_out"].astype(int)).all()
+
+
+def with_extra_planes(batch, p_max, seed=0):
+    """Pads every polytope of a HostBatch with random half-spaces through points ~1 m outside its seed
+    segment (valid but mostly inactive), up to p_max planes per polytope in total with varying counts:
+    exercises the RPL = 3 / 4 kernels (nc = 6P + 55 > 128 / 192)."""
+    rng = np.random.default_rng(seed)
+    B, nm, p0 = batch.planes.shape[:3]
+    planes = np.zeros((B, nm, p_max, 4))
+    planes[:, :, :p0] = batch.planes
+    n_planes = batch.n_planes.copy()
+    for b in range(B):
+        for k in range(int(batch.n_seg[b])):
+            a = batch.x0[b, :3] if k == 0 else batch.seeds[b, k]
+            c = batch.xd[b, :3] if k == batch.n_seg[b] - 1 else batch.seeds[b, k + 1]
+            target = int(rng.integers(max(p0, p_max - 5), p_max + 1))
+            j = int(n_planes[b, k])
+            while j < target:
+                n = rng.normal(size=3)
+                n /= np.linalg.norm(n)
+                off = max(float(n @ a), float(n @ c)) + float(rng.uniform(0.8, 3.0))   # both seeds strictly inside
+                planes[b, k, j] = np.r_[n, -off]
+                j += 1
+            n_planes[b, k] = j
+    return abi.HostBatch(batch.n_seg, batch.x0, batch.xd, batch.T0, n_planes, planes, seeds=batch.seeds, dtype=batch.dtype)

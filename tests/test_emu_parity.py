@@ -130,3 +130,24 @@ def test_line_initialisation_matches_oracle(kind):
     assert (g.line_failed_out == o.line_failed_out).all() and (g.infeas_out == o.infeas_out).all()
     assert np.abs(g.cost / o.cost - 1).max() < 1e-8
     assert helpers.rel(g.T, o.T) < 1e-8
+
+
+@pytest.mark.parametrize("p_max", [20, 32])
+def test_many_planes_per_polytope(p_max):
+    """P up to 20 / 32 planes: nc = 175 / 247 rows per knot, the RPL = 3 / 4 instantiations."""
+    batch = helpers.with_extra_planes(problems.make_batch("corridor", 2, 6, seed=41), p_max, seed=p_max)
+    assert batch.n_planes.max() == p_max
+    p0 = abi.phase0_params()
+    e = emuapi.EmuSolver(p0, batch)
+    r = [refapi.Stepper(p0, batch, i) for i in range(2)]
+    e.backward()
+    e.forward()
+    for i, q in enumerate(r):
+        q.backward()
+        q.forward()
+        for f in (abi.FIELD_KU, abi.FIELD_KUU, abi.FIELD_KS, abi.FIELD_KY, abi.FIELD_X, abi.FIELD_S, abi.FIELD_Y):
+            assert helpers.rel(e.get(f)[i], q.get(f)) < 1e-9, f
+    g = emuapi.solve_batch(p0, batch)
+    o, _ = refapi.solve_batch(p0, batch)
+    assert (g.rtn == o.rtn).all() and (g.iter_used == o.iter_used).all()
+    assert np.abs(g.cost / o.cost - 1).max() < 1e-8

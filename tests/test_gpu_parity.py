@@ -251,3 +251,23 @@ def test_recorded_corridor_replay_in_one_batch(built):
     assert (g1.rtn == r1.rtn).all() and (g1.iter_used == r1.iter_used).all()
     assert np.abs(g1.cost / r1.cost - 1).max() < 1e-6 and helpers.rel(g1.T, r1.T) < 1e-6
     assert helpers.rel(g1.bez, r1.bez) < 1e-5
+
+
+@pytest.mark.parametrize("p_max", [20, 32])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_many_planes_per_polytope(built, p_max, dtype):
+    """P up to 20 / 32 planes per polytope (nc = 175 / 247): the RPL = 3 / 4 kernels, both storage types."""
+    batch = helpers.with_extra_planes(problems.make_batch("corridor", 5, 9, seed=41), p_max, seed=p_max)
+    batch = batch.astype(dtype).astype(np.float64)     # identical (rounded) inputs for the oracle
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    s = make_solver(batch, dtype)
+    g0, g1 = s.plan(p0, p1, batch.astype(dtype))
+    s.close()
+    r0, r1 = refapi.plan_batch(p0, p1, batch)
+    if dtype == np.float64:
+        assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
+        assert (g1.rtn == r1.rtn).all() and (g1.iter_used == r1.iter_used).all()
+        assert np.abs(g1.cost / r1.cost - 1).max() < 1e-6 and helpers.rel(g1.T, r1.T) < 1e-6
+    else:
+        assert (g0.rtn == r0.rtn).all() and (g1.rtn >= 0).all()
+        assert np.abs(g1.cost / r1.cost - 1).max() < 2e-2
