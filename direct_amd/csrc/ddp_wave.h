@@ -285,7 +285,7 @@ struct WaveLds {
   // per knot, both sweeps
   Real tp[8];             // powers of T
   Real z[kXS];
-  Real pl[4 * kPMax];
+  Real pl[4 * kPMax + 20];  // the knot's planes, then five pseudo-planes for the velocity / acceleration / T rows
   Real val[48], G[48];
   union {
     struct {  // ---- backward sweep only
@@ -474,7 +474,7 @@ struct Wave {
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
     St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
-  DDP_DEV void prefetch(Pre& p, int lane, int buf, int k, int P, bool fwd, int infeas) const {
+  DDP_DEV void prefetch(Pre& p, int* pkv, int lane, int buf, int k, int P, bool fwd, int infeas) const {
     const St* rec = XpU(buf, k);
     p.zh = rec[lane < 19 ? lane : 18];
     p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 3 ? lane : 2)] : (St)0;  // see ldx()
@@ -487,8 +487,9 @@ struct Wave {
     const St* ksk = SpU(B.KS, k);
     const St* kyk = SpU(B.KY, k);
     for (int i = 0; i < RPL; i++) {
-      const int r = row_r(i, lane, P);
-      const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0 and are masked in commit_rows()
+      pkv[i] = row_pack(i, lane, P);  // the knot's row descriptors: computed once, carried to its row phases
+      const int r = (pkv[i] & 255) - 1;
+      const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0; their results are masked
       p.s[i] = sk[rc];
       if (infeas) p.y[i] = yk[rc];
       if (fwd) {
@@ -573,54 +574,53 @@ struct Wave {
         double ca = (a + 1) * (a + 2) * (a + 3), cb = (a2 + 1) * (a2 + 2) * (a2 + 3);
         L.Rc[lane] = (Real)(ca * cb / (double)(a + a2 + 1));
       }
+      if (lane < 5) {  // pseudo-planes (n, o) of the non-plane rows: +/-v - vmax, +/-a - amax, -T + 0.3 (DDP:1237-1279)
+        Real* q = &L.pl[4 * Lds::kPMax + 4 * lane];
+        q[0] = (Real)0;
+        q[1] = (Real)0;
+        q[2] = (lane == 0 || lane == 2) ? (Real)1 : (Real)-1;
+        q[3] = lane < 2 ? -(Real)B.k.max_vel : (lane < 4 ? -(Real)B.k.max_acc : (Real)0.3);
+      }
     }
     WSYNC();
   }
 
   // ---- shared pieces ---------------------------------------------------------------------------
-  // HBM row index of (slot, lane), -1 if the slot is empty
-  DDP_DEV int row_r(int slot, int lane, int P) const {
-    if (slot == RPL - 1) {
-      const int rp = 64 * (RPL - 1) + lane - 55;
-      return lane < 55 ? 6 * P + lane : (rp < 6 * P ? rp : -1);
-    }
-    const int rp = lane + 64 * slot;
-    return rp < 6 * P ? rp : -1;
-  }
-  DDP_DEV RowK<Real> row_slot(int slot, int lane, int P) const {
-    RowK<Real> k;
+  // Row descriptor of (slot, lane) for a knot with P planes, packed into one word so that it can be
+  // computed ONCE per knot and carried in a register: (r + 1) | a0 << 8 | (plane index in L.pl) << 16.
+  // Non-plane rows point at the pseudo-planes behind the knot's planes, so every row is a "plane row".
+  DDP_DEV int row_pack(int slot, int lane, int P) const {
     const bool last = (slot == RPL - 1);  // a constant once the slot loop is unrolled
     const int rp = last ? 64 * (RPL - 1) + lane - 55 : lane + 64 * slot;
     const bool pv = rp >= 0 && rp < 6 * P;
     const int rq = pv ? rp : 0;
     const int j = (int)(DDP_UMUL24((unsigned)rq, kInvP[P]) >> 16);  // rq / P: the control point
-    const Real* n = &L.pl[4 * (rq - (int)DDP_UMUL24((unsigned)j, (unsigned)P))];
+    const int q = rq - (int)DDP_UMUL24((unsigned)j, (unsigned)P);   // the plane
+    int pk = (pv ? rp + 1 : 0) | ((3 * j) << 8) | (q << 16);
+    if (last) {  // lanes 0..54: velocity (30), acceleration (24), T_min (1) rows  (DDP:1236-1238, 1274-1279)
+      const bool isv = lane < 30, isa = lane < 54;
+      const int l2 = lane - 30;
+      const int a0v = 16 + (lane < 15 ? lane : lane - 15);  // 18 + . - 2: the bounded value is read through n2
+      const int a0a = 31 + (l2 < 12 ? l2 : l2 - 12);         // 33 + . - 2
+      const int a0 = isv ? a0v : (isa ? a0a : 43);
+      const int pp = isv ? (lane < 15 ? 0 : 1) : (isa ? (l2 < 12 ? 2 : 3) : 4);
+      const int po = (6 * P + lane + 1) | (a0 << 8) | ((Lds::kPMax + pp) << 16);
+      pk = lane < 55 ? po : pk;
+    }
+    return pk;
+  }
+  DDP_DEV RowK<Real> row_unpack(int pk) const {
+    RowK<Real> k;
+    const Real* n = &L.pl[4 * (pk >> 16)];
     k.n0 = n[0];
     k.n1 = n[1];
     k.n2 = n[2];
     k.o = n[3];
-    k.r = pv ? rp : -1;
-    k.a0 = 3 * j;
-    if (last) {  // lanes 0..54: velocity (30), acceleration (24), T_min (1) rows  (DDP:1236-1238, 1274-1279)
-      const bool other = lane < 55;
-      const bool isv = lane < 30, isa = lane < 54;
-      const int l2 = lane - 30;
-      const int a0v = 16 + (lane < 15 ? lane : lane - 15);  // 18 + . - 2
-      const int a0a = 31 + (l2 < 12 ? l2 : l2 - 12);         // 33 + . - 2
-      const bool pos = isv ? lane < 15 : (isa ? l2 < 12 : false);
-      Real mvel = -(Real)B.k.max_vel, macc = -(Real)B.k.max_acc;
-      DDP_OPAQUE_S(mvel);
-      DDP_OPAQUE_S(macc);
-      const Real off = isv ? mvel : (isa ? macc : (Real)0.3);  // DDP:1279: -T + 0.3
-      k.r = other ? 6 * P + lane : k.r;
-      k.a0 = other ? (isv ? a0v : (isa ? a0a : 43)) : k.a0;
-      k.n0 = other ? (Real)0 : k.n0;
-      k.n1 = other ? (Real)0 : k.n1;
-      k.n2 = other ? (pos ? (Real)1 : (Real)-1) : k.n2;
-      k.o = other ? off : k.o;
-    }
+    k.r = (pk & 255) - 1;
+    k.a0 = (pk >> 8) & 255;
     return k;
   }
+  DDP_DEV RowK<Real> row_slot(int slot, int lane, int P) const { return row_unpack(row_pack(slot, lane, P)); }
   // A_r . w
   DDP_DEV Real row_lin(const Real* A, const RowK<Real>& k) const {
     return k.n0 * A[k.a0] + k.n1 * A[k.a0 + 1] + k.n2 * A[k.a0 + 2];
@@ -927,7 +927,9 @@ struct Wave {
     int Pn = DDP_UNIFORM_I(npU(N - 1));
     int Pnn = npU(N > 1 ? N - 2 : 0);
     PLV(Pre, pre);
-    LANES { prefetch(LV(pre), lane, buf, N - 1, Pn, false, infeas); }
+    PLA(int, pkn, RPL);  // row descriptors of the prefetched knot / of the knot being processed
+    PLA(int, pkc, RPL);
+    LANES { prefetch(LV(pre), LV(pkn), lane, buf, N - 1, Pn, false, infeas); }
 #pragma unroll 1
     for (int k_ = N - 1; k_ >= 0; k_--) {
       // the knot index is re-materialised every trip: as a visible induction variable it makes loop
@@ -947,6 +949,7 @@ struct Wave {
         for (int i = 0; i < RPL; i++) {
           LV(rs)[i] = (Real)LV(pre).s[i];
           LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
+          LV(pkc)[i] = LV(pkn)[i];
         }
       }
       // the segment time straight from lane 18's prefetch register (z[18], a single word: see ldx()):
@@ -955,7 +958,7 @@ struct Wave {
       if (k > 0) {
         Pn = DDP_UNIFORM_I(Pnn);
         Pnn = npU(k > 1 ? k - 2 : 0);
-        LANES { prefetch(LV(pre), lane, buf, k - 1, Pn, false, infeas); }
+        LANES { prefetch(LV(pre), LV(pkn), lane, buf, k - 1, Pn, false, infeas); }
       }
       DDP_MARK("B_T1");
       // ---- T1: powers of T, scaled value table, dynamics tables
@@ -1033,7 +1036,7 @@ struct Wave {
         for (int i = 0; i < RPL; i++) {
           // every lane runs the row arithmetic (empty slots alias row 0); only the stores and the
           // running maxima are masked
-          const RowK<Real> rk = row_slot(i, lane, P);
+          const RowK<Real> rk = row_unpack(LV(pkc)[i]);
           const int r = rk.r;
           const bool in = r >= 0;
           Real c = row_c(L.val, rk), s = LV(rs)[i], y = LV(ry)[i];
@@ -1382,7 +1385,7 @@ struct Wave {
         St* ksg = SpU(B.KS, k);
         St* kyg = SpU(B.KY, k);
         for (int i = 0; i < RPL; i++) {
-          const RowK<Real> rk = row_slot(i, lane, P);
+          const RowK<Real> rk = row_unpack(LV(pkc)[i]);
           const int r = rk.r;
           const Real cuku = row_lin(L.G, rk);
           const Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
@@ -1492,7 +1495,9 @@ struct Wave {
       int Pn = DDP_UNIFORM_I(npU(0));
       int Pnn = npU(N > 1 ? 1 : 0);
       PLV(Pre, pre);
-      LANES { prefetch(LV(pre), lane, cur, 0, Pn, true, infeas); }
+      PLA(int, pkn, RPL);
+      PLA(int, pkc, RPL);
+      LANES { prefetch(LV(pre), LV(pkn), lane, cur, 0, Pn, true, infeas); }
 #pragma unroll 1
       for (int k_ = 0; k_ < N; k_++) {
         int k = k_;  // see bwd_sweep()
@@ -1511,6 +1516,7 @@ struct Wave {
             LV(rks)[i] = (Real)LV(pre).ks[i];
             LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
             LV(rky)[i] = infeas ? (Real)LV(pre).ky[i] : (Real)0;
+            LV(pkc)[i] = LV(pkn)[i];
           }
         }
         // the old T straight from lane 18's prefetch register (no LDS round trip)
@@ -1518,7 +1524,7 @@ struct Wave {
         if (k + 1 < N) {
           Pn = DDP_UNIFORM_I(Pnn);
           Pnn = npU(k + 2 < N ? k + 2 : k + 1);
-          LANES { prefetch(LV(pre), lane, cur, k + 1, Pn, true, infeas); }
+          LANES { prefetch(LV(pre), LV(pkn), lane, cur, k + 1, Pn, true, infeas); }
         }
         WSYNC();
       DDP_MARK("F_D");
@@ -1629,7 +1635,7 @@ struct Wave {
           St* yn = SpU(B.Y[nxt], k);
           for (int i = 0; i < RPL; i++) {
             // branch-free rows: empty slots alias row 0, their stores / reductions are masked
-            const RowK<Real> rk = row_slot(i, lane, P);
+            const RowK<Real> rk = row_unpack(LV(pkc)[i]);
             const int r = rk.r;
             const bool in = r >= 0;
             const Real az = row_lin(L.G, rk);
