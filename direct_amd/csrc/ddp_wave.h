@@ -1426,21 +1426,31 @@ struct Wave {
           const Acc h0 = lane < 45 ? L.Hxx[a * 9 + c2] : L.Hz[aa];
           Acc yy = 0, kk2 = 0;
 #pragma unroll
-          for (int half = 0; half < 2; half++) {  // two batches of 20 operands: 40 live doubles would spill
-            Acc ya[5], yb[5], ka[5], kb[5];
+          for (int half = 0; half < 2; half++) {  // two batches of operands: 40 live doubles would spill
+            Acc ya[5], yb[5];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
               const int k2 = 5 * half + j;
               ya[j] = L.UY[k2 * 20 + 10 + cA];
               yb[j] = L.UY[k2 * 20 + 10 + cB];
-              ka[j] = (cA == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cA - 1)];
-              kb[j] = (cB == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cB - 1)];
             }
             DDP_LOADS_ISSUED();
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-              yy += ya[j] * yb[j];
-              kk2 += ka[j] * kb[j];
+            for (int j = 0; j < 5; j++) yy += ya[j] * yb[j];
+          }
+          if (regi > 0) {  // lam = base^reg - 1 is exactly 0 at reg = 0 (the common case): the Ku'Ku term vanishes
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+              Acc ka[5], kb[5];
+#pragma unroll
+              for (int j = 0; j < 5; j++) {
+                const int k2 = 5 * half + j;
+                ka[j] = (cA == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cA - 1)];
+                kb[j] = (cB == 0) ? L.KU[k2] : L.KU[10 + k2 * 9 + (cB - 1)];
+              }
+              DDP_LOADS_ISSUED();
+#pragma unroll
+              for (int j = 0; j < 5; j++) kk2 += ka[j] * kb[j];
             }
           }
           const Acc vnew = h0 - yy - lam * kk2;
