@@ -9,10 +9,12 @@
 //       acc = 1/T_i  sum_j C(3,j) 20 (c_i,j+2 - 2 c_i,j+1 + c_ij) t^j (1-t)^(3-j)
 //       traj_len += |pos - previous pos|
 //
-// One wavefront per trajectory; lane l of a chunk evaluates sample l.  The sample times reproduce the
-// reference's accumulation t += step exactly (lane l performs the l sequential additions), so the
-// number of samples per segment is the reference's.  The kernel streams (bez, T) in and 9 words per
-// sample out: it is HBM-write bound.
+// One wavefront per trajectory; lane l of a chunk evaluates sample l.  The NUMBER of samples per segment
+// is the reference's: its loop accumulates t += step in floating point, so the count is decided by the
+// rounded recurrence, not by ceil(1/step).  The recurrence drifts from k*step by at most k ulp, so when
+// no k*step lies within that margin of 1.0 the count follows from a multiplication (fast path, sample
+// times k*step); otherwise the segment replays the exact recurrence (lane l performs the l sequential
+// additions).  The kernel streams (bez, T) in and 9 words per sample out: it is HBM-write bound.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -34,6 +36,17 @@ struct SampleArgs {
   St* vmax;
   St* amax;
 };
+
+// one 12- / 24-byte store per lane: consecutive lanes write consecutive bytes (global_store_dwordx3 / x4 + x2)
+template <typename St> struct Vec3;
+template <> struct Vec3<float> { typedef float3 type; };
+template <> struct Vec3<double> { typedef double3 type; };
+template <typename St>
+__device__ __forceinline__ void store3(St* dst, double x, double y, double z) {
+  typename Vec3<St>::type v;
+  v.x = (St)x; v.y = (St)y; v.z = (St)z;
+  *reinterpret_cast<typename Vec3<St>::type*>(dst) = v;
+}
 
 __device__ __forceinline__ double sample_readlane(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -71,12 +84,37 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
 #pragma unroll
     for (int q = 0; q < 18; q++) cf[q] = (double)c[q];
     if (A.seg_first && lane == 0) A.seg_first[(size_t)b * A.nmax + i] = base;
+    // fast path: count = the smallest k with k * step >= 1, provided no candidate is within k ulp of 1.0
+    int nfast = -1;
+    if (step < 1.0 && step > 1.0e-7) {
+      const double kf = floor(1.0 / step);
+      int cnt = -1, ambiguous = 0;
+      for (int c = -1; c <= 2; c++) {
+        const double k = kf + (double)c;
+        if (k < 1.0) continue;
+        const double p = k * step, margin = (k + 4.0) * 2.220446049250313e-16;
+        if (fabs(p - 1.0) <= margin) ambiguous = 1;
+        if (cnt < 0 && p >= 1.0) cnt = (int)k;
+      }
+      if (!ambiguous && cnt > 0) nfast = cnt;
+    } else if (step >= 1.0) {
+      nfast = 1;
+    }
+    const double invT = 1.0 / Ti;
     double t_carry = 0.0;
+    int kbase = 0;
     while (true) {
-      double t = t_carry;
+      double t;
+      bool valid;
+      if (nfast >= 0) {
+        t = (double)(kbase + lane) * step;
+        valid = kbase + lane < nfast;
+      } else {
+        t = t_carry;
 #pragma unroll 8
-      for (int q = 0; q < 63; q++) t = (q < lane) ? t + step : t;
-      const bool valid = t < 1.0;
+        for (int q = 0; q < 63; q++) t = (q < lane) ? t + step : t;
+        valid = t < 1.0;
+      }
       const int n = __popcll(__ballot(valid));
       const double u = 1.0 - t;
       double tp[6], up[6];
@@ -102,7 +140,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
 #pragma unroll
           for (int j = 0; j < 4; j++)
             ra += C3[j] * 5.0 * 4.0 * (cf[d * 6 + j + 2] - 2.0 * cf[d * 6 + j + 1] + cf[d * 6 + j]) * tp[j] * up[3 - j];
-          a[d] = ra / Ti;
+          a[d] = ra * invT;
         }
       }
       // distance to the previous sample (lane - 1, or the carried point for lane 0)
@@ -118,16 +156,16 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
         if (A.derivs >= 1) vm = fmax(vm, fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))));
         if (A.derivs >= 2) am = fmax(am, fmax(fabs(a[0]), fmax(fabs(a[1]), fabs(a[2]))));
         if (idx < A.capacity) {
-          St* o = A.pos + (ob + idx) * 3;
-          o[0] = (St)p[0]; o[1] = (St)p[1]; o[2] = (St)p[2];
-          if (A.derivs >= 1 && A.vel) { St* w = A.vel + (ob + idx) * 3; w[0] = (St)v[0]; w[1] = (St)v[1]; w[2] = (St)v[2]; }
-          if (A.derivs >= 2 && A.acc) { St* w = A.acc + (ob + idx) * 3; w[0] = (St)a[0]; w[1] = (St)a[1]; w[2] = (St)a[2]; }
+          store3(A.pos + (ob + idx) * 3, p[0], p[1], p[2]);
+          if (A.derivs >= 1 && A.vel) store3(A.vel + (ob + idx) * 3, v[0], v[1], v[2]);
+          if (A.derivs >= 2 && A.acc) store3(A.acc + (ob + idx) * 3, a[0], a[1], a[2]);
         }
       }
       if (n > 0) {
         px = sample_readlane(p[0], n - 1); py = sample_readlane(p[1], n - 1); pz = sample_readlane(p[2], n - 1);
       }
       base += n;
+      kbase += 64;
       if (n < 64) break;
       t_carry = sample_readlane(t, 63) + step;
     }
