@@ -278,7 +278,7 @@ template <typename Real, typename RowT, int RPL>
 struct WaveLds {
   static constexpr int kPMax = (64 * RPL - 55) / 6 > kPLim ? kPLim : (64 * RPL - 55) / 6;  // planes per knot
   TrajState st;
-  Real WbE[90], WdE[90];  // value / d-dT base tables with Ek_inv folded in (fixed for the launch)
+  Real WbE[126], WdE[90];  // value / d-dT base tables with Ek_inv folded in (fixed for the launch); WbE rows 15..20: [F|G], R
   Real Hc[18], Hpc[18];   // [F|G] and [F'|G'] coefficients; entry = coefficient * T^exponent
   int He[18], Hpe[18];
   Real Rc[9];             // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1)
@@ -290,7 +290,6 @@ struct WaveLds {
   union {
     struct {  // ---- backward sweep only
       Real We[90], dval[48], H[18], Hp[18];
-      RowT drow[64 * RPL], grow[64 * RPL];
       // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
       // (Acc) whatever Real is: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in
       // fp32 over ~100 knots (DESIGN.md "Precision").
@@ -299,10 +298,20 @@ struct WaveLds {
       // Hxu[a][c] (9x10), Huu 10x10, both triangles stored.  Hxx | Hxu | Huu must stay consecutive
       // (phase H stores through one base pointer).  Phase C reads Huu into registers and never again, so
       // the gains it produces share that storage.
-      Acc Hxx[81], Hxu[90];
+      // The per-row weights D = s/c and g of phase R1 are consumed by phase S, before phase H writes the
+      // condensed system, and the system (and the gains) of a knot are dead when the next knot's R1 runs:
+      // the two share storage.
       union {
-        Acc Huu[100];
-        Acc KU[100];
+        struct {
+          Acc Hxx[81], Hxu[90];
+          union {
+            Acc Huu[100];
+            Acc KU[100];
+          };
+        };
+        struct {
+          RowT drow[64 * RPL], grow[64 * RPL];
+        };
       };
       Acc Hz[20];
       union {
@@ -405,7 +414,11 @@ DDP_DEV Real pow3(Real T, Real T2, Real T4, int e) {
   return r;
 }
 
-DDP_DEV int ctrl_off(int cr) { return cr < 6 ? 0 : (cr < 11 ? 1 : 2); }
+// Exponent offset of a row of the value table: entry i carries T^(i - o).  Rows 0..14 are the position /
+// velocity / acceleration control points; rows 15..17 are the rows of [F | G] (o = row) and rows 18..20
+// the rows of the jerk Gram matrix R acting on u (o = 2 - row): the dynamics and the running cost have
+// the same "weight * T^(i-o) * coefficient" structure and run through the same code (forward pass, phase T).
+DDP_DEV int ctrl_off(int cr) { return cr < 6 ? 0 : (cr < 11 ? 1 : (cr < 15 ? 2 : (cr < 18 ? cr - 15 : 20 - cr))); }
 
 // One constraint row as seen by (slot, lane).  Rows are dealt to lanes BY KIND so that a slot runs one
 // kind of code: slots 0..RPL-2 hold position rows r = lane + 64*slot (r < 6P); the last slot holds the
@@ -568,11 +581,14 @@ struct Wave {
           hpe = e - 1;
         }
         L.Hc[lane] = (Real)hc; L.He[lane] = he; L.Hpc[lane] = (Real)hpc; L.Hpe[lane] = hpe;
+        L.WbE[90 + lane] = (Real)hc;  // rows 15..17 of the value table: [F | G], exponent i - row
       }
       if (lane < 9) {  // DDP:991-999: Rc[a][a'] = c_a c_a' / (a+a'+1), c_a = (a+1)(a+2)(a+3)
         int a = lane / 3, a2 = lane % 3;
         double ca = (a + 1) * (a + 2) * (a + 3), cb = (a2 + 1) * (a2 + 2) * (a2 + 3);
         L.Rc[lane] = (Real)(ca * cb / (double)(a + a2 + 1));
+        L.WbE[108 + a * 6 + a2] = (Real)0;  // rows 18..20: [0 0 0 | Rc[a][:]], exponent i - (2 - a) = a + a2 + 1
+        L.WbE[108 + a * 6 + 3 + a2] = (Real)(ca * cb / (double)(a + a2 + 1));
       }
       if (lane < 5) {  // pseudo-planes (n, o) of the non-plane rows: +/-v - vmax, +/-a - amax, -T + 0.3 (DDP:1237-1279)
         Real* q = &L.pl[4 * Lds::kPMax + 4 * lane];
@@ -1589,8 +1605,10 @@ struct Wave {
       DDP_MARK("F_T");
         // ---- T: control values at the old and the new iterate, A*[dx; Ku dx], x+, jerk cost
         LANES {
-          if (lane < 45) {
-            int cr = lane / 3, d = lane % 3, o = ctrl_off(cr);
+          {  // lanes 0..44: control values; 45..53: x+ (rows of [F|G]); 54..62: jerk-cost products (rows of R)
+            const int l62 = lane < 63 ? lane : 62;
+            const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
+            const int crd = cr < 15 ? cr : 14;  // the d/dT table has no rows for the dynamics / cost (unused there)
             Real vo = 0, dvo = 0, vn = 0, gf = 0;
             // Summed over the exponent j = i - o instead of the coefficient index i (same terms, same
             // order: the i < o terms have zero weight): the power T^j is then the same for every lane and
@@ -1603,7 +1621,7 @@ struct Wave {
                 const int j = 3 * half + jj;
                 const bool on = (j < 4) || (j + o < 6);  // o <= 2
                 const int i = on ? j + o : 5;
-                const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[cr * 6 + i];
+                const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[crd * 6 + i];
                 wb6[jj] = on ? wbv : (Real)0;
                 wd6[jj] = on ? wdv : (Real)0;
                 zo6[jj] = L.z[3 * i + d];
@@ -1621,17 +1639,18 @@ struct Wave {
                 vn += wb6[jj] * pwn[j] * zn6[jj];
               }
             }
-            L.val[lane] = vo;
-            L.valn[lane] = vn;
-            L.G[lane] = gf + dvo * L.dz[18];
-          } else if (lane == 63) {
+            const Real un = L.zn[9 + (lane < 54 ? 0 : l62 - 54)], dT = L.dz[18];
+            if (lane < 45) {
+              L.val[lane] = vo;
+              L.G[lane] = gf + dvo * dT;
+            }
+            Real* dst = lane < 45 ? &L.valn[l62] : (lane < 54 ? &L.xnx[l62 - 45] : &L.qp[l62 - 54]);
+            *dst = lane < 54 ? vn : vn * un;  // u_a[d] * (R u)_a[d]: the nine of them sum to u'Ru (DDP:1294-1305)
+          }
+          if (lane == 63) {
             L.val[45] = L.z[18];
             L.valn[45] = L.zn[18];
             L.G[45] = L.dz[18];
-          } else if (lane < 54) {
-            L.xnx[lane - 45] = next_x(L.zn, L.tpn, lane - 45);
-          } else if (lane < 63) {
-            L.qp[lane - 54] = jerk_part(L.zn, L.tpn, lane - 54);
           }
         }
         WSYNC();
