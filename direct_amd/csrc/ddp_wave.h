@@ -278,9 +278,9 @@ template <typename Real, typename RowT, int RPL>
 struct WaveLds {
   static constexpr int kPMax = (64 * RPL - 55) / 6 > kPLim ? kPLim : (64 * RPL - 55) / 6;  // planes per knot
   TrajState st;
-  Real WbE[126], WdE[90];  // value / d-dT base tables with Ek_inv folded in (fixed for the launch); WbE rows 15..20: [F|G], R
-  Real Hc[18], Hpc[18];   // [F|G] and [F'|G'] coefficients; entry = coefficient * T^exponent
-  int He[18], Hpe[18];
+  // value / d-dT base tables with Ek_inv folded in (fixed for the launch).  Rows 15..17: [F|G] and its
+  // T-derivative, rows 18..20: the jerk Gram matrix R acting on u and its T-derivative (see ctrl_off()).
+  Real WbE[126], WdE[126];
   Real Rc[9];             // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1)
   // per knot, both sweeps
   Real tp[8];             // powers of T
@@ -289,7 +289,8 @@ struct WaveLds {
   Real val[48], G[48];
   union {
     struct {  // ---- backward sweep only
-      Real We[90], dval[48], H[18], Hp[18];
+      // We = WbE o T-powers for rows 0..17; rows 15..17 are Z = [F|G] itself
+      Real We[108], dval[48];
       // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
       // (Acc) whatever Real is: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in
       // fp32 over ~100 knots (DESIGN.md "Precision").
@@ -580,8 +581,10 @@ struct Wave {
           hpc = g0 * (double)e;
           hpe = e - 1;
         }
-        L.Hc[lane] = (Real)hc; L.He[lane] = he; L.Hpc[lane] = (Real)hpc; L.Hpe[lane] = hpe;
-        L.WbE[90 + lane] = (Real)hc;  // rows 15..17 of the value table: [F | G], exponent i - row
+        (void)he;
+        (void)hpe;  // the exponents are i - row and i - row - 1: the table's own structure
+        L.WbE[90 + lane] = (Real)hc;   // rows 15..17 of the value table: [F | G]
+        L.WdE[90 + lane] = (Real)hpc;  // and [F' | G']
       }
       if (lane < 9) {  // DDP:991-999: Rc[a][a'] = c_a c_a' / (a+a'+1), c_a = (a+1)(a+2)(a+3)
         int a = lane / 3, a2 = lane % 3;
@@ -589,6 +592,8 @@ struct Wave {
         L.Rc[lane] = (Real)(ca * cb / (double)(a + a2 + 1));
         L.WbE[108 + a * 6 + a2] = (Real)0;  // rows 18..20: [0 0 0 | Rc[a][:]], exponent i - (2 - a) = a + a2 + 1
         L.WbE[108 + a * 6 + 3 + a2] = (Real)(ca * cb / (double)(a + a2 + 1));
+        L.WdE[108 + a * 6 + a2] = (Real)0;  // d/dT: (a + a2 + 1) Rc, one power less
+        L.WdE[108 + a * 6 + 3 + a2] = (Real)(ca * cb / (double)(a + a2 + 1)) * (Real)(a + a2 + 1);
       }
       if (lane < 5) {  // pseudo-planes (n, o) of the non-plane rows: +/-v - vmax, +/-a - amax, -T + 0.3 (DDP:1237-1279)
         Real* q = &L.pl[4 * Lds::kPMax + 4 * lane];
@@ -662,7 +667,7 @@ struct Wave {
     const int c = a / 3, d = a % 3;
     Real acc = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) acc += L.Hc[c * 6 + i] * tpw[L.He[c * 6 + i]] * zz[3 * i + d];
+    for (int i = 0; i < 6; i++) acc += L.WbE[90 + c * 6 + i] * tpw[i < c ? 0 : i - c] * zz[3 * i + d];
     return acc;
   }
   // u_a[d] * (R u)_a[d]; the nine of them sum to u'Ru  (DDP:1294-1305)
@@ -981,14 +986,11 @@ struct Wave {
       const Real T2 = DDP_UNIFORM_R(T * T), T4 = DDP_UNIFORM_R(T2 * T2);
       LANES {
 #pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-          const int e = (lane + 64 * pass < 90) ? lane + 64 * pass : 89;
+        for (int pass = 0; pass < 2; pass++) {  // rows 0..14: control points; rows 15..17: Z = [F | G]
+          const int e = (lane + 64 * pass < 108) ? lane + 64 * pass : 107;
           const int cr = e / 6, i = e % 6, ex = i - ctrl_off(cr);
           L.We[e] = L.WbE[e] * pow3(T, T2, T4, ex < 0 ? 0 : ex);  // WbE is 0 where ex < 0
         }
-        const int l18 = lane < 18 ? lane : 17;
-        L.H[l18] = L.Hc[l18] * pow3(T, T2, T4, L.He[l18]);
-        L.Hp[l18] = L.Hpc[l18] * pow3(T, T2, T4, L.Hpe[l18]);
         L.tp[lane & 7] = pow3(T, T2, T4, lane & 7);
       }
       WSYNC();
@@ -998,51 +1000,40 @@ struct Wave {
 #pragma unroll
       for (int j = 0; j < 6; j++) pw[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(T, T2, T4, j));
       LANES {
-        {
-          const int l45 = lane < 45 ? lane : 44;
-          const int cr = l45 / 3, d = l45 % 3, o = ctrl_off(cr);
-          // summed over the exponent j = i - o (see fwd_pass, phase T): uniform powers, no table reads
-          Real v = 0, dv = 0, z6[6], wb6[6], wd6[6];
+        // One code path for 21 table rows x 3 axes (lanes 0..62, see ctrl_off()): rows 0..14 give the control
+        // values and their d/dT; rows 15..17 give fT = (F' (x) I) x + (G' (x) I) u as the d/dT value
+        // (DDP:1332); rows 18..20 give R u, R'u and R''u (DDP:1349-1355) as value, first and second derivative.
+        const int l62 = lane < 63 ? lane : 62;
+        const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
+        // summed over the exponent j = i - o (see fwd_pass, phase T): uniform powers, no table reads
+        Real v = 0, dv = 0, ddv = 0, z6[6], wb6[6], wd6[6];
 #pragma unroll
-          for (int j = 0; j < 6; j++) {
-            const bool on = (j < 4) || (j + o < 6);  // o <= 2
-            const int i = on ? j + o : 5;
-            const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[cr * 6 + i];
-            z6[j] = L.z[3 * i + d];
-            wb6[j] = on ? wbv : (Real)0;
-            wd6[j] = on ? wdv : (Real)0;
-          }
-          DDP_LOADS_ISSUED();
+        for (int j = 0; j < 6; j++) {
+          const bool on = (j < 4) || (j + o < 6);  // o <= 2
+          const int i = on ? j + o : 5;
+          const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[cr * 6 + i];
+          z6[j] = L.z[3 * i + d];
+          wb6[j] = on ? wbv : (Real)0;
+          wd6[j] = on ? wdv : (Real)0;
+        }
+        DDP_LOADS_ISSUED();
 #pragma unroll
-          for (int j = 0; j < 6; j++) {
-            v += (wb6[j] * pw[j]) * z6[j];  // We[cr][i] = WbE * T^j, exactly as phase T1 forms it
-            dv += wd6[j] * pw[j < 1 ? 0 : j - 1] * z6[j];
-          }
-          L.val[l45] = v;
-          L.dval[l45] = dv;
+        for (int j = 0; j < 6; j++) {
+          v += (wb6[j] * pw[j]) * z6[j];  // We[cr][i] = WbE * T^j, exactly as phase T1 forms it
+          dv += wd6[j] * pw[j < 1 ? 0 : j - 1] * z6[j];
+          if (j >= 2) ddv += (wd6[j] * (Real)(j - 1)) * pw[j - 2] * z6[j];  // only read for rows 18..20
+        }
+        if (lane < 45) {
+          L.val[lane] = v;
+          L.dval[lane] = dv;
+        } else if (lane < 54) {
+          L.fT[lane - 45] = dv;
+        } else if (lane < 63) {
+          L.Ru[lane - 54] = v;
+          L.Rpu[lane - 54] = dv;
+          L.Rppu[lane - 54] = ddv;
+        } else {
           L.val[45] = T;
-        }
-        {  // Ru, R'u, R''u (DDP:1349-1355)
-          const int l27 = lane < 27 ? lane : 26;
-          const int t = l27 / 9, a9 = l27 % 9, a = a9 / 3, d = a9 % 3;
-          Acc acc = 0;
-#pragma unroll
-          for (int a2 = 0; a2 < 3; a2++) {
-            const int e = a + a2 + 1 - t;
-            Real cf = L.Rc[a * 3 + a2];
-            cf *= (t >= 1) ? (Real)(a + a2 + 1) : (Real)1;
-            cf *= (t == 2) ? (Real)(a + a2) : (Real)1;
-            acc += cf * L.tp[e < 0 ? 0 : e] * L.z[9 + 3 * a2 + d];  // cf is 0 where e < 0
-          }
-          Acc* dst = (t == 0) ? L.Ru : (t == 1 ? L.Rpu : L.Rppu);
-          dst[a9] = acc;
-        }
-        {  // fT = (F' (x) I) x + (G' (x) I) u  (DDP:1332)
-          const int a = lane < 27 ? 0 : (lane < 36 ? lane - 27 : 8), c = a / 3, d = a % 3;
-          Acc acc = 0;
-#pragma unroll
-          for (int i = 0; i < 6; i++) acc += L.Hp[c * 6 + i] * L.z[3 * i + d];
-          L.fT[a] = acc;
         }
       }
       WSYNC();
@@ -1088,7 +1079,7 @@ struct Wave {
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             v3[c] = L.V[a * 9 + 3 * c + d];
-            h3[c] = L.H[c * 6 + i];
+            h3[c] = L.We[90 + c * 6 + i];
           }
           DDP_LOADS_ISSUED();
           Acc acc = 0;
@@ -1182,7 +1173,7 @@ struct Wave {
             w2[cr] = L.We[cr * 6 + i2];
           }
 #pragma unroll
-          for (int c = 0; c < 3; c++) hh3[c] = L.H[c * 6 + i];
+          for (int c = 0; c < 3; c++) hh3[c] = L.We[90 + c * 6 + i];
           DDP_LOADS_ISSUED();
 #pragma unroll
           for (int cr = 0; cr < 6; cr++) {
@@ -1259,7 +1250,7 @@ struct Wave {
           if (lane < 18) {
             Acc zvz = 0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) zvz += L.H[c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
+            for (int c = 0; c < 3; c++) zvz += L.We[90 + c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
             const Acc v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Acc)0) + sig * acc;
             if (p < 9) {
               L.Hxu[p * 10 + 9] = v;
@@ -1270,7 +1261,7 @@ struct Wave {
           } else {
             Acc zv = 0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) zv += L.H[c * 6 + i] * L.Vx[3 * c + d];
+            for (int c = 0; c < 3; c++) zv += L.We[90 + c * 6 + i] * L.Vx[3 * c + d];
             L.Hz[p] = ((i >= 3) ? wsn * L.Ru[p - 9] : (Acc)0) + zv + acc;
           }
         }
