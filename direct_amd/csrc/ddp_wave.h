@@ -488,7 +488,7 @@ struct Wave {
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
     St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
-  DDP_DEV void prefetch(Pre& p, int* pkv, int lane, int buf, int k, int P, bool fwd, int infeas) const {
+  DDP_DEV void prefetch(Pre& p, int* pkv, int pk_valid, int lane, int buf, int k, int P, bool fwd, int infeas) const {
     const St* rec = XpU(buf, k);
     p.zh = rec[lane < 19 ? lane : 18];
     p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 3 ? lane : 2)] : (St)0;  // see ldx()
@@ -501,7 +501,9 @@ struct Wave {
     const St* ksk = SpU(B.KS, k);
     const St* kyk = SpU(B.KY, k);
     for (int i = 0; i < RPL; i++) {
-      pkv[i] = row_pack(i, lane, P);  // the knot's row descriptors: computed once, carried to its row phases
+      // the knot's row descriptors: computed once, carried to its row phases; they only depend on P,
+      // so a run of knots with the same plane count (every free-space corridor) reuses them
+      if (!pk_valid) pkv[i] = row_pack(i, lane, P);
       const int r = (pkv[i] & 255) - 1;
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0; their results are masked
       p.s[i] = sk[rc];
@@ -950,7 +952,7 @@ struct Wave {
     PLV(Pre, pre);
     PLA(int, pkn, RPL);  // row descriptors of the prefetched knot / of the knot being processed
     PLA(int, pkc, RPL);
-    LANES { prefetch(LV(pre), LV(pkn), lane, buf, N - 1, Pn, false, infeas); }
+    LANES { prefetch(LV(pre), LV(pkn), 0, lane, buf, N - 1, Pn, false, infeas); }
 #pragma unroll 1
     for (int k_ = N - 1; k_ >= 0; k_--) {
       // the knot index is re-materialised every trip: as a visible induction variable it makes loop
@@ -979,7 +981,8 @@ struct Wave {
       if (k > 0) {
         Pn = DDP_UNIFORM_I(Pnn);
         Pnn = npU(k > 1 ? k - 2 : 0);
-        LANES { prefetch(LV(pre), LV(pkn), lane, buf, k - 1, Pn, false, infeas); }
+        const int same = (Pn == P) ? 1 : 0;
+        LANES { prefetch(LV(pre), LV(pkn), same, lane, buf, k - 1, Pn, false, infeas); }
       }
       DDP_MARK("B_T1");
       // ---- T1: powers of T, scaled value table, dynamics tables
@@ -1514,7 +1517,7 @@ struct Wave {
       PLV(Pre, pre);
       PLA(int, pkn, RPL);
       PLA(int, pkc, RPL);
-      LANES { prefetch(LV(pre), LV(pkn), lane, cur, 0, Pn, true, infeas); }
+      LANES { prefetch(LV(pre), LV(pkn), 0, lane, cur, 0, Pn, true, infeas); }
 #pragma unroll 1
       for (int k_ = 0; k_ < N; k_++) {
         int k = k_;  // see bwd_sweep()
@@ -1541,7 +1544,8 @@ struct Wave {
         if (k + 1 < N) {
           Pn = DDP_UNIFORM_I(Pnn);
           Pnn = npU(k + 2 < N ? k + 2 : k + 1);
-          LANES { prefetch(LV(pre), LV(pkn), lane, cur, k + 1, Pn, true, infeas); }
+          const int same = (Pn == P) ? 1 : 0;
+          LANES { prefetch(LV(pre), LV(pkn), same, lane, cur, k + 1, Pn, true, infeas); }
         }
         WSYNC();
       DDP_MARK("F_D");
