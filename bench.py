@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--kind", default="free", choices=["free", "corridor"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="0 = max(512, 8 x host cores)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="0 = max(512, 256 x usable host threads), capped by the batch")
     args = ap.parse_args()
 
     import torch  # first: the library then binds to the HIP runtime torch has already loaded
@@ -208,7 +208,7 @@ def main():
             "iters_per_step_rank0": iters_step, "best_cost": bc, "best_index": bidx, "gather_ms": gather_ms,
         }
         if not args.no_cpu_baseline and world == 1:
-            sample = args.cpu_sample or max(512, 8 * usable_cpus())
+            sample = args.cpu_sample or max(512, 256 * usable_cpus())  # ~10-20 s of host work at ~0.8 k iter/s per thread
             line["cpu_baseline"] = cpu_baseline(batch1.astype(np.float64), params, min(sample, B))
         print(json.dumps(line))
     s.close()
