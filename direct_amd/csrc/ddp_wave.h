@@ -710,7 +710,6 @@ struct Wave {
     int neg = 0;
     for (int k = 0; k < N; k++) {
       const int P = np_(k);
-      const int nc = 6 * P + 55;
       LANES {
         if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
         for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
@@ -1523,7 +1522,6 @@ struct Wave {
         int k = k_;  // see bwd_sweep()
         DDP_LAUNDER_S(k);
         const int P = Pn;
-        const int nc = 6 * P + 55;
         DDP_MARK("F_L");
         PLA(Real, rs, RPL);
         PLA(Real, ry, RPL);
