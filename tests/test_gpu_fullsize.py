@@ -220,3 +220,21 @@ def test_output_sampling_of_the_full_batch(built, free_batch):
     o = refapi.sample_batch(free_batch.n_seg[sub], g1.bez[sub], g1.T[sub], dt, cap)
     assert (o["count"] == cnt[sub]).all()
     assert helpers.rel(d["pos"][sub], o["pos"]) < 2e-6 and helpers.rel(d["length"][sub], o["length"]) < 2e-6
+
+
+@pytest.mark.parametrize("nb", [3073, 5000])
+def test_ticket_scheduler_at_awkward_batch_sizes(built, nb, monkeypatch):
+    """Batches just above the resident-wave count (3072 on MI355X) and far from a multiple of it, short
+    trajectories with very different iteration counts: static and ticket-scheduled launches agree bit for bit."""
+    batch = problems.make_batch("corridor", nb, 6, seed=77)
+    res = {}
+    for mode in ("static", "dynamic"):
+        monkeypatch.setenv("DIRECT_DDP_SCHED", mode)
+        s = solver.DdpSolver(nb, 6, batch.p_max, np.float64)
+        res[mode] = s.plan(abi.phase0_params(), abi.phase1_params(), batch)
+        s.close()
+    for a, b in zip(res["static"], res["dynamic"]):
+        for f in ("rtn", "iter_used", "fwd_passes", "cost", "T", "bez"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    it = res["dynamic"][1].iter_used
+    assert it.min() < it.max()
