@@ -12,6 +12,7 @@
 //
 // Requirements on Mat: Mat(rows, cols), rows(), cols(), operator()(i, j).  On Vec: Vec(n), size(), operator()(i).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <chrono>
 #include <cstdint>
@@ -193,5 +194,89 @@ class ddpTrajOptimizer {
   std::vector<uint8_t> raw_cost_, raw_jerk_, raw_tn_, raw_bez_, raw_poly_, raw_T_;
   double compTime_ = 0.0;
 };
+
+// ---- the steps around the path, same names as the node's helpers ---------------------------------
+// writeCorridorMsg / readCorridorMsg (teach_repeat_planner.cpp:354-410): msgs/corridor in ROS 1 wire
+// serialisation <-> FlightCorridor.
+inline std::vector<uint8_t> writeCorridorMsg(int path_id, const decomp_cvx_space::FlightCorridor& corridor) {
+  const int N = (int)corridor.polyhedrons.size();
+  int pm = 1;
+  for (const auto& pl : corridor.polyhedrons) pm = std::max(pm, (int)pl.planes.size());
+  std::vector<int32_t> n_planes(N);
+  std::vector<double> planes((size_t)N * pm * 4, 0.0), seeds((size_t)N * 3), centers((size_t)N * 3);
+  for (int k = 0; k < N; k++) {
+    const auto& pl = corridor.polyhedrons[k];
+    n_planes[k] = (int32_t)pl.planes.size();
+    for (size_t j = 0; j < pl.planes.size(); j++)
+      for (int q = 0; q < 4; q++) planes[((size_t)k * pm + j) * 4 + q] = pl.planes[j][q];
+    seeds[k * 3] = pl.seed_coord.x; seeds[k * 3 + 1] = pl.seed_coord.y; seeds[k * 3 + 2] = pl.seed_coord.z;
+    centers[k * 3] = pl.center.x; centers[k * 3 + 1] = pl.center.y; centers[k * 3 + 2] = pl.center.z;
+  }
+  std::vector<uint8_t> buf(direct_corridor_wire_size(N, n_planes.data()));
+  size_t written = 0;
+  if (direct_corridor_pack(path_id, N, n_planes.data(), planes.data(), pm, seeds.data(), centers.data(), buf.data(),
+                           buf.size(), &written) != DIRECT_OK)
+    throw std::runtime_error(direct_ddp_last_error());
+  buf.resize(written);
+  return buf;
+}
+inline void readCorridorMsg(const std::vector<uint8_t>& msg, decomp_cvx_space::FlightCorridor& corridor, int& path_id,
+                            int n_seg_max = 256, int p_max = DIRECT_P_LIMIT) {
+  std::vector<int32_t> n_planes(n_seg_max);
+  std::vector<double> planes((size_t)n_seg_max * p_max * 4), seeds((size_t)n_seg_max * 3), centers((size_t)n_seg_max * 3);
+  int32_t pid = 0, N = 0;
+  if (direct_corridor_unpack(msg.data(), msg.size(), n_seg_max, p_max, &pid, &N, n_planes.data(), planes.data(),
+                             seeds.data(), centers.data(), nullptr) != DIRECT_OK)
+    throw std::runtime_error(direct_ddp_last_error());
+  corridor.polyhedrons.clear();
+  for (int k = 0; k < N; k++) {
+    decomp_cvx_space::Polytope pl;
+    pl.center = {centers[k * 3], centers[k * 3 + 1], centers[k * 3 + 2]};
+    pl.seed_coord = {seeds[k * 3], seeds[k * 3 + 1], seeds[k * 3 + 2]};
+    for (int j = 0; j < n_planes[k]; j++) {
+      const double* q = &planes[((size_t)k * p_max + j) * 4];
+      pl.appendPlane({q[0], q[1], q[2], q[3]});
+    }
+    corridor.polyhedrons.push_back(pl);
+  }
+  path_id = pid;
+}
+
+// The sampling loop of visBezierTrajectory & co. (teach_repeat_planner.cpp:1551-1566) for one trajectory on
+// the device: polyCoeff = getBezCoeff() (N x 18), time = getPolyTime(); returns the sampled positions and,
+// through traj_len, the reference's polyline length.  Batched callers use direct_traj_sample_batch directly.
+template <class Mat, class Vec>
+std::vector<std::array<double, 3>> sampleBezierTrajectory(DdpDevice& dev, const Mat& polyCoeff, const Vec& time, double dt,
+                                                        double* traj_len = nullptr) {
+  const int N = (int)time.size(), nm = N;
+  const bool f64 = dev.dtype() == DIRECT_F64;
+  double total = 0.0;
+  for (int k = 0; k < N; k++) total += time(k) > 0 ? time(k) : 0.0;
+  const int cap = (int)(total / dt) + 2 * N + 8;
+  std::vector<double> bez((size_t)nm * 18), T(nm), pos((size_t)cap * 3), len(1);
+  for (int k = 0; k < N; k++) {
+    T[k] = time(k);
+    for (int q = 0; q < 18; q++) bez[(size_t)k * 18 + q] = polyCoeff(k, q);
+  }
+  std::vector<float> fb, fT, fpos, flen;
+  int32_t n_seg = N, count = 0;
+  direct_sample_in_t in{};
+  in.batch = 1; in.n_seg_max = nm; in.capacity = cap; in.derivs = 0; in.mem = DIRECT_MEM_HOST; in.n_seg = &n_seg; in.dt = dt;
+  direct_sample_out_t out{};
+  out.count = &count;
+  if (f64) {
+    in.bez = bez.data(); in.T = T.data(); out.pos = pos.data(); out.length = len.data();
+  } else {
+    fb.assign(bez.begin(), bez.end()); fT.assign(T.begin(), T.end()); fpos.resize(pos.size()); flen.resize(1);
+    in.bez = fb.data(); in.T = fT.data(); out.pos = fpos.data(); out.length = flen.data();
+  }
+  if (direct_traj_sample_batch(dev.handle(), &in, &out) != DIRECT_OK) throw std::runtime_error(direct_ddp_last_error());
+  if (count < 0) return {};  // "time less than 0, returning" (TRP:1552-1555)
+  std::vector<std::array<double, 3>> pts((size_t)std::min(count, cap));
+  for (size_t i = 0; i < pts.size(); i++)
+    for (int d = 0; d < 3; d++) pts[i][d] = f64 ? pos[i * 3 + d] : (double)fpos[i * 3 + d];
+  if (traj_len) *traj_len = f64 ? len[0] : (double)flen[0];
+  return pts;
+}
 
 }  // namespace direct

@@ -14,6 +14,10 @@ extern "C" int direct_ref_plan_batch(const direct_ddp_params_t*, const direct_dd
 using direct::DenseMatrix;
 using direct::DenseVector;
 
+extern "C" int direct_ref_sample(int n_seg, const double* bez, const double* T, double dt, int capacity, int derivs,
+                                 int* seg_first, double* pos, double* vel, double* acc, double* length, double* vmax,
+                                 double* amax);
+
 int main() {
   const int N = 6, B = 2;
   std::vector<decomp_cvx_space::FlightCorridor> cors(B);
@@ -84,6 +88,35 @@ int main() {
     std::printf("corridor %d: rtn0 %d/%d rtn1 %d/%d iters %d/%d cost %.9g/%.9g rel %.2e T0 %.6f/%.6f\n", b, rtn0[b], r0[b], rtn1[b],
                 r1[b], opt1.getIterUsed(b), it1[b], opt1.getDDPObjective(b), c1[b], rel, opt1.getPolyTime(b)(0), Tout[(size_t)b * N]);
     if (rtn0[b] != r0[b] || rtn1[b] != r1[b] || opt1.getIterUsed(b) != it1[b] || rel > 1e-8) bad++;
+  }
+  // the steps around the path: corridor message round trip and output sampling against the oracle
+  {
+    for (size_t k = 0; k < cors[0].polyhedrons.size(); k++) cors[0].polyhedrons[k].center = {0.5 + k, -1.0, 1.0};
+    const std::vector<uint8_t> msg = direct::writeCorridorMsg(42, cors[0]);
+    decomp_cvx_space::FlightCorridor back;
+    int pid = 0;
+    direct::readCorridorMsg(msg, back, pid, 16, 8);
+    bool same = pid == 42 && back.polyhedrons.size() == cors[0].polyhedrons.size();
+    for (size_t k = 0; same && k < back.polyhedrons.size(); k++) {
+      const auto &a = back.polyhedrons[k], &b = cors[0].polyhedrons[k];
+      same = a.planes == b.planes && a.center.x == b.center.x && a.seed_coord.y == b.seed_coord.y;
+    }
+    std::printf("corridor message: %zu bytes, round trip %s\n", msg.size(), same ? "ok" : "MISMATCH");
+    if (!same) bad++;
+    double len = 0.0, len_ref = 0.0;
+    const auto pts = direct::sampleBezierTrajectory(dev, opt1.getBezCoeff(0), opt1.getPolyTime(0), 0.2, &len);
+    std::vector<double> bz((size_t)N * 18), Tt(N), pref(pts.size() * 3 + 3);
+    for (int k = 0; k < N; k++) {
+      Tt[k] = opt1.getPolyTime(0)(k);
+      for (int q = 0; q < 18; q++) bz[(size_t)k * 18 + q] = opt1.getBezCoeff(0)(k, q);
+    }
+    const int cnt = direct_ref_sample(N, bz.data(), Tt.data(), 0.2, (int)pts.size(), 0, nullptr, pref.data(), nullptr, nullptr,
+                                      &len_ref, nullptr, nullptr);
+    double err = 0.0;
+    for (size_t i = 0; i < pts.size() && (int)i < cnt; i++)
+      for (int d = 0; d < 3; d++) err = std::fmax(err, std::fabs(pts[i][d] - pref[i * 3 + d]));
+    std::printf("sampling: %zu points (oracle %d), max |dp| %.2e, length %.9f / %.9f\n", pts.size(), cnt, err, len, len_ref);
+    if ((int)pts.size() != cnt || err > 1e-10 || std::fabs(len / len_ref - 1.0) > 1e-12) bad++;
   }
   std::printf(bad ? "FAIL\n" : "PASS\n");
   return bad ? 1 : 0;
