@@ -78,3 +78,30 @@ def test_replay_batch_follows_the_reference_protocol(rec):
         assert np.allclose(b.T0[i, :n], T[0], rtol=1e-14) and (b.T0[i, n:] == 0).all()
     with pytest.raises(solver.DirectError):
         corridor_io.replay_batch(rec, n_first=2, batch=64)  # "no enough recorded polyhedrons" (TRP:802-804)
+
+
+def test_unpack_survives_random_corruption(rec):
+    """A wire-format reader must never read out of bounds: random byte flips, truncations and garbage
+    either decode to something self-consistent or are rejected with an error code."""
+    rng = np.random.default_rng(123)
+    data = bytearray(golden_bytes())
+    for trial in range(400):
+        buf = bytearray(data)
+        kind = trial % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                buf[int(rng.integers(0, len(buf)))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            buf = buf[:int(rng.integers(0, len(buf)))]
+        elif kind == 2:
+            pos = int(rng.integers(0, len(buf) - 4))
+            buf[pos:pos + 4] = struct.pack("<I", int(rng.integers(0, 2 ** 32)))
+        else:
+            buf = bytearray(rng.integers(0, 256, int(rng.integers(0, 4000)), dtype=np.uint8).tobytes())
+        try:
+            cor, used = corridor_io.unpack(bytes(buf), 64, rec.p_max)
+        except solver.DirectError as e:
+            assert e.status in (abi.DIRECT_ERR_INVALID, abi.DIRECT_ERR_UNSUPPORTED)
+            continue
+        assert 0 <= cor.n_seg <= 64 and used <= len(buf) and (cor.n_planes <= rec.p_max).all()
+        assert used == 8 + sum(52 + 32 * int(m) for m in cor.n_planes)
