@@ -41,6 +41,7 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define DDP_PIN(x) ((void)0)
 #define DDP_OPAQUE_S(x) ((void)0)
 #define DDP_UMUL24(a, b) ((a) * (b))
+#define DDP_GLOBAL
 #define DDP_MARK(name)
 #else
 #include <hip/hip_runtime.h>
@@ -89,6 +90,9 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 // segment, i.e. a full memory round trip (and a vmcnt(0) that also drains the prefetch) in the row loop.
 #define DDP_OPAQUE_S(x) asm("" : "+s"(x))
 #define DDP_UMUL24(a, b) __umul24(a, b)  // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
+// A pointer that went through an empty asm is a generic pointer to the compiler (FLAT loads, which also
+// count on lgkmcnt); the sweep's array bases are therefore typed as global-memory pointers.
+#define DDP_GLOBAL __attribute__((address_space(1)))
 
 #if defined(DDP_MARKS)  // phase markers in the .s for static instruction accounting (tools/phase_count.py)
 #define DDP_MARK(name) asm volatile("; DDP_MARK " name ::: "memory")
@@ -460,21 +464,55 @@ struct Wave {
   // The same for a WAVE-UNIFORM k (the sweeps).  The 32-bit row index is forced into an SGPR so that
   // every 64-bit address product stays on the scalar unit (under SGPR pressure `b` ends up in a VGPR and
   // each address would otherwise cost several quarter-rate v_mad_u64_u32).
+  // The array bases themselves are read from the kernel arguments ONCE per sweep (set_sweep_ptrs) and made
+  // opaque: the iterate buffers are selected by a run-time index (cur / 1 - cur), which otherwise costs a
+  // scalar load from the kernarg segment - and an lgkmcnt(0) stall that also drains the LDS queue - in
+  // every knot.  An opaque SGPR pair can at worst be spilled to a VGPR lane (two v_readlane to restore).
+  typedef DDP_GLOBAL St GSt;
+  typedef DDP_GLOBAL const St GCSt;
+  typedef DDP_GLOBAL const int32_t GCInt;
+  struct SweepPtrs {
+    GSt *X[2], *S[2], *Y[2];  // [0] = buffer `cur`, [1] = the trial buffer
+    GSt *KS, *KY, *KU;
+    GCSt* planes;
+    GCInt* n_planes;
+  };
+  SweepPtrs sp;
+  DDP_DEV void set_sweep_ptrs(int cur) {
+    for (int i = 0; i < 2; i++) {
+      sp.X[i] = (GSt*)B.X[i ? 1 - cur : cur];
+      sp.S[i] = (GSt*)B.S[i ? 1 - cur : cur];
+      sp.Y[i] = (GSt*)B.Y[i ? 1 - cur : cur];
+      DDP_OPAQUE_S(sp.X[i]);
+      DDP_OPAQUE_S(sp.S[i]);
+      DDP_OPAQUE_S(sp.Y[i]);
+    }
+    sp.KS = (GSt*)B.KS; sp.KY = (GSt*)B.KY; sp.KU = (GSt*)B.KU; sp.planes = (GCSt*)B.planes;
+    sp.n_planes = (GCInt*)B.n_planes;
+    DDP_OPAQUE_S(sp.KS);
+    DDP_OPAQUE_S(sp.KY);
+    DDP_OPAQUE_S(sp.KU);
+    DDP_OPAQUE_S(sp.planes);
+    DDP_OPAQUE_S(sp.n_planes);
+  }
   DDP_DEV size_t rowU(int k) const { return (size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k); }
-  DDP_DEV St* XpU(int buf, int k) const { return B.X[buf] + (size_t)(unsigned)DDP_UNIFORM_I(b * (B.nmax + 1) + k) * kXS; }
-  DDP_DEV St* SpU(St* base, int k) const { return base + rowU(k) * B.ncs; }
-  DDP_DEV const St* planesU(int k) const { return B.planes + rowU(k) * (B.pmax * 4); }
-  DDP_DEV int npU(int k) const { return B.n_planes[rowU(k)]; }
-  DDP_DEV St* KUpU(int k) const { return B.KU + rowU(k) * 100; }
+  // sel: 0 = the current iterate buffer, 1 = the trial buffer
+  DDP_DEV GSt* XpU(int sel, int k) const { return sp.X[sel] + (size_t)(unsigned)DDP_UNIFORM_I(b * (B.nmax + 1) + k) * kXS; }
+  DDP_DEV GSt* SpU(GSt* base, int k) const { return base + rowU(k) * B.ncs; }
+  DDP_DEV GCSt* planesU(int k) const { return sp.planes + rowU(k) * (B.pmax * 4); }
+  DDP_DEV int npU(int k) const { return sp.n_planes[rowU(k)]; }
+  DDP_DEV GSt* KUpU(int k) const { return sp.KU + rowU(k) * 100; }
   // Knot-record access.  Positions reach hundreds of metres while a barrier step must resolve
   // ~1e-7 of the log-cost, so with float storage the three position words are kept as an unevaluated
   // hi + lo pair (words a and 19 + a); every other entry is O(1) and a single word suffices.
-  DDP_DEV Real ldx(const St* rec, int a) const {
+  template <typename Ptr>
+  DDP_DEV Real ldx(Ptr rec, int a) const {
     Real v = (Real)rec[a];
     if (sizeof(St) < sizeof(double) && a < 3) v += (Real)rec[19 + a];
     return v;
   }
-  DDP_DEV void stx(St* rec, int a, Real v) const {
+  template <typename Ptr>
+  DDP_DEV void stx(Ptr rec, int a, Real v) const {
     const St hi = (St)v;
     rec[a] = hi;
     if (sizeof(St) < sizeof(double) && a < 3) rec[19 + a] = (St)(v - (Real)hi);
@@ -489,17 +527,18 @@ struct Wave {
     St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
   DDP_DEV void prefetch(Pre& p, int* pkv, int pk_valid, int lane, int buf, int k, int P, bool fwd, int infeas) const {
-    const St* rec = XpU(buf, k);
+    (void)buf;
+    GCSt* rec = XpU(0, k);
     p.zh = rec[lane < 19 ? lane : 18];
     p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 3 ? lane : 2)] : (St)0;  // see ldx()
-    const St* pk = planesU(k);
+    GCSt* pk = planesU(k);
     const int pend = 4 * P - 1;
     p.pl[0] = pk[lane < pend ? lane : pend];
     p.pl[1] = pk[lane + 64 < pend ? lane + 64 : pend];
-    const St* sk = SpU(B.S[buf], k);
-    const St* yk = SpU(B.Y[buf], k);
-    const St* ksk = SpU(B.KS, k);
-    const St* kyk = SpU(B.KY, k);
+    GCSt* sk = SpU(sp.S[0], k);
+    GCSt* yk = SpU(sp.Y[0], k);
+    GCSt* ksk = SpU(sp.KS, k);
+    GCSt* kyk = SpU(sp.KY, k);
     for (int i = 0; i < RPL; i++) {
       // the knot's row descriptors: computed once, carried to its row phases; they only depend on P,
       // so a run of knots with the same plane count (every free-space corridor) reuses them
@@ -514,7 +553,7 @@ struct Wave {
       }
     }
     if (fwd) {
-      const St* ku = KUpU(k);
+      GCSt* ku = KUpU(k);
       p.ku[0] = ku[lane];
       p.ku[1] = ku[lane + 64 < 100 ? lane + 64 : 99];
     }
@@ -927,6 +966,7 @@ struct Wave {
     for (int q = 0; q < regi; q++) lam_d *= B.k.reg_base;
     const Acc lam = DDP_UNIFORM_R((Acc)(lam_d - 1.0));  // DDP:529
     const int buf = DDP_UNIFORM_I(st.cur);
+    set_sweep_ptrs(buf);
     const int infeas = DDP_UNIFORM_I(st.infeas);
     const Real mu = DDP_UNIFORM_R((Real)st.mu);
     const Real wsn = (Real)B.k.w_snap;
@@ -936,7 +976,7 @@ struct Wave {
     LANES {
 #pragma unroll 1
       for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Acc)B.k.w_term : (Acc)0;
-      if (lane < 9) L.Vx[lane] = (Acc)B.k.w_term * (Acc)(ldx(XpU(buf, N), lane) - (Real)B.xd[(size_t)b * 9 + lane]);
+      if (lane < 9) L.Vx[lane] = (Acc)B.k.w_term * (Acc)(ldx(XpU(0, N), lane) - (Real)B.xd[(size_t)b * 9 + lane]);
     }
     WSYNC();
     // opterr = max(|Qu|, |r|, |c + y|) over the sweep (DDP:641): one running maximum per lane is enough
@@ -1391,8 +1431,8 @@ struct Wave {
       DDP_MARK("B_R2");
       // ---- R2: slack / dual gains per row; V recursion; gains to HBM
       LANES {
-        St* ksg = SpU(B.KS, k);
-        St* kyg = SpU(B.KY, k);
+        GSt* ksg = SpU(sp.KS, k);
+        GSt* kyg = SpU(sp.KY, k);
         for (int i = 0; i < RPL; i++) {
           const RowK<Real> rk = row_unpack(LV(pkc)[i]);
           const int r = rk.r;
@@ -1485,6 +1525,7 @@ struct Wave {
     DDP_LAUNDER_S(b);
     DDP_LAUNDER_S(N);
     const int cur = DDP_UNIFORM_I(st.cur), nxt = 1 - cur;
+    set_sweep_ptrs(cur);
     const int infeas = DDP_UNIFORM_I(st.infeas);
     const double mu_d = st.mu;
     const double tau_d = fmax(0.99, 1.0 - mu_d);
@@ -1505,7 +1546,7 @@ struct Wave {
       PLV(int, nviol);
       LANES {
         LV(plog).init(); LV(serr) = 0; LV(nviol) = 0;
-        if (lane < 9) L.xn[lane] = ldx(XpU(cur, 0), lane);
+        if (lane < 9) L.xn[lane] = ldx(XpU(0, 0), lane);
       }
       WSYNC();
       double qsum = 0.0;
@@ -1653,8 +1694,8 @@ struct Wave {
         PLV(int, bad);
         LANES {
           LV(bad) = 0;
-          St* sn = SpU(B.S[nxt], k);
-          St* yn = SpU(B.Y[nxt], k);
+          GSt* sn = SpU(sp.S[1], k);
+          GSt* yn = SpU(sp.Y[1], k);
           for (int i = 0; i < RPL; i++) {
             // branch-free rows: empty slots alias row 0, their stores / reductions are masked
             const RowK<Real> rk = row_unpack(LV(pkc)[i]);
@@ -1685,7 +1726,7 @@ struct Wave {
             LV(nviol) += (in && cn >= (Real)2.0e-4) ? 1 : 0;
           }
           LV(plog).norm();
-          if (lane < 19) stx(XpU(nxt, k), lane, L.zn[lane]);
+          if (lane < 19) stx(XpU(1, k), lane, L.zn[lane]);
           if (lane < 9) L.xn[lane] = L.xnx[lane];
         }
         failed = WAVE_ANY(bad);
@@ -1696,7 +1737,7 @@ struct Wave {
       if (failed) continue;
       LANES {
         if (lane < 9) {
-          stx(XpU(nxt, N), lane, L.xn[lane]);
+          stx(XpU(1, N), lane, L.xn[lane]);
           L.z[lane] = L.xn[lane] - B.xd[(size_t)b * 9 + lane];
         }
       }
