@@ -71,6 +71,7 @@ class SampleIn(C.Structure):
         ("batch", C.c_int32), ("n_seg_max", C.c_int32), ("capacity", C.c_int32), ("derivs", C.c_int32),
         ("mem", C.c_int32),
         ("n_seg", C.c_void_p), ("bez", C.c_void_p), ("T", C.c_void_p), ("dt", C.c_double),
+        ("p_max", C.c_int32), ("n_planes", C.c_void_p), ("planes", C.c_void_p),
     ]
 
 
@@ -78,6 +79,7 @@ class SampleOut(C.Structure):
     _fields_ = [
         ("count", C.c_void_p), ("seg_first", C.c_void_p), ("pos", C.c_void_p), ("vel", C.c_void_p),
         ("acc", C.c_void_p), ("length", C.c_void_p), ("vmax", C.c_void_p), ("amax", C.c_void_p),
+        ("cmax", C.c_void_p),
     ]
 
 

@@ -399,6 +399,14 @@ static direct_status_t sample_t(direct_ddp_handle_t h, const direct_sample_in_t*
   A.length = (Real*)out_arr(out->length, B * r);
   A.vmax = (Real*)out_arr(out->vmax, B * r);
   A.amax = (Real*)out_arr(out->amax, B * r);
+  A.cmax = (Real*)out_arr(out->cmax, B * r);
+  A.pmax = in->p_max;
+  A.n_planes = out->cmax ? (const int32_t*)in_arr(in->n_planes, B * nm * 4) : nullptr;
+  A.planes = out->cmax ? (const Real*)in_arr(in->planes, B * nm * (size_t)in->p_max * 4 * r) : nullptr;
+  if (out->cmax && (!A.n_planes || !A.planes || !A.cmax)) {
+    cleanup();
+    return fail(DIRECT_ERR_DEVICE, "staging buffers for direct_traj_sample_batch");
+  }
   if (!A.n_seg || !A.bez || !A.T || !A.count || !A.pos || (out->vel && !A.vel) || (out->acc && !A.acc)) {
     cleanup();
     return fail(DIRECT_ERR_DEVICE, "staging buffers for direct_traj_sample_batch");
@@ -420,6 +428,7 @@ static direct_status_t sample_t(direct_ddp_handle_t h, const direct_sample_in_t*
     if (e == hipSuccess) e = dn(out->length, A.length, B * r);
     if (e == hipSuccess) e = dn(out->vmax, A.vmax, B * r);
     if (e == hipSuccess) e = dn(out->amax, A.amax, B * r);
+    if (e == hipSuccess) e = dn(out->cmax, A.cmax, B * r);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   }
   if (host) { (void)hipStreamSynchronize(h->stream); cleanup(); }
@@ -891,6 +900,8 @@ direct_status_t direct_traj_sample_batch(direct_ddp_handle_t h, const direct_sam
     return fail(DIRECT_ERR_INVALID, "bad sizes");
   if (!(in->dt > 0.0)) return fail(DIRECT_ERR_INVALID, "dt must be positive");
   if (!in->n_seg || !in->bez || !in->T || !out->count || !out->pos) return fail(DIRECT_ERR_INVALID, "null array");
+  if (out->cmax && (!in->planes || !in->n_planes || in->p_max <= 0))
+    return fail(DIRECT_ERR_INVALID, "the containment audit (cmax) needs planes, n_planes and p_max");
   HIP_TRY(hipSetDevice(h->device));
   if (h->dtype == DIRECT_F64) return sample_t<double>(h, in, out);
   return sample_t<float>(h, in, out);

@@ -35,6 +35,11 @@ struct SampleArgs {
   St* length;
   St* vmax;
   St* amax;
+  // containment audit (optional)
+  int pmax;
+  const int32_t* n_planes;
+  const St* planes;
+  St* cmax;
 };
 
 // one 12- / 24-byte store per lane: consecutive lanes write consecutive bytes (global_store_dwordx3 / x4 + x2)
@@ -68,11 +73,13 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
       if (A.length) A.length[b] = (St)0;
       if (A.vmax) A.vmax[b] = (St)0;
       if (A.amax) A.amax[b] = (St)0;
+      if (A.cmax) A.cmax[b] = (St)0;
     }
     return;
   }
   int base = 0;
-  double len = 0.0, vm = 0.0, am = 0.0;
+  double len = 0.0, vm = 0.0, am = 0.0, cm = -1.0e300;
+  const bool audit = A.cmax != nullptr;
   double px = 0.0, py = 0.0, pz = 0.0;  // last point of the previous chunk
   const size_t ob = (size_t)b * A.capacity;
   for (int i = 0; i < N; i++) {
@@ -152,6 +159,12 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
       for (int o = 32; o > 0; o >>= 1) dist += __shfl_xor(dist, o, 64);
       len += dist;
       const int idx = base + lane;
+      if (audit && valid) {  // the planes of a segment are the same for every lane: broadcast loads
+        const int np = A.n_planes[(size_t)b * A.nmax + i];
+        const St* pq = A.planes + ((size_t)b * A.nmax + i) * A.pmax * 4;
+        for (int q = 0; q < np; q++)
+          cm = fmax(cm, (double)pq[4 * q] * p[0] + (double)pq[4 * q + 1] * p[1] + (double)pq[4 * q + 2] * p[2] + (double)pq[4 * q + 3]);
+      }
       if (valid) {
         if (A.derivs >= 1) vm = fmax(vm, fmax(fabs(v[0]), fmax(fabs(v[1]), fabs(v[2]))));
         if (A.derivs >= 2) am = fmax(am, fmax(fabs(a[0]), fmax(fabs(a[1]), fabs(a[2]))));
@@ -173,12 +186,14 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
   for (int o = 32; o > 0; o >>= 1) {
     vm = fmax(vm, __shfl_xor(vm, o, 64));
     am = fmax(am, __shfl_xor(am, o, 64));
+    cm = fmax(cm, __shfl_xor(cm, o, 64));
   }
   if (lane == 0) {
     A.count[b] = base;
     if (A.length) A.length[b] = (St)len;
     if (A.vmax) A.vmax[b] = (St)vm;
     if (A.amax) A.amax[b] = (St)am;
+    if (A.cmax) A.cmax[b] = (St)cm;
   }
 }
 

@@ -194,7 +194,7 @@ class DdpSolver:
         _check(lib().direct_ddp_plan_batch(self.h, C.addressof(params0), C.addressof(params1), C.addressof(cin),
                                            None if cout0 is None else C.addressof(cout0), C.addressof(cout1)))
 
-    def sample(self, n_seg, bez, T, dt, capacity, derivs=2):
+    def sample(self, n_seg, bez, T, dt, capacity, derivs=2, n_planes=None, planes=None):
         """Batched output sampling (direct_traj_sample_batch; teach_repeat_planner.cpp:1551-1566 over
         utils/bezier_base.h:77-127).  Host numpy arrays in, dict of numpy arrays out."""
         n_seg = np.ascontiguousarray(n_seg, np.int32)
@@ -213,6 +213,11 @@ class DdpSolver:
         cin, cout = abi.SampleIn(), abi.SampleOut()
         cin.batch, cin.n_seg_max, cin.capacity, cin.derivs, cin.mem = B, nm, capacity, derivs, abi.MEM_HOST
         cin.n_seg, cin.bez, cin.T, cin.dt = n_seg.ctypes.data, bez.ctypes.data, T.ctypes.data, float(dt)
+        if planes is not None:  # containment audit against the corridor
+            planes = np.ascontiguousarray(planes, self.np_dtype)
+            n_planes = np.ascontiguousarray(n_planes, np.int32)
+            cin.p_max, cin.n_planes, cin.planes = planes.shape[2], n_planes.ctypes.data, planes.ctypes.data
+            o["cmax"] = np.zeros(B, self.np_dtype)
         for k, v in o.items():
             setattr(cout, k, v.ctypes.data)
         _check(lib().direct_traj_sample_batch(self.h, C.addressof(cin), C.addressof(cout)))

@@ -211,6 +211,10 @@ typedef struct {
   const void* bez;           /* [batch][n_seg_max][18] getBezCoeff() layout (time-scaled control points) */
   const void* T;             /* [batch][n_seg_max] getPolyTime() */
   double dt;                 /* sample period [s] (> 0): 0.1 and 0.2 in the reference's helpers */
+  /* optional corridor for the containment audit (out->cmax); all three NULL / 0 when not wanted */
+  int32_t p_max;
+  const int32_t* n_planes;   /* [batch][n_seg_max] */
+  const void* planes;        /* [batch][n_seg_max][p_max][4] as in direct_ddp_batch_in_t */
 } direct_sample_in_t;
 
 typedef struct {
@@ -223,6 +227,8 @@ typedef struct {
   void* length;              /* [batch] traj_len, or NULL */
   void* vmax;                /* [batch] max over samples and axes of |vel| (derivs >= 1), or NULL */
   void* amax;                /* [batch] max over samples and axes of |acc| (derivs >= 2), or NULL */
+  void* cmax;                /* [batch] max over samples of max_p (a x + b y + c z + d) against the planes of the
+                                sample's own segment: <= 0 iff every sample lies in its polytope; needs in->planes */
 } direct_sample_out_t;
 
 direct_status_t direct_traj_sample_batch(direct_ddp_handle_t h, const direct_sample_in_t* in,

@@ -200,8 +200,10 @@ def time_allocation(n_seg, start, goal, seeds, max_vel=2.0, max_acc=2.0):
     return T
 
 
-def sample_batch(n_seg, bez, T, dt, capacity, derivs=2):
-    """The caller's sampling loop (teach_repeat_planner.cpp:1551-1566) for every trajectory of a batch, fp64."""
+def sample_batch(n_seg, bez, T, dt, capacity, derivs=2, n_planes=None, planes=None):
+    """The caller's sampling loop (teach_repeat_planner.cpp:1551-1566) for every trajectory of a batch, fp64.
+    With planes: also cmax[b] = max over the stored samples of max_p (n_p . x + d_p) against the polytope of the
+    sample's own segment (the containment audit; plain numpy over the oracle's samples)."""
     n_seg = np.ascontiguousarray(n_seg, np.int32)
     bez = np.ascontiguousarray(bez, np.float64)
     T = np.ascontiguousarray(T, np.float64)
@@ -217,6 +219,21 @@ def sample_batch(n_seg, bez, T, dt, capacity, derivs=2):
                           o["seg_first"][b].ctypes.data, o["pos"][b].ctypes.data, o["vel"][b].ctypes.data,
                           o["acc"][b].ctypes.data, o["length"][b:].ctypes.data, o["vmax"][b:].ctypes.data,
                           o["amax"][b:].ctypes.data)
+    if planes is not None:
+        planes = np.asarray(planes, np.float64)
+        o["cmax"] = np.zeros(B)
+        for b in range(B):
+            if o["count"][b] < 0:
+                continue
+            worst = -1.0e300
+            for i in range(int(n_seg[b])):
+                lo = int(o["seg_first"][b, i])
+                hi = int(o["seg_first"][b, i + 1]) if i + 1 < int(n_seg[b]) else int(o["count"][b])
+                pts = o["pos"][b, lo:min(hi, capacity)]
+                pl = planes[b, i, :int(n_planes[b, i])]
+                if len(pts):
+                    worst = max(worst, float((pts @ pl[:, :3].T + pl[:, 3]).max()))
+            o["cmax"][b] = worst
     return o
 
 

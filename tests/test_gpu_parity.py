@@ -271,3 +271,26 @@ def test_many_planes_per_polytope(built, p_max, dtype):
     else:
         assert (g0.rtn == r0.rtn).all() and (g1.rtn >= 0).all()
         assert np.abs(g1.cost / r1.cost - 1).max() < 2e-2
+
+
+def test_containment_audit_of_the_samples(built):
+    """cmax of direct_traj_sample_batch: the worst plane value over the samples of each trajectory, against a
+    numpy evaluation over the oracle's samples; solved corridors are inside (convex-hull property of the
+    Bezier control points, which is what the constraints act on)."""
+    batch = problems.make_batch("corridor", 12, 9, seed=91)
+    s = make_solver(batch, np.float64)
+    g0, g1 = s.plan(abi.phase0_params(), abi.phase1_params(), batch)
+    d = s.sample(batch.n_seg, g1.bez, g1.T, 0.05, 2048, derivs=0, n_planes=batch.n_planes, planes=batch.planes)
+    s.close()
+    o = refapi.sample_batch(batch.n_seg, g1.bez, g1.T, 0.05, 2048, derivs=0, n_planes=batch.n_planes, planes=batch.planes)
+    assert (d["count"] == o["count"]).all()
+    assert np.abs(d["cmax"] - o["cmax"]).max() < 1e-10
+    ok = g1.rtn >= 0
+    assert ok.any() and (d["cmax"][ok] < 1e-6).all()
+    # a trajectory pushed out of its corridor is flagged
+    shifted = g1.bez.copy()
+    shifted[0, 2, 0:6] += 5.0 / g1.T[0, 2]          # x control points of segment 2 moved by 5 m
+    s = make_solver(batch, np.float64)
+    bad = s.sample(batch.n_seg, shifted, g1.T, 0.05, 2048, derivs=0, n_planes=batch.n_planes, planes=batch.planes)
+    s.close()
+    assert bad["cmax"][0] > 1.0 and np.array_equal(bad["cmax"][1:], d["cmax"][1:])
