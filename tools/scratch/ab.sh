@@ -1,8 +1,7 @@
 mkdir -p gpurun_out; rm -f gpurun_out/ab.log
-timeout 600 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > gpurun_out/ab_tests.log
 for rep in 1 2; do
-for v in base new; do
-  if [ $v = new ]; then unset DIRECT_DDP_LIB; else export DIRECT_DDP_LIB=$PWD/build_variants/$v.so; fi
+for v in base max-ilp max-mem; do
+  export DIRECT_DDP_LIB=$PWD/build_variants/$v.so
   echo "== $v rep $rep" >> gpurun_out/ab.log
   timeout 120 python tools/ab_time.py free f32 7 >> gpurun_out/ab.log 2>&1
   timeout 120 python tools/ab_time.py corridor f32 7 >> gpurun_out/ab.log 2>&1
