@@ -21,12 +21,33 @@
 
 #if defined(DIRECT_EMULATE)
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 namespace direct {
 using std::fabs; using std::fmax; using std::fmin; using std::log; using std::pow; using std::sqrt;
+// The emulator also CHECKS what the device code merely assumes: a value passed through DDP_UNIFORM_* (a
+// v_readfirstlane on the GPU) must be the same on every lane of the enclosing LANES block, otherwise the
+// GPU silently uses lane 0's value for all of them.  emu_lane is the lane being emulated (64 outside blocks).
+inline int& emu_lane() { static thread_local int l = 64; return l; }
+template <typename T>
+inline T emu_uniform(T x, int line) {
+  static thread_local unsigned char seen[4096][sizeof(double)];
+  const int l = emu_lane();
+  if (l >= 64) return x;
+  unsigned char* ref = seen[line & 4095];
+  if (l == 0) {
+    std::memcpy(ref, &x, sizeof(T));
+  } else if (std::memcmp(ref, &x, sizeof(T)) != 0 && !(x != x)) {  // NaNs of different payloads are not an error
+    std::fprintf(stderr, "ddp_wave.h: wave-uniform site %d: the value differs between lanes 0 and %d\n", line, l);
+    std::abort();
+  }
+  return x;
+}
 }
 #define DDP_DEV inline
 #define DDP_DEV_NOINLINE inline
-#define LANES for (int lane = 0; lane < 64; ++lane)
+#define LANES for (int lane = (direct::emu_lane() = 0); lane < 64; direct::emu_lane() = ++lane)
 #define PLV(T, name) T name[64]
 #define PLA(T, name, n) T name[64][n]
 #define LV(name) name[lane]
@@ -34,8 +55,8 @@ using std::fabs; using std::fmax; using std::fmin; using std::log; using std::po
 #define RDLANE(arr, idx, src) (arr[src][idx])
 #define RDLANE_M(var, member, src) (var[src].member)
 #define RDLANE_V(var, src) (var[src])
-#define DDP_UNIFORM_I(x) (x)
-#define DDP_UNIFORM_R(x) (x)
+#define DDP_UNIFORM_I(x) direct::emu_uniform((x), __COUNTER__)
+#define DDP_UNIFORM_R(x) direct::emu_uniform((x), __COUNTER__)
 #define DDP_LAUNDER_S(x) ((void)0)
 #define DDP_LOADS_ISSUED() ((void)0)
 #define DDP_PIN(x) ((void)0)
