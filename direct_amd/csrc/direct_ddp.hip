@@ -486,6 +486,10 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
   h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
                                             : resident_slots<float>(h, prop.multiProcessorCount);
+  if (const char* ev = getenv("DIRECT_DDP_SLOTS")) {  // experiments: fewer persistent waves than fit
+    const int v = atoi(ev);
+    if (v > 0 && v < h->sched_slots) h->sched_slots = v;
+  }
   h->fieldbuf_bytes = B * nm * (size_t)std::max(ncm, 100) * r + B * 16 * r + B * 9 * r;
   A(&h->fieldbuf, h->fieldbuf_bytes);
   if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
