@@ -1,23 +1,30 @@
 #!/usr/bin/env python
 """Headline benchmark: DDP iterations per second over a batch (BASELINE.json metric).
 
-Workload (config.workload): BASELINE config 2 -- 4096 free-space corridors PER GPU, N = 100
-segments, fp32, the reference's polynomial-segment model (9 states / 10 controls).
-One "step" = one pass of the hot path over the batch: polyCurveGeneration for every corridor
-(ddp_optimizer.cpp:5-438) in its phase-1 configuration (feasible IPDDP, launch-file weights), warm
-started from the phase-0 result and run for a FIXED 20 iterations with the early exits disabled so
-that every implementation does identical work.  Inputs are resident
-in HBM before the timed region; outputs stay in HBM.
+Default workload = BASELINE config 2: 4096 free-space corridors PER GPU, N = 100 segments, float storage,
+the reference's polynomial-segment model (9 states / 10 controls).  `--config 3|4|5`
+selects the other single-GPU-shaped configurations (5 = the per-GPU shard of config 5: 16384 polyhedron
+corridors per GPU); --batch/--nseg/--kind/--dtype override individual fields and config.workload always
+names what was actually run.
 
-Launch: `python bench.py [--gpus 1]` or, for N > 1,
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
- bench.py --gpus N`.  Ranks shard the problem stream (weak scaling, no data-path collective); the
-config-5 RCCL gather of the best trajectory runs once after the timed region as a functional check.
+One "step" = one pass of the hot path over the batch: polyCurveGeneration for every corridor
+(ddp_optimizer.cpp:5-438) in its phase-1 configuration (feasible IPDDP, launch-file weights), warm started
+from the phase-0 result and run for a FIXED 20 iterations with the early exits disabled so that every
+implementation does identical work.  Inputs are resident in HBM before the timed region,
+outputs stay in HBM.  After the timed region the same batch is solved once more with the reference's natural
+exits (secondary figure: rtn histogram, iterations to exit).
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU over
+RCCL; launched by torchrun directly it reads RANK / LOCAL_RANK / WORLD_SIZE.  Ranks shard the problem stream
+(weak scaling, no data-path collective); the config-5 gather of the best trajectory (direct_ddp_gather_best:
+two ncclAllGather through the library's C entry point) runs once after the timed region.
 """
 import argparse
-import ctypes as C
+import glob
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,8 +33,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+F64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector peak (same guide)
 FIXED_ITERS = 20
+CONFIGS = {  # BASELINE.json configs[1..4]
+    2: dict(kind="free", batch=4096, nseg=100, dtype="f32", name="config 2"),
+    3: dict(kind="corridor", batch=4096, nseg=100, dtype="f32", name="config 3"),
+    4: dict(kind="corridor", batch=16384, nseg=300, dtype="f64", name="config 4"),
+    5: dict(kind="corridor", batch=16384, nseg=100, dtype="f32", name="config 5 (per-GPU shard of 131072 / 8)"),
+}
 
 
 def usable_cpus():
@@ -75,41 +89,113 @@ def cpu_baseline(batch1, params, sample):
             "single_thread_value": float(res1.fwd_passes.sum() / dt1)}
 
 
-def measured_traffic_bytes():
-    """HBM bytes per k_iterate launch from the committed rocprofv3 PMC passes of THIS command
-    (profiles/*_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, KB units); None if absent.
-    Dword loads, so the guide's x2 FETCH_SIZE correction for 16 B/lane streams is not applied."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
-    return (d["FETCH_SIZE"]["workload_mean_kb"] + d["WRITE_SIZE"]["workload_mean_kb"]) * 1024.0
+def matching_profile(pattern, workload):
+    """Newest committed profiles/<pattern> whose recorded "workload" equals this run's; None otherwise.
+    A profile of a different batch / N / dtype / kind says nothing about this launch."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload:
+            d["_file"] = os.path.relpath(f, ROOT)
+            return d
+    return None
+
+
+def hbm_copy_gbs(torch, dev):
+    """Measured HBM bandwidth of a device-to-device copy (read + write bytes / time): the second, measured
+    denominator SURVEY.md 8(d) asks for next to the 8 TB/s datasheet figure."""
+    n = 1 << 28  # 2 x 1 GiB of float32
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def dry_run(args, cfg, rank, world, torch, dist, distributed, problems):
+    """The N > 1 plumbing without a device: spawn, gloo rendezvous, position-independent shard generation and
+    the config-5 gather on a placeholder cost (the shard's first duration) - nothing is solved or measured."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, N = cfg["batch"], cfg["nseg"]
+    first = rank * B
+    batch = problems.make_batch(cfg["kind"], B, N, seed=1000, first=first)
+    cost = batch.T0.sum(axis=1)
+    li, lc = distributed.local_best(cost, np.zeros(B, np.int32))
+    block = torch.from_numpy(np.concatenate([batch.T0[li], batch.seeds[li].ravel()]))
+    bc, bidx, owner, blk = distributed.gather_best(lc, first + li, block)
+    if rank == 0:
+        print(json.dumps({"metric": "ddp_iterations_per_sec", "value": None, "dry": True, "n_gpus": world,
+                          "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                          "gather": {"best_cost": bc, "best_index": bidx, "owner": owner,
+                                     "block_checksum": float(blk.double().sum())}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="corridors per GPU")
-    ap.add_argument("--nseg", type=int, default=100)
-    ap.add_argument("--kind", default="free", choices=["free", "corridor"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]")
+    ap.add_argument("--batch", type=int, default=0, help="corridors per GPU (0 = the config's)")
+    ap.add_argument("--nseg", type=int, default=0)
+    ap.add_argument("--kind", default="", choices=["", "free", "corridor"])
+    ap.add_argument("--dtype", default="", choices=["", "f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the natural-exit run and the HBM copy microbench")
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU: exercise launch, rendezvous (gloo), sharding and the gather on placeholder costs; "
+                         "prints a line with value null (CPU test of the N > 1 plumbing, never a measurement)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 = max(512, 256 x usable host threads), capped by the batch")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU, RCCL)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
+    cfg = dict(CONFIGS[args.config])
+    for k in ("batch", "nseg", "kind", "dtype"):
+        if getattr(args, k):
+            cfg[k] = getattr(args, k)
+    custom = any(cfg[k] != CONFIGS[args.config][k] for k in ("batch", "nseg", "kind", "dtype"))
+
     import torch  # first: the library then binds to the HIP runtime torch has already loaded
     import torch.distributed as dist
-    from direct_amd import abi, distributed, problems, solver
+    from direct_amd import abi, devmem, distributed, problems, solver
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry:
+        return dry_run(args, cfg, rank, world, torch, dist, distributed, problems)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the library has no CPU fallback")
     torch.cuda.set_device(local)
@@ -118,11 +204,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    np_dt = np.float32 if args.dtype == "f32" else np.float64
-    t_dt = torch.float32 if args.dtype == "f32" else torch.float64
-    B, N = args.batch, args.nseg
+    np_dt = np.float32 if cfg["dtype"] == "f32" else np.float64
+    B, N = cfg["batch"], cfg["nseg"]
     first = rank * B  # weak scaling: rank r solves problems [r*B, (r+1)*B) of the stream
-    batch = problems.make_batch(args.kind, B, N, seed=1000, first=first, dtype=np_dt)
+    batch = problems.make_batch(cfg["kind"], B, N, seed=1000, first=first, dtype=np_dt)
     s = solver.DdpSolver(B, N, batch.p_max, np_dt, device=local)
     s.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -131,21 +216,17 @@ def main():
     batch1 = batch.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, batch.T0), infeas_in=g0.infeas_out,
                              init_poly=g0.poly)  # monomial hand-off: well conditioned in float (include/direct_ddp.h)
     params = abi.phase1_params(iter_max=FIXED_ITERS, fixed_iters=1)
+    workload = {"kind": cfg["kind"], "batch": B, "nseg": N, "dtype": cfg["dtype"], "fixed_iters": FIXED_ITERS}
 
-    # inputs resident in HBM
-    tens = {k: torch.from_numpy(np.ascontiguousarray(getattr(batch1, k))).to(dev)
-            for k in ("n_seg", "x0", "xd", "T0", "n_planes", "planes", "init_poly", "infeas_in")}
-    cin = abi.BatchIn()
-    cin.batch, cin.n_seg_max, cin.p_max, cin.mem = B, N, batch1.p_max, abi.MEM_DEVICE
-    for k, v in tens.items():
-        setattr(cin, k, v.data_ptr())
-    outs = dict(rtn=torch.zeros(B, dtype=torch.int32, device=dev), fwd_passes=torch.zeros(B, dtype=torch.int32, device=dev),
-                iter_used=torch.zeros(B, dtype=torch.int32, device=dev), cost=torch.zeros(B, dtype=t_dt, device=dev),
-                bez=torch.zeros(B, N, 18, dtype=t_dt, device=dev), T=torch.zeros(B, N, dtype=t_dt, device=dev))
-    cout = abi.BatchOut()
-    cout.mem = abi.MEM_DEVICE
-    for k, v in outs.items():
-        setattr(cout, k, v.data_ptr())
+    # The CPU leg runs BEFORE the GPU's timed region so that the GPU is the last thing busy in the process
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        sample = args.cpu_sample or max(512, 256 * usable_cpus())  # ~10-20 s of host work at ~0.8 k iter/s per thread
+        cpu = cpu_baseline(batch1.astype(np.float64), params, min(sample, B))
+
+    dbatch = devmem.DeviceBatch(batch1, dev)  # inputs resident in HBM
+    outs = devmem.DeviceResult(B, N, np_dt, dev)
+    cin, cout = dbatch.cin, outs.cout
 
     def step():
         s.solve_device(params, cin, cout)
@@ -169,47 +250,114 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if s.sched_error():
+        raise SystemExit("the ticket scheduler reported an error: results are invalid")
     iters_step = int(outs["fwd_passes"].sum().item())
     total = torch.tensor([float(iters_step)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
     iters_all = float(total.item()) * args.steps
 
-    # config-5 reduction (functional check, untimed): cheapest feasible trajectory on every rank
+    # config-5 reduction (functional check, untimed): cheapest feasible trajectory on every rank.
+    # (a) through torch.distributed, (b) through the library's C entry point on its own RCCL communicator.
     cost_h, rtn_h = outs["cost"].cpu().numpy(), outs["rtn"].cpu().numpy()
     li, lc = s.best_cost(outs["cost"].data_ptr(), outs["rtn"].data_ptr(), mem=abi.MEM_DEVICE, batch=B)
     hi, hc = distributed.local_best(cost_h, rtn_h)
     assert li == hi, (li, hi)
-    block = torch.cat([outs["bez"][li].reshape(-1), outs["T"][li].reshape(-1)])
+    blk_src = max(li, 0)
+    block = torch.cat([outs["bez"][blk_src].reshape(-1), outs["T"][blk_src].reshape(-1)])
     tg = time.perf_counter()
-    bc, bidx, owner, blk = distributed.gather_best(lc, first + li, block)
+    bc, bidx, owner, blk = distributed.gather_best(lc, first + li if li >= 0 else -1, block)
     torch.cuda.synchronize()
-    gather_ms = (time.perf_counter() - tg) * 1e3
+    gather = {"torch_ms": (time.perf_counter() - tg) * 1e3, "best_cost": bc, "best_index": bidx, "owner": owner}
+    try:
+        uid = [s.rccl_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        comm = s.rccl_comm_create(uid[0], world, rank)
+        wb = torch.zeros(N, 18, dtype=outs["bez"].dtype, device=dev)
+        wT = torch.zeros(N, dtype=outs["T"].dtype, device=dev)
+        for rep in range(2):  # the second call is the timed one (the first builds RCCL's channels)
+            tg = time.perf_counter()
+            ci, cc, cown = s.gather_best(comm, world, rank, outs["cost"].data_ptr(), outs["rtn"].data_ptr(),
+                                         outs["bez"].data_ptr(), outs["T"].data_ptr(), first, mem=abi.MEM_DEVICE, batch=B,
+                                         out_bez=wb.data_ptr(), out_T=wT.data_ptr())
+            c_ms = (time.perf_counter() - tg) * 1e3
+        s.rccl_comm_destroy(comm)
+        same = (ci == bidx and cc == bc and cown == owner
+                and bool(torch.equal(torch.cat([wb.reshape(-1), wT.reshape(-1)]), blk.to(dev))))
+        gather.update({"c_abi_rccl_ms": c_ms, "c_abi_matches_torch": bool(same), "rccl_ranks": world})
+    except Exception as e:  # noqa: BLE001 - the bench line must survive a gather failure; it is reported, not hidden
+        gather.update({"c_abi_error": repr(e)})
+    devices = [local]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, (rank, local, torch.cuda.get_device_name(local)))
+        devices = got
+        gather["dist_world_size"] = dist.get_world_size()
+
+    # secondary: the same batch with the reference's natural exits (DDP:335-396)
+    natural, hbm_copy = None, None
+    if not args.no_secondary:
+        pn = abi.phase1_params()
+        s.solve_device(pn, cin, cout)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s.solve_device(pn, cin, cout)
+        torch.cuda.synchronize()
+        dtn = time.perf_counter() - t1
+        fp, rt = outs["fwd_passes"].cpu().numpy(), outs["rtn"].cpu().numpy()
+        natural = {"iter_per_s": float(fp.sum() / dtn), "ms": dtn * 1e3, "kernel_ms": s.last_kernel_ms()[0],
+                   "iterations_mean": float(fp.mean()), "iterations_p50": float(np.median(fp)),
+                   "iterations_max": int(fp.max()), "iterations_min": int(fp.min()),
+                   "rtn_histogram": {str(int(v)): int(c) for v, c in zip(*np.unique(rt, return_counts=True))}}
+        hbm_copy = hbm_copy_gbs(torch, dev)
 
     if rank == 0:
         words = problems.algorithmic_words(batch1.n_planes, batch1.n_seg, infeasible=False)
         bytes_per_launch = words * np.dtype(np_dt).itemsize * FIXED_ITERS  # one launch = FIXED_ITERS iterations of B corridors
         avg_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        value = iters_all / dt
+        traffic = matching_profile("r*_hbm_traffic.json", workload)
+        sq = matching_profile("r*_sq_counters.json", workload)
         line = {
-            "metric": "ddp_iterations_per_sec", "value": iters_all / dt, "unit": "iter/s",
+            "metric": "ddp_iterations_per_sec", "value": value, "unit": "iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # arithmetic type of the path: double for both storage types
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config 2: %d %s corridors per GPU, N=%d segments, polynomial-segment IPDDP "
+            "dtype": "f64", "storage_dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": "%s%s: %d %s corridors per GPU, N=%d segments, %s storage, polynomial-segment IPDDP "
                                    "(9 states / 10 controls), phase-1 weights, fixed %d iterations, warm start from phase 0"
-                                   % (B, "free-space" if args.kind == "free" else "polyhedron", N, FIXED_ITERS),
+                                   % (cfg["name"], " (modified)" if custom else "", B,
+                                      "free-space" if cfg["kind"] == "free" else "polyhedron", N, cfg["dtype"], FIXED_ITERS),
                        "batch_per_gpu": B, "n_seg": N, "fixed_iters": FIXED_ITERS, "parallelism": "shard%d" % world,
-                       "storage_dtype": args.dtype},
+                       "storage_dtype": cfg["dtype"], "kind": cfg["kind"], "devices": devices},
+            # bound "hbm" is the roofline BASELINE.json's north_star stipulates; the counters say the kernel is
+            # instruction-issue bound, which roofline_compute prices
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
-                         "kernel": "k_iterate_dyn (ticket-scheduled k_iterate)", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
-            "iters_per_step_rank0": iters_step, "best_cost": bc, "best_index": bidx, "gather_ms": gather_ms,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if traffic is None else traffic["traffic_bytes_per_launch"],
+                         "traffic_source": None if traffic is None else traffic["_file"],
+                         "peak_measured_copy": hbm_copy, "frac_of_measured_copy": None if not hbm_copy else achieved / hbm_copy,
+                         "kernel": "k_iterate_dyn (ticket-scheduled k_iterate)", "kernel_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "iters_per_step_rank0": iters_step, "gather": gather,
         }
-        if not args.no_cpu_baseline and world == 1:
-            sample = args.cpu_sample or max(512, 256 * usable_cpus())  # ~10-20 s of host work at ~0.8 k iter/s per thread
-            line["cpu_baseline"] = cpu_baseline(batch1.astype(np.float64), params, min(sample, B))
+        if sq is not None:
+            fl = sq["derived"]["f64_flops_per_ddp_iteration"]
+            tf = fl * (iters_step / (avg_ms * 1e-3)) / 1e12
+            line["roofline_compute"] = {"bound": "fp64 vector", "achieved_tflops_f64": tf, "peak": F64_VECTOR_PEAK_TF,
+                                        "frac": tf / F64_VECTOR_PEAK_TF, "valu_busy": sq["derived"]["valu_busy_frac_per_simd"],
+                                        "f64_arith_frac_of_valu": sq["derived"]["f64_arith_frac_of_valu"],
+                                        "valu_insts_per_ddp_iteration": sq["derived"]["valu_insts_per_ddp_iteration"],
+                                        "source": sq["_file"],
+                                        "note": "flops per DDP iteration counted by rocprofv3 (committed profile of this "
+                                                "workload, all 64 lanes of an instruction counted) x this run's kernel rate"}
+        if natural is not None:
+            line["natural_exit"] = natural
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line))
     s.close()
     if world > 1:

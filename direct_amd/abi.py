@@ -29,6 +29,8 @@ RTN_FEAS_OPT = 1
 RTN_FEAS_FOUND = 2
 RTN_NEG_TIME = -3
 RTN_BP_STUCK = -4
+RTN_INVALID = -100
+RTN_SCHED_ERROR = -101
 
 FIELD_X, FIELD_U, FIELD_S, FIELD_Y, FIELD_C = 0, 1, 2, 3, 4
 FIELD_KU, FIELD_KUU, FIELD_KS, FIELD_KY, FIELD_SCALARS = 5, 6, 7, 8, 9

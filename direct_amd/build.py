@@ -5,9 +5,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "direct_ddp.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "ddp_wave.h"), os.path.join(_HERE, "csrc", "ddp_tables.h"),
-        os.path.join(_HERE, "csrc", "traj_sample.h"),
-        os.path.join(_HERE, "..", "include", "direct_ddp.h")]
+import glob
+DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + [os.path.join(_HERE, "..", "include", "direct_ddp.h")]
 OUT = os.path.join(_HERE, "lib", "libdirect_ddp.so")
 
 # DDP_WAVES_*: occupancy target of the hot kernel (waves per SIMD; 3 <=> at most 168 VGPRs, matching the

@@ -906,7 +906,34 @@ struct Wave {
 
   // ---- setup (DDP:104-286) -----------------------------------------------------------------------
   DDP_DEV void begin() {
+    // Sizes are validated HERE, on the device: with device-resident inputs (DIRECT_MEM_DEVICE) the host
+    // never sees them, and an n_seg / n_planes outside the handle's configuration would index past every
+    // per-trajectory array (and past kInvP / L.pl).  A bad row is finished at once with DIRECT_RTN_INVALID.
     N = B.n_seg[b];
+    int bad_sizes = (N < 1 || N > B.nmax) ? 1 : 0;
+    if (!bad_sizes) {
+      PLV(int, badp);
+      LANES {
+        LV(badp) = 0;
+        for (int k = lane; k < N; k += 64) {
+          const int np = np_(k);
+          if (np < 1 || np > B.pmax || np > Lds::kPMax) LV(badp) = 1;
+        }
+      }
+      bad_sizes = WAVE_ANY(badp);
+    }
+    if (bad_sizes) {
+      N = 0;
+      LANES {
+        int* dst = (int*)&L.st;
+        for (int e = lane; e < (int)(sizeof(TrajState) / 4); e += 64) dst[e] = 0;
+      }
+      WSYNC();
+      st.rtn = -100;  // DIRECT_RTN_INVALID
+      st.done = 1;
+      st.line_failed = 1;
+      return;
+    }
     st.nseg = N;
     st.cur = 0;
     st.infeas = B.infeas_in ? (int)B.infeas_in[b] : 0;

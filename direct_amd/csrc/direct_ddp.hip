@@ -16,6 +16,7 @@
 #include "ddp_wave.h"
 #include "traj_sample.h"
 #include "corridor_io.h"
+#include "rccl_gather.h"
 
 using namespace direct;
 
@@ -71,7 +72,8 @@ struct Sched {
   int chunk;
 };
 // Draws the next ticket and waits for the previous chunk of its trajectory.  Returns the ticket, -1
-// when none are left, -2 when the ticket's trajectory has already finished (kDoneBit in done_epoch).  Out of line and free of early exits on purpose: inlined into the (huge) iterate
+// when none are left, -2 when the ticket's trajectory has already finished (kDoneBit in done_epoch),
+// -3 - b when the wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early exits on purpose: inlined into the (huge) iterate
 // loop the structuriser turned the nested uniform loops into exec-masked ones.
 __device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsigned total) {
   unsigned tv = 0;
@@ -87,7 +89,11 @@ __device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsig
     ready = (have >= e) ? 1 : 0;
     if (!ready) __builtin_amdgcn_s_sleep(32);
   }
-  if (!ready && threadIdx.x == 0) *S.err = 1;  // a scheduling bug: reported by direct_ddp_finish, never a hang
+  if (!ready) {  // a scheduling bug: never a hang, and never a chunk run on a trajectory whose previous chunk
+                 // may still be in flight elsewhere.  The flag is sticky until the next solve (direct_ddp.h).
+    if (threadIdx.x == 0) __hip_atomic_store(S.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return -3 - b;
+  }
   if (have >= kDoneBit) return -2;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return (int)t;
@@ -105,6 +111,10 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
     const int t = __builtin_amdgcn_readfirstlane(next_ticket(S, nb, total));
     if (t == -1) break;
     if (t == -2) continue;
+    if (t <= -3) {  // timed out: retire the trajectory so that its later tickets are skipped at once
+      if (threadIdx.x == 0) __hip_atomic_store(&S.done_epoch[-3 - t], kDoneBit | (int)n_epochs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
     const int e = __builtin_amdgcn_readfirstlane((int)((unsigned)t / nb));
     const int b = __builtin_amdgcn_readfirstlane(t - e * (int)nb);
     W.b = b;
@@ -134,11 +144,13 @@ __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
 }
 
 template <typename St, int RPL>
-__global__ __launch_bounds__(64) void k_finish(Batch<St> B, OutPtrs<St> O) {
+__global__ __launch_bounds__(64) void k_finish(Batch<St> B, OutPtrs<St> O, const int* sched_err) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   W.init_tables();
+  // a scheduler error makes the whole launch's results suspect: every row says so (direct_ddp.h)
+  if (__builtin_amdgcn_readfirstlane(*sched_err)) lds.st.rtn = -101;
   finish_wave(W, O);
 }
 
@@ -239,9 +251,13 @@ struct direct_ddp_handle_s {
   } o = {};
   int *best_idx = nullptr;
   double* best_cost = nullptr;
+  // config-5 gather (allocated on first use): [n_ranks] records, [n_ranks][nmax*19] blocks, winner, owner
+  void *g_recs = nullptr, *g_blocks = nullptr, *g_win = nullptr, *g_in = nullptr;
+  int g_ranks = 0;
   // dynamic scheduling of k_iterate_dyn: [0] ticket, [1] error flag, [2..] done_epoch[max_batch]
   int* sched = nullptr;
   int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device
+  int sched_chunk = 1;   // outer-loop trips per ticket (DIRECT_DDP_CHUNK at create time; experiments)
   bool dynamic = true;
   // current batch
   int B = 0;
@@ -322,9 +338,9 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.ticket = (unsigned*)h->sched;
       S.err = h->sched + 1;
       S.done_epoch = h->sched + 2;
-      S.chunk = 1;
-      if (const char* ev = getenv("DIRECT_DDP_CHUNK")) S.chunk = atoi(ev) > 0 ? atoi(ev) : 1;
-      (void)hipMemsetAsync(h->sched, 0, (size_t)(2 + h->B) * sizeof(int), h->stream);
+      S.chunk = h->sched_chunk;
+      (void)hipMemsetAsync(h->sched, 0, sizeof(int), h->stream);  // the error flag [1] is sticky: cleared in stage_inputs
+      (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);
       RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
     } else {
       RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n);
@@ -356,7 +372,7 @@ template <typename Real>
 static void launch_finish_t(direct_ddp_handle_t h, const direct_ddp_batch_out_t* out) {
   auto Bt = make_batch<Real>(h, h->cur_in, h->params);
   auto O = out_ptrs<Real>(h, out);
-  RPL_LAUNCH(h, k_finish, Real, h->B, Bt, O);
+  RPL_LAUNCH(h, k_finish, Real, h->B, Bt, O, (const int*)(h->sched + 1));
 }
 
 // direct_traj_sample_batch for one storage type: host arrays are staged through temporary device buffers
@@ -486,6 +502,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
   h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
                                             : resident_slots<float>(h, prop.multiProcessorCount);
+  if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
   if (const char* ev = getenv("DIRECT_DDP_SLOTS")) {  // experiments: fewer persistent waves than fit
     const int v = atoi(ev);
     if (v > 0 && v < h->sched_slots) h->sched_slots = v;
@@ -511,6 +528,8 @@ direct_status_t direct_ddp_destroy(direct_ddp_handle_t h) {
   (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->filt) (void)hipFree(h->filt);
+  for (void* q : {h->g_recs, h->g_blocks, h->g_win, h->g_in})
+    if (q) (void)hipFree(q);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -534,7 +553,8 @@ static direct_status_t check_params(const direct_ddp_params_t* p) {
 }
 
 // copy (or alias) the inputs into device memory and fill h->cur_in with device pointers
-static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in) {
+static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in,
+                                    bool fresh = true) {
   if (!h || !in) return fail(DIRECT_ERR_INVALID, "null argument");
   TRY(check_params(p));
   if (in->batch <= 0 || in->batch > h->max_batch) return fail(DIRECT_ERR_INVALID, "batch exceeds the handle's max_batch");
@@ -574,6 +594,8 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
     HIP_TRY(hipMemsetAsync(h->infeas_in, p->infeas ? 1 : 0, B, h->stream));
     d.infeas_in = h->infeas_in;
   }
+  // the scheduler-error flag is sticky within one API call (both phases of a plan) and cleared between calls
+  if (fresh) HIP_TRY(hipMemsetAsync(h->sched + 1, 0, sizeof(int), h->stream));
   d.mem = DIRECT_MEM_DEVICE;
   h->cur_in = d;
   h->params = *p;
@@ -667,7 +689,8 @@ direct_status_t direct_ddp_solve_batch(direct_ddp_handle_t h, const direct_ddp_p
 direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_params_t* p0, const direct_ddp_params_t* p1,
                                       const direct_ddp_batch_in_t* in, direct_ddp_batch_out_t* out0,
                                       direct_ddp_batch_out_t* out1) {
-  if (!h || !out1) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!h || !out1 || !in || !p0 || !p1) return fail(DIRECT_ERR_INVALID, "null argument");
+  TRY(check_params(p0));
   TRY(check_params(p1));
   // phase 0 (teach_repeat_planner.cpp:886-897): infeas = true for every problem
   direct_ddp_batch_in_t in0 = *in;
@@ -716,7 +739,7 @@ direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_pa
   in1.init_bez = nullptr;
   in1.init_poly = h->init_poly;
   in1.infeas_in = h->infeas_next;
-  TRY(stage_inputs(h, p1, &in1));
+  TRY(stage_inputs(h, p1, &in1, false));
   TRY(launch_begin(h));
   TRY(launch_iterate(h, p1->iter_max, 0));
   return launch_finish(h, out1);
@@ -775,6 +798,16 @@ direct_status_t direct_ddp_last_kernel_ms(direct_ddp_handle_t h, double* ms, int
   return DIRECT_OK;
 }
 
+direct_status_t direct_ddp_sched_error(direct_ddp_handle_t h, int32_t* flag) {
+  if (!h || !flag) return fail(DIRECT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, h->sched + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *flag = v;
+  return DIRECT_OK;
+}
+
 direct_status_t direct_ddp_best_cost(direct_ddp_handle_t h, int32_t mem, const void* cost, const int32_t* rtn,
                                      int32_t batch, int32_t* best_index, double* best_cost) {
   if (!h || !cost || !rtn || !best_index || !best_cost || batch <= 0 || batch > h->max_batch)
@@ -796,6 +829,121 @@ direct_status_t direct_ddp_best_cost(direct_ddp_handle_t h, int32_t mem, const v
   HIP_TRY(hipMemcpyAsync(best_index, h->best_idx, 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(best_cost, h->best_cost, 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return DIRECT_OK;
+}
+
+#define NCCL_TRY(expr)                                                                             \
+  do {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess)                                                                         \
+      return fail(DIRECT_ERR_DEVICE, std::string(#expr) + ": " + rccl_api().GetErrorString(r_));   \
+  } while (0)
+
+direct_status_t direct_rccl_unique_id(direct_rccl_id_t* id) {
+  static_assert(sizeof(direct_rccl_id_t) == sizeof(ncclUniqueId), "direct_rccl_id_t must mirror ncclUniqueId");
+  if (!id) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!rccl_api().ok) return fail(DIRECT_ERR_UNSUPPORTED, "librccl.so.1 not found");
+  NCCL_TRY(rccl_api().GetUniqueId((ncclUniqueId*)id));
+  return DIRECT_OK;
+}
+
+direct_status_t direct_rccl_comm_create(direct_ddp_handle_t h, const direct_rccl_id_t* id, int32_t n_ranks, int32_t rank,
+                                        void** comm) {
+  if (!h || !id || !comm || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(DIRECT_ERR_INVALID, "bad argument");
+  if (!rccl_api().ok) return fail(DIRECT_ERR_UNSUPPORTED, "librccl.so.1 not found");
+  HIP_TRY(hipSetDevice(h->device));
+  ncclComm_t c = nullptr;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  NCCL_TRY(rccl_api().CommInitRank(&c, n_ranks, uid, rank));
+  *comm = (void*)c;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_rccl_comm_destroy(void* comm) {
+  if (!comm) return DIRECT_OK;
+  if (!rccl_api().ok) return fail(DIRECT_ERR_UNSUPPORTED, "librccl.so.1 not found");
+  NCCL_TRY(rccl_api().CommDestroy((ncclComm_t)comm));
+  return DIRECT_OK;
+}
+
+extern "C++" {
+template <typename Real>
+static direct_status_t gather_best_t(direct_ddp_handle_t h, ncclComm_t comm, int n_ranks, int rank, const Real* cost,
+                                     const int32_t* rtn, const Real* bez, const Real* T, int batch, long long first,
+                                     Real* out_bez, Real* out_T) {
+  const int nm = h->nmax;
+  const size_t blk = (size_t)nm * 19;
+  hipLaunchKernelGGL(k_best<Real>, dim3(1), dim3(256), 0, h->stream, cost, rtn, batch, h->best_idx, h->best_cost);
+  hipLaunchKernelGGL(k_pack_best<Real>, dim3(8), dim3(256), 0, h->stream, h->best_idx, h->best_cost, first, rank, nm, bez, T,
+                     (BestRec*)h->g_recs, (Real*)h->g_blocks);
+  HIP_TRY(hipGetLastError());
+  // in-place all-gathers: every rank's send buffer is its own slot of the receive buffer
+  NCCL_TRY(rccl_api().AllGather((char*)h->g_recs + (size_t)rank * sizeof(BestRec), h->g_recs, sizeof(BestRec), ncclChar, comm,
+                                h->stream));
+  NCCL_TRY(rccl_api().AllGather((Real*)h->g_blocks + (size_t)rank * blk, h->g_blocks, blk * sizeof(Real), ncclChar, comm,
+                                h->stream));
+  hipLaunchKernelGGL(k_pick_best<Real>, dim3(8), dim3(256), 0, h->stream, (const BestRec*)h->g_recs, (const Real*)h->g_blocks,
+                     n_ranks, nm, (BestRec*)h->g_win, (int*)((char*)h->g_win + sizeof(BestRec)), out_bez, out_T);
+  HIP_TRY(hipGetLastError());
+  return DIRECT_OK;
+}
+}  // extern "C++"
+
+direct_status_t direct_ddp_gather_best(direct_ddp_handle_t h, void* nccl_comm, int32_t n_ranks, int32_t rank, int32_t mem,
+                                       const void* cost, const int32_t* rtn, const void* bez, const void* T, int32_t batch,
+                                       int64_t first_index, int64_t* best_index, double* best_cost, int32_t* owner_rank,
+                                       void* best_bez, void* best_T) {
+  if (!h || !nccl_comm || !cost || !rtn || !bez || !T || !best_index || !best_cost || batch <= 0 || batch > h->max_batch ||
+      n_ranks < 1 || rank < 0 || rank >= n_ranks)
+    return fail(DIRECT_ERR_INVALID, "bad argument");
+  if (!rccl_api().ok) return fail(DIRECT_ERR_UNSUPPORTED, "librccl.so.1 not found");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nm = h->nmax, r = h->rsz, blk = nm * 19 * r;
+  if (h->g_ranks < n_ranks) {  // (re)allocate the gather buffers for this communicator size
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (void** q : {&h->g_recs, &h->g_blocks, &h->g_win, &h->g_in})
+      if (*q) { (void)hipFree(*q); *q = nullptr; }
+    HIP_TRY(hipMalloc(&h->g_recs, (size_t)n_ranks * sizeof(BestRec)));
+    HIP_TRY(hipMalloc(&h->g_blocks, (size_t)n_ranks * blk));
+    HIP_TRY(hipMalloc(&h->g_win, sizeof(BestRec) + 16));
+    HIP_TRY(hipMalloc(&h->g_in, (size_t)h->max_batch * (nm * 19 * r + r + 4) + blk));
+    h->g_ranks = n_ranks;
+  }
+  const void *dc = cost, *db = bez, *dT = T;
+  const int32_t* dr = rtn;
+  void *ob = best_bez, *oT = best_T;
+  if (mem == DIRECT_MEM_HOST) {  // stage the host arrays
+    char* p = (char*)h->g_in;
+    auto up = [&](const void* src, size_t bytes) -> const void* {
+      void* d = p;
+      p += (bytes + 15) / 16 * 16;
+      return hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess ? d : nullptr;
+    };
+    dc = up(cost, (size_t)batch * r);
+    dr = (const int32_t*)up(rtn, (size_t)batch * 4);
+    db = up(bez, (size_t)batch * nm * 18 * r);
+    dT = up(T, (size_t)batch * nm * r);
+    if (!dc || !dr || !db || !dT) return fail(DIRECT_ERR_DEVICE, "staging copy failed");
+    ob = best_bez ? (void*)p : nullptr;
+    oT = best_T ? (void*)(p + nm * 18 * r) : nullptr;
+  }
+  if (h->dtype == DIRECT_F64)
+    TRY(gather_best_t<double>(h, (ncclComm_t)nccl_comm, n_ranks, rank, (const double*)dc, dr, (const double*)db,
+                              (const double*)dT, batch, (long long)first_index, (double*)ob, (double*)oT));
+  else
+    TRY(gather_best_t<float>(h, (ncclComm_t)nccl_comm, n_ranks, rank, (const float*)dc, dr, (const float*)db,
+                             (const float*)dT, batch, (long long)first_index, (float*)ob, (float*)oT));
+  struct { BestRec w; int owner; int pad; } res;
+  HIP_TRY(hipMemcpyAsync(&res, h->g_win, sizeof(BestRec) + 8, hipMemcpyDeviceToHost, h->stream));
+  if (mem == DIRECT_MEM_HOST) {
+    if (best_bez) HIP_TRY(hipMemcpyAsync(best_bez, ob, nm * 18 * r, hipMemcpyDeviceToHost, h->stream));
+    if (best_T) HIP_TRY(hipMemcpyAsync(best_T, oT, nm * r, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *best_index = res.w.index;
+  *best_cost = res.w.cost;
+  if (owner_rank) *owner_rank = res.owner;
   return DIRECT_OK;
 }
 

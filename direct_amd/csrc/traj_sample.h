@@ -62,7 +62,8 @@ __device__ __forceinline__ double sample_readlane(double v, int src) {
 template <typename St>
 __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int N = A.n_seg[b];
+  // n_seg is clamped to the array extent: with device-resident inputs nothing has validated it on the host
+  const int N = min(max(A.n_seg[b], 0), A.nmax);
   const St* Tb = A.T + (size_t)b * A.nmax;
   // a negative duration aborts the reference's loop before anything is published (TRP:1552-1555)
   int neg = 0;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
       len += dist;
       const int idx = base + lane;
       if (audit && valid) {  // the planes of a segment are the same for every lane: broadcast loads
-        const int np = A.n_planes[(size_t)b * A.nmax + i];
+        const int np = min(max(A.n_planes[(size_t)b * A.nmax + i], 0), A.pmax);
         const St* pq = A.planes + ((size_t)b * A.nmax + i) * A.pmax * 4;
         for (int q = 0; q < np; q++)
           cm = fmax(cm, (double)pq[4 * q] * p[0] + (double)pq[4 * q + 1] * p[1] + (double)pq[4 * q + 2] * p[2] + (double)pq[4 * q + 3]);

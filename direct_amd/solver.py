@@ -23,7 +23,8 @@ EXPORTS = (
     "direct_ddp_set_stream", "direct_ddp_solve_batch", "direct_ddp_plan_batch", "direct_time_allocation",
     "direct_ddp_begin", "direct_ddp_backward_pass", "direct_ddp_forward_pass", "direct_ddp_iterate",
     "direct_ddp_finish", "direct_ddp_get_field", "direct_ddp_set_field", "direct_ddp_last_kernel_ms",
-    "direct_ddp_best_cost", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
+    "direct_ddp_best_cost", "direct_ddp_sched_error", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
+    "direct_rccl_unique_id", "direct_rccl_comm_create", "direct_rccl_comm_destroy", "direct_ddp_gather_best",
     "direct_corridor_wire_size", "direct_corridor_pack", "direct_corridor_unpack", "direct_corridor_replay_batch",
 )
 
@@ -60,6 +61,13 @@ def lib():
         L.direct_ddp_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.direct_ddp_best_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p]
+        L.direct_ddp_sched_error.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_rccl_unique_id.argtypes = [C.c_void_p]
+        L.direct_rccl_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.direct_rccl_comm_destroy.argtypes = [C.c_void_p]
+        L.direct_ddp_gather_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.direct_traj_sample_batch.argtypes = [C.c_void_p] * 3
         L.direct_traj_sample_last_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.direct_time_allocation.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -231,6 +239,51 @@ class DdpSolver:
         ms = C.c_float()
         _check(lib().direct_traj_sample_last_ms(self.h, C.addressof(ms)))
         return ms.value
+
+    # -- config-5 reduction through the C entry points (RCCL) ------------------------------------
+    @staticmethod
+    def rccl_unique_id():
+        """128-byte ncclUniqueId (call on rank 0, ship to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        _check(lib().direct_rccl_unique_id(buf))
+        return buf.raw
+
+    def rccl_comm_create(self, uid, n_ranks, rank):
+        comm = C.c_void_p()
+        _check(lib().direct_rccl_comm_create(self.h, C.c_char_p(uid), n_ranks, rank, C.addressof(comm)))
+        return comm
+
+    @staticmethod
+    def rccl_comm_destroy(comm):
+        _check(lib().direct_rccl_comm_destroy(comm))
+
+    def gather_best(self, comm, n_ranks, rank, cost, rtn, bez, T, first_index, mem=abi.MEM_HOST, batch=None,
+                    out_bez=None, out_T=None):
+        """direct_ddp_gather_best.  Host mode: numpy arrays in, returns (index, cost, owner, bez, T) with numpy
+        outputs; device mode: raw pointers in (and optional raw output pointers), returns (index, cost, owner)."""
+        idx, val, owner = C.c_int64(), C.c_double(), C.c_int32()
+        if mem == abi.MEM_HOST:
+            cost = np.ascontiguousarray(cost, self.np_dtype)
+            rtn = np.ascontiguousarray(rtn, np.int32)
+            bez = np.ascontiguousarray(bez, self.np_dtype)
+            T = np.ascontiguousarray(T, self.np_dtype)
+            batch = cost.shape[0]
+            ob = np.zeros((self.n_seg_max, 18), self.np_dtype)
+            oT = np.zeros(self.n_seg_max, self.np_dtype)
+            _check(lib().direct_ddp_gather_best(self.h, comm, n_ranks, rank, mem, cost.ctypes.data, rtn.ctypes.data,
+                                                bez.ctypes.data, T.ctypes.data, batch, int(first_index), C.addressof(idx),
+                                                C.addressof(val), C.addressof(owner), ob.ctypes.data, oT.ctypes.data))
+            return idx.value, val.value, owner.value, ob, oT
+        _check(lib().direct_ddp_gather_best(self.h, comm, n_ranks, rank, mem, C.c_void_p(cost), C.c_void_p(rtn),
+                                            C.c_void_p(bez), C.c_void_p(T), int(batch), int(first_index), C.addressof(idx),
+                                            C.addressof(val), C.addressof(owner), C.c_void_p(out_bez), C.c_void_p(out_T)))
+        return idx.value, val.value, owner.value
+
+    def sched_error(self):
+        """Synchronise and read the sticky scheduler-error flag (include/direct_ddp.h)."""
+        v = C.c_int32()
+        _check(lib().direct_ddp_sched_error(self.h, C.addressof(v)))
+        return v.value
 
     def best_cost(self, cost, rtn, mem=abi.MEM_HOST, batch=None):
         """(index, cost) of the cheapest trajectory with rtn >= 0.  cost/rtn: numpy arrays or raw pointers."""

@@ -60,6 +60,9 @@ typedef enum { DIRECT_MEM_HOST = 0, DIRECT_MEM_DEVICE = 1 } direct_mem_t;
 #define DIRECT_RTN_FEAS_FOUND 2  /* phase 0: all c < 2e-4 */
 #define DIRECT_RTN_NEG_TIME (-3)
 #define DIRECT_RTN_BP_STUCK (-4)
+/* Extensions (no reference counterpart; both are < 0, so "rtn >= 0" keeps meaning "usable result"): */
+#define DIRECT_RTN_INVALID (-100)     /* this row's n_seg / n_planes lie outside [1, n_seg_max] / [1, p_max] */
+#define DIRECT_RTN_SCHED_ERROR (-101) /* the launch's ticket scheduler reported an error: results incomplete */
 
 /* By-value scalar arguments of polyCurveGeneration (ddp_optimizer.h:275-289). */
 typedef struct {
@@ -146,9 +149,23 @@ direct_status_t direct_ddp_set_stream(direct_ddp_handle_t h, void* hip_stream);
 
 /* One polyCurveGeneration per problem (replaces ddp_optimizer.cpp:5-438).  Blocks until
  * the results are in `out` when out->mem is host; with device memory the call returns
- * after enqueueing on the handle's stream. */
+ * after enqueueing on the handle's stream.
+ *
+ * Validation.  Scalars, pointers-not-NULL and the batch / n_seg_max / p_max fields are checked on the host
+ * for both memory kinds.  The CONTENTS of n_seg and n_planes are checked on the host for DIRECT_MEM_HOST
+ * (-> DIRECT_ERR_INVALID, nothing is launched) and ON THE DEVICE for DIRECT_MEM_DEVICE: a row whose sizes
+ * are out of range is not solved and reports rtn = DIRECT_RTN_INVALID (its other outputs are zero).
+ * Nothing else about device arrays (extents, finiteness of the reals) can be or is validated.
+ *
+ * Scheduler errors.  The ticket scheduler's spin limit (a scheduling bug, never expected) sets a sticky
+ * per-handle flag: it is cleared when a solve / plan / begin call starts, makes every host-memory finish
+ * return DIRECT_ERR_DEVICE, makes the finish kernel write rtn = DIRECT_RTN_SCHED_ERROR for every row of a
+ * device-memory result, and can be polled with direct_ddp_sched_error(). */
 direct_status_t direct_ddp_solve_batch(direct_ddp_handle_t h, const direct_ddp_params_t* params,
                                        const direct_ddp_batch_in_t* in, direct_ddp_batch_out_t* out);
+
+/* Synchronises the handle's stream and reads the sticky scheduler-error flag (see above). */
+direct_status_t direct_ddp_sched_error(direct_ddp_handle_t h, int32_t* flag);
 
 /* fastTrajPlanning's protocol (teach_repeat_planner.cpp:886-921) for a batch: phase 0
  * (params0: zero init, infeasible start), UpdateTime where rtn0 == 2, phase 1 (params1) from
@@ -275,6 +292,31 @@ direct_status_t direct_ddp_last_kernel_ms(direct_ddp_handle_t h, double* ms, int
 direct_status_t direct_ddp_best_cost(direct_ddp_handle_t h, int32_t mem, const void* cost,
                                      const int32_t* rtn, int32_t batch, int32_t* best_index,
                                      double* best_cost);
+
+/* ---- config-5 reduction across the GPUs of one node, for a C / C++ host ---------------------------
+ * No reference counterpart (the reference is one process, no collectives); specified by BASELINE.json
+ * configs[4] and SURVEY.md 8(e): one process (or thread) per GPU, each with its own handle, solves its shard
+ * [first_index, first_index + batch) with no exchange; then ONE ncclAllGather of (cost, global index) and ONE
+ * of every rank's local-best block put the cheapest trajectory with rtn >= 0 on every rank.  RCCL is resolved
+ * at run time (librccl.so.1); DIRECT_ERR_UNSUPPORTED when it cannot be found.
+ *
+ *   direct_rccl_id_t id;  if (rank == 0) direct_rccl_unique_id(&id);   // ship the 128 bytes to the other ranks
+ *   void* comm;  direct_rccl_comm_create(h, &id, n_ranks, rank, &comm); // ncclCommInitRank on h's device
+ *   direct_ddp_solve_batch(h, &params, &in, &out);                      // out->mem may be device
+ *   direct_ddp_gather_best(h, comm, n_ranks, rank, out.mem, out.cost, out.rtn, out.bez, out.T, batch, first, ...);
+ * `comm` is an ncclComm_t; a communicator the host created itself with ncclCommInitRank is equally valid. */
+typedef struct { char internal[128]; } direct_rccl_id_t; /* = ncclUniqueId */
+direct_status_t direct_rccl_unique_id(direct_rccl_id_t* id);
+direct_status_t direct_rccl_comm_create(direct_ddp_handle_t h, const direct_rccl_id_t* id, int32_t n_ranks,
+                                        int32_t rank, void** comm);
+direct_status_t direct_rccl_comm_destroy(void* comm);
+/* cost[batch], rtn[batch], bez[batch][n_seg_max][18], T[batch][n_seg_max] as written by solve/plan (memory kind
+ * `mem`).  Results: best_index (global, -1 if no rank has a feasible trajectory), best_cost, owner_rank on the
+ * host; best_bez[n_seg_max][18], best_T[n_seg_max] (may be NULL) in memory kind `mem`.  Blocks until done. */
+direct_status_t direct_ddp_gather_best(direct_ddp_handle_t h, void* nccl_comm, int32_t n_ranks, int32_t rank,
+                                       int32_t mem, const void* cost, const int32_t* rtn, const void* bez,
+                                       const void* T, int32_t batch, int64_t first_index, int64_t* best_index,
+                                       double* best_cost, int32_t* owner_rank, void* best_bez, void* best_T);
 
 #ifdef __cplusplus
 }

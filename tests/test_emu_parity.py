@@ -151,3 +151,20 @@ def test_many_planes_per_polytope(p_max):
     o, _ = refapi.solve_batch(p0, batch)
     assert (g.rtn == o.rtn).all() and (g.iter_used == o.iter_used).all()
     assert np.abs(g.cost / o.cost - 1).max() < 1e-8
+
+
+def test_emulated_begin_rejects_bad_sizes_row_by_row():
+    """begin() validates n_seg / n_planes itself (device-resident inputs never pass the host's checks): bad
+    rows finish at once with DIRECT_RTN_INVALID and zero outputs, good rows are solved as if alone."""
+    batch = problems.make_batch("corridor", 6, 5, seed=9)
+    p0 = abi.phase0_params()
+    want = emuapi.solve_batch(p0, batch)
+    bad = abi.HostBatch(batch.n_seg.copy(), batch.x0, batch.xd, batch.T0, batch.n_planes.copy(), batch.planes, seeds=batch.seeds)
+    bad.n_seg[1] = 0
+    bad.n_seg[2] = 9
+    bad.n_planes[4, 3] = batch.p_max + 1
+    got = emuapi.solve_batch(p0, bad)
+    rows = np.array([1, 2, 4])
+    assert (got.rtn[rows] == abi.RTN_INVALID).all() and not got.bez[rows].any() and not got.T[rows].any()
+    for i in (0, 3, 5):
+        assert got.rtn[i] == want.rtn[i] and np.array_equal(got.bez[i], want.bez[i])

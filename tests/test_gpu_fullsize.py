@@ -38,6 +38,7 @@ def poly_eval(poly, T, order):
 
 def check_properties(batch, res, fp_tol):
     n = batch.n_seg_max
+    B = batch.batch
     ok = res.rtn >= 0
     assert ok.mean() > 0.85
     # continuity of position / velocity / acceleration across segments = the dynamics roll-out

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Refreshes the judged artifacts of a round on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/rNN_bench.json               python bench.py
+#   gpurun_out/rNN_bench.json               python bench.py   (the line the driver will reproduce)
 #   gpurun_out/rNN_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/rNN_{fetch,write}_size_k_iterate.csv + rNN_hbm_traffic.json   separate --pmc passes
-# Copy the files into profiles/ afterwards.  usage: tools/profile_round.sh r01
-R=${1:-r01}
+#   gpurun_out/rNN_hbm_calib.json           tools/hbm_calib: counter calibration for dword streams + measured HBM peak
+#   gpurun_out/rNN_sq_counters.json, rNN_hbm_traffic.json   separate --pmc passes over tools/prof_one.py (same workload)
+# Copy the files into profiles/ afterwards.  usage: tools/profile_round.sh r02 [quick]
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -12,26 +13,23 @@ cd $ROOT
 python bench.py > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$ROOT
-rm -rf /tmp/prof_stats /tmp/prof_f /tmp/prof_w
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python $ROOT/bench.py --no-cpu-baseline > $OUT/${R}_stats_run.log 2>&1
+rm -rf /tmp/prof_stats /tmp/pmc /tmp/cal_f /tmp/cal_w
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python $ROOT/bench.py --no-cpu-baseline --no-secondary > $OUT/${R}_stats_run.log 2>&1
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_f -o f -- python $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 1 > $OUT/${R}_fetch_run.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -o w -- python $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 1 > $OUT/${R}_write_run.log 2>&1
-python - $R $OUT <<'PY'
-import csv, glob, json, sys
-R, OUT = sys.argv[1], sys.argv[2]
-res = {}
-for tag, d, name in (("FETCH_SIZE", "/tmp/prof_f", "fetch"), ("WRITE_SIZE", "/tmp/prof_w", "write")):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "k_iterate" in r["Kernel_Name"] and r["Counter_Name"] == tag]
-    keep = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "VGPR_Count", "LDS_Block_Size", "Scratch_Size"]
-    keep = [k for k in keep if k in rows[0]]
-    with open("%s/%s_%s_size_k_iterate.csv" % (OUT, R, name), "w") as g:
-        w = csv.writer(g); w.writerow(keep)
-        for r in rows: w.writerow([r[k] for k in keep])
-    vals = [float(r["Counter_Value"]) for r in rows]
-    big = [v for v in vals if v > 0.5 * max(vals)]  # the timed workload launches (the phase-0 launch is much smaller)
-    res[tag] = {"per_dispatch_kb": vals, "workload_mean_kb": sum(big) / len(big)}
-json.dump(res, open("%s/%s_hbm_traffic.json" % (OUT, R), "w"), indent=1)
-print(json.dumps({k: v["workload_mean_kb"] for k, v in res.items()}))
-PY
+# counter calibration + measured peak
+$ROOT/tools/hbm_calib > $OUT/${R}_hbm_calib_plain.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/cal_f -o f -- $ROOT/tools/hbm_calib > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/cal_w -o w -- $ROOT/tools/hbm_calib > /dev/null 2>&1
+python $ROOT/tools/hbm_calib_collect.py /tmp/cal_f /tmp/cal_w $OUT/${R}_hbm_calib_plain.log $OUT/${R}
+# PMC passes over the workload (no torch in the process: a pass is ~10 s)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_BRANCH" \
+           "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc/p$i -o pmc -- python $ROOT/tools/prof_one.py free f32 4096 100 20 > $OUT/${R}_pmc_run$i.log 2>&1
+done
+python $ROOT/tools/pmc_collect.py /tmp/pmc $OUT/${R} free f32 4096 100 20
