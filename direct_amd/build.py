@@ -5,8 +5,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "direct_ddp.hip")
+SRC_CLUSTER = os.path.join(_HERE, "csrc", "direct_cluster.hip")  # corridor-cluster generation (include/direct_cluster.h)
 import glob
-DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + [os.path.join(_HERE, "..", "include", "direct_ddp.h")]
+DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + sorted(glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
 OUT = os.path.join(_HERE, "lib", "libdirect_ddp.so")
 
 # DDP_WAVES_*: occupancy target of the hot kernel (waves per SIMD; 3 <=> at most 168 VGPRs, matching the
@@ -28,7 +29,7 @@ def build(force=False, extra_flags=()):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + [SRC, "-o", OUT]
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + [SRC, SRC_CLUSTER, "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 

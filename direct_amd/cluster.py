@@ -1,0 +1,98 @@
+"""Python binding of the corridor-cluster generator of libdirect_ddp.so (include/direct_cluster.h) for tests and
+tools.  Mirrors cudaPolytopeGeneration's calling protocol (polyhedron_generator/include/polyhedron_generator/
+cluster_server_cpu.h:54-74): paramSet -> ClusterGenerator(...), setObs/mapUpload -> set_map, polygonGeneration ->
+polygon_generation (for a batch of seed voxels).  No CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, solver
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32), ("max_z", C.c_int32),
+                ("max_batch", C.c_int32), ("cluster_capacity", C.c_int32), ("candidate_capacity", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+EXPORTS = ("direct_cluster_create", "direct_cluster_destroy", "direct_cluster_last_error", "direct_cluster_set_map",
+           "direct_cluster_polygon_generation_batch", "direct_cluster_convex_test", "direct_cluster_last_ms")
+CLUSTER_OK, CLUSTER_OVERFLOW, CLUSTER_BAD_SEED = 0, 1, 2
+_BOUND = False
+
+
+def _lib():
+    global _BOUND
+    L = solver.lib()
+    if not _BOUND:
+        L.direct_cluster_last_error.restype = C.c_char_p
+        L.direct_cluster_create.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_cluster_destroy.argtypes = [C.c_void_p]
+        L.direct_cluster_set_map.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.direct_cluster_polygon_generation_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                                               C.c_int32] + [C.c_void_p] * 5
+        L.direct_cluster_convex_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        L.direct_cluster_last_ms.argtypes = [C.c_void_p, C.c_void_p]
+        _BOUND = True
+    return L
+
+
+def _check(st):
+    if st != abi.DIRECT_OK:
+        raise solver.DirectError(st, _lib().direct_cluster_last_error().decode())
+
+
+class ClusterGenerator:
+    def __init__(self, dims, max_batch=64, cluster_capacity=50000, candidate_capacity=10000, device=0):
+        self.dims = tuple(int(d) for d in dims)
+        self.max_batch, self.ccap, self.kcap = int(max_batch), int(cluster_capacity), int(candidate_capacity)
+        cfg = Config(device, self.dims[0], self.dims[1], self.dims[2], self.max_batch, self.ccap, self.kcap, 0)
+        h = C.c_void_p()
+        _check(_lib().direct_cluster_create(C.addressof(cfg), C.addressof(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib().direct_cluster_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_map(self, grid):
+        g = np.ascontiguousarray(grid, np.uint8)
+        assert g.shape == self.dims
+        _check(_lib().direct_cluster_set_map(self.h, abi.MEM_HOST, g.ctypes.data))
+
+    def polygon_generation(self, seeds, itr_inflate_max=1000, itr_cluster_max=50):
+        """-> dict(vertex_idx [B][24], clusters: list of [n][3] arrays, cluster_num, iters, rtn)"""
+        seeds = np.ascontiguousarray(seeds, np.int32).reshape(-1, 3)
+        B = seeds.shape[0]
+        v = np.zeros((B, 24), np.int32)
+        cl = np.zeros((B, self.ccap, 3), np.int32)
+        n, it, rtn = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        _check(_lib().direct_cluster_polygon_generation_batch(self.h, B, seeds.ctypes.data, int(itr_inflate_max),
+                                                              int(itr_cluster_max), abi.MEM_HOST, v.ctypes.data,
+                                                              cl.ctypes.data, n.ctypes.data, it.ctypes.data, rtn.ctypes.data))
+        return dict(vertex_idx=v, clusters=[cl[b, :n[b]].copy() for b in range(B)], cluster_num=n, iters=it, rtn=rtn)
+
+    def convex_test(self, inside, cand, cluster):
+        """-> (can_clu [n], can_can packed lower triangle [n(n-1)/2], accept [n]), uint8 each"""
+        inside = np.ascontiguousarray(inside, np.uint8)
+        cand = np.ascontiguousarray(cand, np.int32).reshape(-1, 3)
+        cluster = np.ascontiguousarray(cluster, np.int32).reshape(-1, 3)
+        n = cand.shape[0]
+        clu, acc = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        cc = np.zeros(max(n * (n - 1) // 2, 1), np.uint8)
+        _check(_lib().direct_cluster_convex_test(self.h, inside.ctypes.data, n, cand.ctypes.data, cluster.shape[0],
+                                                 cluster.ctypes.data, clu.ctypes.data, cc.ctypes.data, acc.ctypes.data))
+        return clu, cc[:n * (n - 1) // 2], acc
+
+    def last_ms(self):
+        ms = C.c_float()
+        _check(_lib().direct_cluster_last_ms(self.h, C.addressof(ms)))
+        return ms.value

@@ -1,0 +1,626 @@
+// Corridor-cluster generation on gfx950 (include/direct_cluster.h).
+//
+// Replaces cudaPolytopeGeneration::polygonGeneration of the reference's SHIPPED CPU build
+// (polyhedron_generator/src/cluster_server_cpu.cpp:394-528, "CS") for a batch of seed voxels, bit for bit:
+//   cubeInflation_cpu    CS:257-293  -> k_inflate   (one workgroup per seed runs ALL rounds and directions on the
+//                                       device; the reference's CUDA twin paraCubeInflation, cluster_engine.cu:185-350,
+//                                       pays one H2D + launch + D2H per direction per round and reduces through a
+//                                       racy single bool; here a face is reduced with __syncthreads_or)
+//   getVoxelsInCube + surface extraction CS:62-81, 441-506 -> k_inflate (ordered block-scan compaction)
+//   candidate generation CS:301-353  -> k_mark + k_compact (first-discoverer order reproduced with an atomicMin
+//                                       of the discovery key per voxel, then an ordered compaction)
+//   serialConvexTest     cluster_engine_cpu.cpp:31-136 -> k_convex (one workgroup per candidate, one lane per
+//                                       target ray; float DDA exactly as the reference's; a candidate blocked by a
+//                                       cluster voxel stops at once)
+//   the sequential accept loop CS:360-384 -> k_resolve (one wave; bit-matrix of candidate-candidate rays, the
+//                                       device form of paraResultCheck's packed triangle, cluster_engine.cu:37-67)
+// Integer / byte work, HBM- and L2-bound: no MFMA anywhere.  Flag bytes of a seed's grid: bit0 use_data,
+// bit1 invalid_data, bit2 inside_data, bit3 map_data == 1 (one load per DDA step instead of two).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/direct_cluster.h"
+
+namespace {
+
+constexpr uint8_t F_USE = 1, F_INVALID = 2, F_INSIDE = 4, F_OBS = 8;
+constexpr int KEY_NONE = 0x7f7f7f7f;
+constexpr int kDimLimit = 1024;  // voxels are packed as x << 20 | y << 10 | z
+
+__device__ __forceinline__ int pack3(int x, int y, int z) { return (x << 20) | (y << 10) | z; }
+__device__ __forceinline__ int px(int p) { return p >> 20; }
+__device__ __forceinline__ int py(int p) { return (p >> 10) & 1023; }
+__device__ __forceinline__ int pz(int p) { return p & 1023; }
+
+struct Elem {  // per-seed counters, device resident
+  int n_cluster, n_active, n_cand, iters, live, rtn, pad0, pad1;
+  int vertex[24];
+};
+
+struct Dev {
+  int max_x, max_y, max_z, max_yz, G;
+  int ccap, kcap, kwords;  // cluster / candidate capacity, 64-bit words per candidate row
+  const uint8_t* map;      // [G]
+  uint8_t* flags;          // [batch][G]
+  int* key;                // [batch][G]
+  int *cluster, *active;   // [batch][ccap] packed voxels
+  int* cand;               // [batch][kcap]
+  uint8_t *can_clu, *accept;        // [batch][kcap]
+  unsigned long long* blocked;      // [batch][kcap][kwords]
+  Elem* el;                // [batch]
+};
+
+// ---- flags <- map ---------------------------------------------------------------------------------------
+__global__ void k_flags_init(Dev D, const uint8_t* inside /* or null */) {
+  const size_t e = blockIdx.y;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)D.G; i += (size_t)gridDim.x * blockDim.x) {
+    uint8_t f = D.map[i] == 1 ? F_OBS : 0;
+    if (inside && inside[i] == 1) f |= F_INSIDE;
+    D.flags[e * D.G + i] = f;
+    D.key[e * D.G + i] = KEY_NONE;
+  }
+}
+
+// exclusive position of `flag` among the flags of a 256-thread block + the block total (ordered compaction)
+__device__ __forceinline__ int block_scan256(int flag, int* total, int* wsum /* shared[4] */) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int pos = __popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) wsum[w] = __popcll(m);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int q = 0; q < 4; q++) {
+    if (q < w) base += wsum[q];
+    tot += wsum[q];
+  }
+  *total = tot;
+  return base + pos;
+}
+
+// ---- cube inflation + initial surface cluster (CS:257-293, 400-518) ---------------------------------------
+__global__ __launch_bounds__(256) void k_inflate(Dev D, const int* seeds, int itr_inflate_max) {
+  __shared__ int v[24], vl[24], wsum[4];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  Elem* E = &D.el[e];
+  uint8_t* fl = D.flags + (size_t)e * D.G;
+  const int sx = seeds[3 * e], sy = seeds[3 * e + 1], sz = seeds[3 * e + 2];
+  if (sx < 0 || sx >= D.max_x || sy < 0 || sy >= D.max_y || sz < 0 || sz >= D.max_z) {
+    if (tid == 0) {
+      E->n_cluster = E->n_active = E->n_cand = E->iters = E->live = 0;
+      E->rtn = DIRECT_CLUSTER_BAD_SEED;
+      for (int q = 0; q < 24; q++) E->vertex[q] = 0;
+    }
+    return;
+  }
+  if (tid < 8) { v[tid] = vl[tid] = sx; v[tid + 8] = vl[tid + 8] = sy; v[tid + 16] = vl[tid + 16] = sz; }  // CS:400-408
+  __syncthreads();
+  const int step = 1;  // inf_step, CS:117
+  for (int iter = 0; iter < itr_inflate_max; iter++) {
+    for (int dir = 0; dir < 6; dir++) {  // Y-, Y+, X-, X+, Z-, Z+ (CS:263-268)
+      // the face slab one voxel beyond the cube: ranges (a, b) and the fixed coordinate, per CS:126-255
+      int a0, a1, b0, b1, fixed, edge;
+      switch (dir) {
+        case 0: edge = v[8] == 0;            fixed = v[8] - 1;  a0 = v[3]; a1 = v[0]; b0 = v[20]; b1 = v[16]; break;
+        case 1: edge = v[9] == D.max_y - 1;  fixed = v[9] + 1;  a0 = v[2]; a1 = v[1]; b0 = v[21]; b1 = v[17]; break;
+        case 2: edge = v[3] == 0;            fixed = v[3] - 1;  a0 = v[11]; a1 = v[10]; b0 = v[23]; b1 = v[19]; break;
+        case 3: edge = v[0] == D.max_x - 1;  fixed = v[0] + 1;  a0 = v[8]; a1 = v[9]; b0 = v[20]; b1 = v[16]; break;
+        case 4: edge = v[20] == 0;           fixed = v[20] - 1; a0 = v[7]; a1 = v[4]; b0 = v[12]; b1 = v[13]; break;
+        default: edge = v[16] == D.max_z - 1; fixed = v[16] + 1; a0 = v[3]; a1 = v[0]; b0 = v[8]; b1 = v[9]; break;
+      }
+      int hit = 0;
+      if (!edge) {
+        const int nb = b1 - b0 + 1, cells = (a1 - a0 + 1) * nb;
+        for (int c = tid; c < cells; c += 256) {
+          const int a = a0 + c / nb, b = b0 + c % nb;
+          int id;
+          if (dir < 2) id = a * D.max_yz + fixed * D.max_z + b;        // (x, fixed y, z)
+          else if (dir < 4) id = fixed * D.max_yz + a * D.max_z + b;   // (fixed x, y, z)
+          else id = a * D.max_yz + b * D.max_z + fixed;                // (x, y, fixed z)
+          hit |= D.map[id] > 0;
+        }
+      }
+      const int blocked = __syncthreads_or(hit);
+      if (tid == 0 && !edge && !blocked) {
+        switch (dir) {
+          case 0: v[8] -= step; v[11] -= step; v[12] -= step; v[15] -= step; break;
+          case 1: v[9] += step; v[10] += step; v[13] += step; v[14] += step; break;
+          case 2: v[2] -= step; v[3] -= step; v[6] -= step; v[7] -= step; break;
+          case 3: v[0] += step; v[1] += step; v[4] += step; v[5] += step; break;
+          case 4: v[20] -= step; v[21] -= step; v[22] -= step; v[23] -= step; break;
+          default: v[16] += step; v[17] += step; v[18] += step; v[19] += step; break;
+        }
+      }
+      __syncthreads();
+    }
+    const int changed = __syncthreads_or(tid < 24 ? (v[tid] != vl[tid]) : 0);  // CS:270-281
+    if (!changed) break;
+    if (tid < 24) vl[tid] = v[tid];
+    __syncthreads();
+  }
+  if (tid < 24) E->vertex[tid] = v[tid];
+  // getVoxelsInCube (CS:62-81) and the surface cells (CS:441-489), in x, y, z order
+  const int x0 = v[7], x1 = v[1], y0 = v[15], y1 = v[9], z0 = v[23], z1 = v[17];
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+  const long ncube = (long)nx * ny * nz;
+  int* cl = D.cluster + (size_t)e * D.ccap;
+  int* ac = D.active + (size_t)e * D.ccap;
+  int n_out = 0, overflow = 0;
+  if (ncube == 1) {  // CS:433-439: the cell is its own surface; use_data is NOT set on this branch
+    if (tid == 0) cl[0] = ac[0] = pack3(x0, y0, z0);
+    n_out = 1;
+  } else {
+    for (long base = 0; base < ncube; base += 256) {
+      const long c = base + tid;
+      int surf = 0, p = 0;
+      if (c < ncube) {
+        const int x = x0 + (int)(c / ((long)ny * nz)), r = (int)(c % ((long)ny * nz)), y = y0 + r / nz, z = z0 + r % nz;
+        p = pack3(x, y, z);
+        // a cell is interior iff all 26 neighbours lie in the cube (and hence in the map): strictly inside the box
+        surf = x == x0 || x == x1 || y == y0 || y == y1 || z == z0 || z == z1;
+        const int id = x * D.max_yz + y * D.max_z + z;
+        fl[id] = (fl[id] & F_OBS) | F_USE | (surf ? 0 : F_INSIDE);  // CS:447, 76, 491-494
+      }
+      int tot;
+      const int pos = block_scan256(surf, &tot, wsum);
+      if (surf) {
+        if (n_out + pos < D.ccap) cl[n_out + pos] = ac[n_out + pos] = p;
+        else overflow = 1;
+      }
+      n_out += tot;
+      __syncthreads();
+    }
+  }
+  overflow = __syncthreads_or(overflow);
+  if (tid == 0) {
+    const int degenerate = x0 == x1 || y0 == y1 || z0 == z1;  // CS:509-518
+    E->n_cluster = E->n_active = overflow ? D.ccap : n_out;
+    E->n_cand = 0;
+    E->iters = 0;
+    E->rtn = overflow ? DIRECT_CLUSTER_OVERFLOW : DIRECT_CLUSTER_OK;
+    E->live = (!overflow && !degenerate) ? 1 : 0;
+  }
+}
+
+// ---- candidate generation (CS:301-353) -------------------------------------------------------------------
+// discovery key of (active voxel a, neighbour n): the order in which the sequential loop would reach it
+__device__ __forceinline__ int neighbour_id(const Dev& D, int p, int n, int* packed) {
+  const int q = n < 13 ? n : n + 1;  // 27 offsets without the centre, dx outermost (CS:315-319)
+  const int x = px(p) + q / 9 - 1, y = py(p) + (q / 3) % 3 - 1, z = pz(p) + q % 3 - 1;
+  if (x < 0 || x > D.max_x - 1 || y < 0 || y > D.max_y - 1 || z < 0 || z > D.max_z - 1) return -1;
+  *packed = pack3(x, y, z);
+  return x * D.max_yz + y * D.max_z + z;
+}
+__global__ void k_mark(Dev D) {
+  const int e = blockIdx.y;
+  const Elem* E = &D.el[e];
+  if (!E->live) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= E->n_active * 26) return;
+  int p;
+  const int id = neighbour_id(D, D.active[(size_t)e * D.ccap + t / 26], t % 26, &p);
+  // map == 1 || use || invalid || inside -> skip (CS:332-338): all four are bits of the one flag byte
+  if (id >= 0 && D.flags[(size_t)e * D.G + id] == 0) atomicMin(&D.key[(size_t)e * D.G + id], t);
+}
+__global__ __launch_bounds__(256) void k_compact(Dev D) {
+  __shared__ int wsum[4];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  Elem* E = &D.el[e];
+  if (!E->live) return;
+  const int total = E->n_active * 26;
+  int n_out = 0, overflow = 0;
+  for (int base = 0; base < total; base += 256) {
+    const int t = base + tid;
+    int first = 0, p = 0, id = -1;
+    if (t < total) {
+      id = neighbour_id(D, D.active[(size_t)e * D.ccap + t / 26], t % 26, &p);
+      first = id >= 0 && D.key[(size_t)e * D.G + id] == t;
+    }
+    int tot;
+    const int pos = block_scan256(first, &tot, wsum);
+    if (first) {
+      D.key[(size_t)e * D.G + id] = KEY_NONE;
+      D.flags[(size_t)e * D.G + id] |= F_USE;  // CS:347
+      if (n_out + pos < D.kcap) D.cand[(size_t)e * D.kcap + n_out + pos] = p;
+      else overflow = 1;
+    }
+    n_out += tot;
+    __syncthreads();
+  }
+  overflow = __syncthreads_or(overflow);
+  if (tid == 0) {
+    E->n_cand = overflow ? 0 : n_out;
+    if (overflow) { E->rtn = DIRECT_CLUSTER_OVERFLOW; E->live = 0; }
+    else if (n_out == 0) E->live = 0;  // CS:356-357
+  }
+}
+
+// ---- serialConvexTest, one ray (cluster_engine_cpu.cpp:44-131).  Returns 1 when an obstacle blocks it. -------
+__device__ __forceinline__ float intbound_half(int ds) {
+  // intbound_cpu(0.5, ds), cluster_engine_cpu.cpp:13-29: mod(+-0.5, 1) is 0.5 for either sign, so the value is
+  // 0.5f / |ds| in float; computed in double and rounded once, which is the correctly rounded float quotient
+  if (ds == 0) return INFINITY;  // numeric_limits<double>::max() returned through float
+  return (float)(0.5 / (double)(ds < 0 ? -ds : ds));
+}
+__device__ __forceinline__ int ray_blocked(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
+  const int ex = px(target), ey = py(target), ez = pz(target);
+  if (fl[ex * D.max_yz + ey * D.max_z + ez] & F_INSIDE) return 0;  // only targets with inside_data == 0 are traced
+  const int mx = cx / 2 + (ex >> 1), my = cy / 2 + (ey >> 1), mz = cz / 2 + (ez >> 1);
+  if (fl[mx * D.max_yz + my * D.max_z + mz] & F_INSIDE) return 0;  // "midpoint" inside the cube: skipped
+  int x = cx, y = cy, z = cz;
+  const int dx = ex - x, dy = ey - y, dz = ez - z;
+  const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0), sz = (dz > 0) - (dz < 0);
+  float tMaxX = intbound_half(dx), tMaxY = intbound_half(dy), tMaxZ = intbound_half(dz);
+  // tDelta = ((float)step) / d: 1 / |d| correctly rounded, NaN (0 / 0) for d == 0 - never added: tMax stays +inf
+  const float tDX = dx ? (float)(1.0 / (double)(dx < 0 ? -dx : dx)) : 0.0f;
+  const float tDY = dy ? (float)(1.0 / (double)(dy < 0 ? -dy : dy)) : 0.0f;
+  const float tDZ = dz ? (float)(1.0 / (double)(dz < 0 ? -dz : dz)) : 0.0f;
+  int budget = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) + (dz < 0 ? -dz : dz);
+  for (;;) {
+    if (tMaxX < tMaxY) {
+      if (tMaxX < tMaxZ) { x += sx; tMaxX += tDX; }
+      else               { z += sz; tMaxZ += tDZ; }
+    } else {
+      if (tMaxY < tMaxZ) { y += sy; tMaxY += tDY; }
+      else               { z += sz; tMaxZ += tDZ; }
+    }
+    if (x == ex && y == ey && z == ez) return 0;
+    // each axis makes exactly |d| steps before the end voxel is reached; a ray that float rounding made miss its
+    // end would leave the map (the reference then reads outside its arrays): cut off, reported as clear
+    if (--budget < 0) return 0;
+    const uint8_t f = fl[x * D.max_yz + y * D.max_z + z];
+    if (f & F_INSIDE) return 0;
+    if (f & F_OBS) return 1;
+  }
+}
+
+// one workgroup per candidate.  full = 1 (kernel-level parity entry point): no early exit, every row is complete
+__global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
+  const int e = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  const Elem* E = &D.el[e];
+  if (!E->live || i >= E->n_cand) return;
+  const uint8_t* fl = D.flags + (size_t)e * D.G;
+  const int* cl = D.cluster + (size_t)e * D.ccap;
+  const int* cd = D.cand + (size_t)e * D.kcap;
+  const int c = cd[i], cx = px(c), cy = py(c), cz = pz(c), n_clu = E->n_cluster;
+  int bad = 0;
+  for (int base = 0; base < n_clu; base += 256) {
+    const int t = base + tid;
+    if (t < n_clu) bad |= ray_blocked(D, fl, cx, cy, cz, cl[t]);
+    if (!full && __syncthreads_or(bad)) {  // a rejected candidate's rays towards other candidates are never consulted
+      if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = 0;
+      return;
+    }
+  }
+  bad = __syncthreads_or(bad);
+  if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = bad ? 0 : 1;
+  if (bad && !full) return;
+  unsigned long long* row = D.blocked + ((size_t)e * D.kcap + i) * D.kwords;
+  for (int base = 0; base < i; base += 256) {  // rays towards the candidates before this one
+    const int j = base + tid;
+    const int b = j < i ? ray_blocked(D, fl, cx, cy, cz, cd[j]) : 0;
+    const unsigned long long m = __ballot(b);
+    if ((tid & 63) == 0 && base + (tid & ~63) < i) row[(base + tid) >> 6] = m;
+  }
+}
+
+// the sequential accept loop (CS:360-384) for one seed: one wave.  dry = 1: only accept[] is written.
+__global__ __launch_bounds__(64) void k_resolve(Dev D, int dry) {
+  extern __shared__ unsigned long long acc[];  // accepted-candidate bitset, kwords words
+  const int e = blockIdx.x, lane = threadIdx.x;
+  Elem* E = &D.el[e];
+  if (!E->live) return;
+  const int n_cand = E->n_cand, n_clu = E->n_cluster;
+  for (int w = lane; w < D.kwords; w += 64) acc[w] = 0ull;
+  __syncthreads();
+  int count = 0, overflow = 0;
+  const int* cd = D.cand + (size_t)e * D.kcap;
+  int* cl = D.cluster + (size_t)e * D.ccap;
+  int* ac = D.active + (size_t)e * D.ccap;
+  uint8_t* fl = D.flags + (size_t)e * D.G;
+  for (int i = 0; i < n_cand; i++) {
+    int ok = D.can_clu[(size_t)e * D.kcap + i];
+    if (ok) {
+      const unsigned long long* row = D.blocked + ((size_t)e * D.kcap + i) * D.kwords;
+      int hit = 0;
+      for (int w = lane; w < (i + 63) / 64; w += 64) hit |= (row[w] & acc[w]) != 0ull;
+      ok = !__any(hit);
+    }
+    if (lane == 0) {
+      D.accept[(size_t)e * D.kcap + i] = (uint8_t)ok;
+      if (ok) acc[i >> 6] |= 1ull << (i & 63);
+      if (!dry) {
+        const int p = cd[i];
+        if (ok) {
+          if (n_clu + count < D.ccap) { cl[n_clu + count] = p; ac[count] = p; }
+          else overflow = 1;
+        } else {
+          fl[px(p) * D.max_yz + py(p) * D.max_z + pz(p)] |= F_INVALID;  // CS:380-383
+        }
+      }
+    }
+    count += ok;
+    __syncthreads();
+  }
+  if (lane == 0 && !dry) {
+    if (overflow) { E->rtn = DIRECT_CLUSTER_OVERFLOW; E->live = 0; E->n_cluster = D.ccap; E->n_active = 0; }
+    else {
+      E->n_cluster = n_clu + count;
+      E->n_active = count;
+      if (count == 0) E->live = 0;  // CS:386-387
+      else E->iters += 1;           // CS:389
+    }
+  }
+}
+
+__global__ void k_emit(Dev D, int batch, int32_t* vertex_idx, int32_t* cluster_xyz, int32_t* cluster_num, int32_t* iters,
+                       int32_t* rtn) {
+  const int e = blockIdx.y;
+  const Elem* E = &D.el[e];
+  const int n = E->rtn == DIRECT_CLUSTER_BAD_SEED ? 0 : E->n_cluster;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    if (cluster_num) cluster_num[e] = n;
+    if (iters) iters[e] = E->iters;
+    if (rtn) rtn[e] = E->rtn;
+  }
+  if (vertex_idx && t < 24) vertex_idx[e * 24 + t] = E->vertex[t];
+  if (cluster_xyz)
+    for (int q = t; q < n; q += gridDim.x * blockDim.x) {
+      const int p = D.cluster[(size_t)e * D.ccap + q];
+      int32_t* o = cluster_xyz + ((size_t)e * D.ccap + q) * 3;
+      o[0] = px(p); o[1] = py(p); o[2] = pz(p);
+    }
+  (void)batch;
+}
+
+thread_local std::string g_cerr;
+direct_status_t cfail(direct_status_t st, const std::string& msg) {
+  g_cerr = msg;
+  return st;
+}
+#define CHIP_TRY(expr)                                                                             \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return cfail(DIRECT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+}  // namespace
+
+struct direct_cluster_handle_s {
+  direct_cluster_config_t cfg = {};
+  Dev D = {};
+  uint8_t* map = nullptr;
+  uint8_t* inside_tmp = nullptr;
+  int* seeds = nullptr;
+  bool have_map = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  std::vector<void*> allocs;
+};
+
+extern "C" {
+
+const char* direct_cluster_last_error(void) { return g_cerr.c_str(); }
+
+direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct_cluster_handle_t* out) {
+  if (!cfg || !out) return cfail(DIRECT_ERR_INVALID, "null argument");
+  if (cfg->max_x <= 0 || cfg->max_y <= 0 || cfg->max_z <= 0 || cfg->max_batch <= 0 || cfg->cluster_capacity <= 0 ||
+      cfg->candidate_capacity <= 0)
+    return cfail(DIRECT_ERR_INVALID, "bad sizes");
+  if (cfg->max_x > kDimLimit || cfg->max_y > kDimLimit || cfg->max_z > kDimLimit)
+    return cfail(DIRECT_ERR_UNSUPPORTED, "map dimensions above 1024 voxels per axis");
+  if ((long long)cfg->max_x * cfg->max_y * cfg->max_z > 0x7fffffffLL / 2) return cfail(DIRECT_ERR_UNSUPPORTED, "map too large");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return cfail(DIRECT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return cfail(DIRECT_ERR_INVALID, "bad device ordinal");
+  CHIP_TRY(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  CHIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return cfail(DIRECT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  direct_cluster_handle_t h = new direct_cluster_handle_s();
+  h->cfg = *cfg;
+  Dev& D = h->D;
+  D.max_x = cfg->max_x; D.max_y = cfg->max_y; D.max_z = cfg->max_z; D.max_yz = cfg->max_y * cfg->max_z;
+  D.G = cfg->max_x * cfg->max_y * cfg->max_z;
+  D.ccap = cfg->cluster_capacity; D.kcap = cfg->candidate_capacity; D.kwords = (cfg->candidate_capacity + 63) / 64;
+  const size_t B = cfg->max_batch, G = D.G;
+  direct_status_t st = DIRECT_OK;
+  auto A = [&](auto pp, size_t bytes) {
+    if (st != DIRECT_OK) return;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    if (e != hipSuccess) { st = cfail(DIRECT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); return; }
+    h->allocs.push_back(q);
+    *pp = (typename std::remove_pointer<decltype(pp)>::type)q;
+  };
+  A(&h->map, G); A(&h->inside_tmp, G); A(&h->seeds, B * 3 * sizeof(int));
+  A(&D.flags, B * G); A(&D.key, B * G * sizeof(int));
+  A(&D.cluster, B * D.ccap * sizeof(int)); A(&D.active, B * D.ccap * sizeof(int)); A(&D.cand, B * D.kcap * sizeof(int));
+  A(&D.can_clu, B * D.kcap); A(&D.accept, B * D.kcap);
+  A(&D.blocked, B * D.kcap * (size_t)D.kwords * sizeof(unsigned long long));
+  A(&D.el, B * sizeof(Elem));
+  D.map = h->map;
+  if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
+    st = cfail(DIRECT_ERR_DEVICE, "hipEventCreate failed");
+  if (st != DIRECT_OK) {
+    direct_cluster_destroy(h);
+    return st;
+  }
+  *out = h;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_cluster_destroy(direct_cluster_handle_t h) {
+  if (!h) return DIRECT_OK;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_cluster_set_map(direct_cluster_handle_t h, int32_t mem, const uint8_t* map_data) {
+  if (!h || !map_data) return cfail(DIRECT_ERR_INVALID, "null argument");
+  CHIP_TRY(hipSetDevice(h->cfg.device));
+  CHIP_TRY(hipMemcpyAsync(h->map, map_data, (size_t)h->D.G, mem == DIRECT_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                          h->stream));
+  CHIP_TRY(hipStreamSynchronize(h->stream));
+  h->have_map = true;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t h, int32_t batch, const int32_t* seeds,
+                                                        int32_t itr_inflate_max, int32_t itr_cluster_max, int32_t mem,
+                                                        int32_t* vertex_idx, int32_t* cluster_xyz, int32_t* cluster_num,
+                                                        int32_t* cluster_iters, int32_t* rtn) {
+  if (!h || !seeds) return cfail(DIRECT_ERR_INVALID, "null argument");
+  if (batch <= 0 || batch > h->cfg.max_batch) return cfail(DIRECT_ERR_INVALID, "batch exceeds the handle's max_batch");
+  if (itr_inflate_max < 0 || itr_cluster_max < 0) return cfail(DIRECT_ERR_INVALID, "negative iteration limit");
+  if (!h->have_map) return cfail(DIRECT_ERR_INVALID, "direct_cluster_set_map has not been called");
+  CHIP_TRY(hipSetDevice(h->cfg.device));
+  Dev& D = h->D;
+  CHIP_TRY(hipMemcpyAsync(h->seeds, seeds, (size_t)batch * 3 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  CHIP_TRY(hipEventRecord(h->ev0, h->stream));
+  const int gblocks = std::min((D.G + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_flags_init, dim3(gblocks, batch), dim3(256), 0, h->stream, D, (const uint8_t*)nullptr);  // flagClear CS:20-26
+  hipLaunchKernelGGL(k_inflate, dim3(batch), dim3(256), 0, h->stream, D, (const int*)h->seeds, itr_inflate_max);
+  CHIP_TRY(hipGetLastError());
+  std::vector<Elem> el(batch);
+  auto fetch = [&]() -> hipError_t {
+    hipError_t e = hipMemcpyAsync(el.data(), D.el, (size_t)batch * sizeof(Elem), hipMemcpyDeviceToHost, h->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+  };
+  CHIP_TRY(fetch());
+  // polytopeCluster_cpu (CS:295-392): one round per trip; two small read-backs per round size the launches
+  for (int round = 0; round < itr_cluster_max; round++) {
+    int max_active = 0, live = 0;
+    for (const Elem& E : el)
+      if (E.live) { live++; max_active = std::max(max_active, E.n_active); }
+    if (!live) break;
+    hipLaunchKernelGGL(k_mark, dim3((max_active * 26 + 255) / 256, batch), dim3(256), 0, h->stream, D);
+    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, h->stream, D);
+    CHIP_TRY(hipGetLastError());
+    CHIP_TRY(fetch());
+    int max_cand = 0;
+    for (const Elem& E : el)
+      if (E.live) max_cand = std::max(max_cand, E.n_cand);
+    if (max_cand > 0) {
+      hipLaunchKernelGGL(k_convex, dim3(max_cand, batch), dim3(256), 0, h->stream, D, 0);
+      hipLaunchKernelGGL(k_resolve, dim3(batch), dim3(64), (size_t)D.kwords * 8, h->stream, D, 0);
+      CHIP_TRY(hipGetLastError());
+      CHIP_TRY(fetch());
+    }
+  }
+  int32_t *dv = vertex_idx, *dc = cluster_xyz, *dn = cluster_num, *di = cluster_iters, *dr = rtn;
+  std::vector<void*> tmp;
+  auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); };
+  if (mem == DIRECT_MEM_HOST) {
+    auto dev = [&](int32_t* hostp, size_t bytes) -> int32_t* {
+      if (!hostp) return nullptr;
+      void* q = nullptr;
+      if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+      tmp.push_back(q);
+      return (int32_t*)q;
+    };
+    dv = dev(vertex_idx, (size_t)batch * 24 * 4); dc = dev(cluster_xyz, (size_t)batch * D.ccap * 12);
+    dn = dev(cluster_num, (size_t)batch * 4); di = dev(cluster_iters, (size_t)batch * 4); dr = dev(rtn, (size_t)batch * 4);
+    if ((vertex_idx && !dv) || (cluster_xyz && !dc) || (cluster_num && !dn) || (cluster_iters && !di) || (rtn && !dr)) {
+      cleanup();
+      return cfail(DIRECT_ERR_DEVICE, "staging buffers");
+    }
+  }
+  hipLaunchKernelGGL(k_emit, dim3(64, batch), dim3(256), 0, h->stream, D, batch, dv, dc, dn, di, dr);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+  h->timed = e == hipSuccess;
+  if (e == hipSuccess && mem == DIRECT_MEM_HOST) {
+    auto dn_ = [&](void* dst, const void* src, size_t bytes) {
+      return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+    };
+    if (e == hipSuccess) e = dn_(vertex_idx, dv, (size_t)batch * 24 * 4);
+    if (e == hipSuccess && cluster_xyz)  // only the filled prefix of every row
+      for (int b = 0; b < batch && e == hipSuccess; b++) {
+        const int n = el[b].rtn == DIRECT_CLUSTER_BAD_SEED ? 0 : el[b].n_cluster;
+        if (n > 0) e = hipMemcpyAsync(cluster_xyz + (size_t)b * D.ccap * 3, dc + (size_t)b * D.ccap * 3, (size_t)n * 12,
+                                      hipMemcpyDeviceToHost, h->stream);
+      }
+    if (e == hipSuccess) e = dn_(cluster_num, dn, (size_t)batch * 4);
+    if (e == hipSuccess) e = dn_(cluster_iters, di, (size_t)batch * 4);
+    if (e == hipSuccess) e = dn_(rtn, dr, (size_t)batch * 4);
+  }
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  cleanup();
+  if (e != hipSuccess || e2 != hipSuccess)
+    return cfail(DIRECT_ERR_DEVICE, std::string("polygon_generation_batch: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  return DIRECT_OK;
+}
+
+direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint8_t* inside_data, int32_t n_candidate,
+                                           const int32_t* candidate_xyz, int32_t n_cluster, const int32_t* cluster_xyz,
+                                           uint8_t* can_clu, uint8_t* can_can, uint8_t* accept) {
+  if (!h || !inside_data || !candidate_xyz || (!cluster_xyz && n_cluster > 0) || !can_clu)
+    return cfail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->have_map) return cfail(DIRECT_ERR_INVALID, "direct_cluster_set_map has not been called");
+  Dev& D = h->D;
+  if (n_candidate <= 0 || n_candidate > D.kcap || n_cluster < 0 || n_cluster > D.ccap)
+    return cfail(DIRECT_ERR_INVALID, "candidate / cluster count exceeds the handle's capacity");
+  CHIP_TRY(hipSetDevice(h->cfg.device));
+  auto pack = [&](const int32_t* xyz, int n, std::vector<int>& out) -> bool {
+    out.resize(n);
+    for (int i = 0; i < n; i++) {
+      const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+      if (x < 0 || x >= D.max_x || y < 0 || y >= D.max_y || z < 0 || z >= D.max_z) return false;
+      out[i] = (x << 20) | (y << 10) | z;
+    }
+    return true;
+  };
+  std::vector<int> pc, pk;
+  if (!pack(candidate_xyz, n_candidate, pc) || !pack(cluster_xyz, n_cluster, pk)) return cfail(DIRECT_ERR_INVALID, "voxel outside the map");
+  Elem E = {};
+  E.n_cluster = n_cluster; E.n_cand = n_candidate; E.live = 1;
+  CHIP_TRY(hipMemcpyAsync(h->inside_tmp, inside_data, (size_t)D.G, hipMemcpyHostToDevice, h->stream));
+  CHIP_TRY(hipMemcpyAsync(D.cand, pc.data(), (size_t)n_candidate * 4, hipMemcpyHostToDevice, h->stream));
+  if (n_cluster) CHIP_TRY(hipMemcpyAsync(D.cluster, pk.data(), (size_t)n_cluster * 4, hipMemcpyHostToDevice, h->stream));
+  CHIP_TRY(hipMemcpyAsync(D.el, &E, sizeof E, hipMemcpyHostToDevice, h->stream));
+  CHIP_TRY(hipMemsetAsync(D.blocked, 0, (size_t)n_candidate * D.kwords * 8, h->stream));
+  CHIP_TRY(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(k_flags_init, dim3(std::min((D.G + 255) / 256, 4096), 1), dim3(256), 0, h->stream, D, (const uint8_t*)h->inside_tmp);
+  hipLaunchKernelGGL(k_convex, dim3(n_candidate, 1), dim3(256), 0, h->stream, D, 1);
+  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), (size_t)D.kwords * 8, h->stream, D, 1);
+  CHIP_TRY(hipGetLastError());
+  CHIP_TRY(hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  std::vector<unsigned long long> rows(can_can ? (size_t)n_candidate * D.kwords : 0);
+  CHIP_TRY(hipMemcpyAsync(can_clu, D.can_clu, (size_t)n_candidate, hipMemcpyDeviceToHost, h->stream));
+  if (accept) CHIP_TRY(hipMemcpyAsync(accept, D.accept, (size_t)n_candidate, hipMemcpyDeviceToHost, h->stream));
+  if (can_can) CHIP_TRY(hipMemcpyAsync(rows.data(), D.blocked, rows.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  CHIP_TRY(hipStreamSynchronize(h->stream));
+  if (can_can)
+    for (int i = 0; i < n_candidate; i++)
+      for (int j = 0; j < i; j++)
+        can_can[(size_t)i * (i - 1) / 2 + j] = ((rows[(size_t)i * D.kwords + (j >> 6)] >> (j & 63)) & 1ull) ? 0 : 1;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_cluster_last_ms(direct_cluster_handle_t h, float* ms) {
+  if (!h || !ms) return cfail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->timed) return cfail(DIRECT_ERR_INVALID, "nothing has been timed yet");
+  CHIP_TRY(hipEventSynchronize(h->ev1));
+  CHIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return DIRECT_OK;
+}
+
+}  // extern "C"

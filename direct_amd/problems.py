@@ -161,3 +161,28 @@ def algorithmic_words(n_planes, n_seg, infeasible=False):
     nc = 6 * n_planes + 55
     w = 257 + (10 if infeasible else 5) * nc + 8 * n_planes
     return int(np.where(k, w, 0).sum())
+
+
+def make_voxel_map(dims=(120, 120, 24), seed=7, n_pillars=60, n_boxes=25, n_rings=6):
+    """Synthetic occupancy grid in the spirit of the reference's random map publisher (pillars and rings of
+    global_planner/src/utils/random_complex_generator.cpp:40-150; 0 = free, 1 = obstacle, index [x][y][z]).
+    Returns the uint8 grid and a list of free seed voxels spread over the map."""
+    rng = _rng(seed, 0)
+    X, Y, Z = dims
+    g = np.zeros(dims, np.uint8)
+    for _ in range(n_pillars):
+        x, y = int(rng.integers(2, X - 4)), int(rng.integers(2, Y - 4))
+        w, hgt = int(rng.integers(1, 4)), int(rng.integers(Z // 3, Z))
+        g[x:x + w, y:y + w, :hgt] = 1
+    for _ in range(n_boxes):
+        x, y, z = int(rng.integers(0, X - 8)), int(rng.integers(0, Y - 8)), int(rng.integers(0, Z - 3))
+        g[x:x + int(rng.integers(2, 8)), y:y + int(rng.integers(2, 8)), z:z + int(rng.integers(1, 4))] = 1
+    for _ in range(n_rings):  # vertical rings: obstacles one voxel thick around a free hole
+        x, y0, z0 = int(rng.integers(4, X - 4)), int(rng.integers(2, Y - 12)), int(rng.integers(1, max(2, Z - 10)))
+        r = int(rng.integers(3, 6))
+        yy, zz = np.meshgrid(np.arange(Y), np.arange(Z), indexing="ij")
+        d = np.maximum(np.abs(yy - (y0 + r)), np.abs(zz - (z0 + r)))
+        g[x][(d == r)] = 1
+    free = np.argwhere(g == 0)
+    seeds = free[rng.choice(len(free), 256, replace=False)].astype(np.int32)
+    return g, seeds

@@ -15,8 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "direct_ddp.h")
 
 
-def declared_functions():
-    txt = open(HEADER).read()
+HEADER_CLUSTER = os.path.join(ROOT, "include", "direct_cluster.h")
+
+
+def declared_functions(header=HEADER):
+    txt = open(header).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(direct_[a-z_0-9]+)\s*\(", txt)))
 
@@ -29,6 +32,11 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, n), "libdirect_ddp.so does not export %s" % n
     assert set(names) == set(solver.EXPORTS)
     assert lib.direct_ddp_abi_version() == 1
+    from direct_amd import cluster
+    cnames = declared_functions(HEADER_CLUSTER)
+    for n in cnames:
+        assert hasattr(lib, n), "libdirect_ddp.so does not export %s" % n
+    assert set(cnames) == set(cluster.EXPORTS)
 
 
 def test_struct_sizes_match_the_header(tmp_path):
@@ -41,6 +49,11 @@ def test_struct_sizes_match_the_header(tmp_path):
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(abi.Params), C.sizeof(abi.BatchIn), C.sizeof(abi.BatchOut), C.sizeof(abi.Config),
                      C.sizeof(abi.SampleIn), C.sizeof(abi.SampleOut)]
+    from direct_amd import cluster
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu\\n",sizeof(direct_cluster_config_t),'
+                   'sizeof(direct_rccl_id_t));return 0;}\n' % HEADER_CLUSTER)
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    assert [int(x) for x in subprocess.check_output([str(exe)]).split()] == [C.sizeof(cluster.Config), 128]
 
 
 def _has_gpu():
@@ -56,6 +69,10 @@ def test_no_cpu_fallback_without_device(built):
         pytest.skip("a GPU is present")
     with pytest.raises(solver.DirectError) as e:
         solver.DdpSolver(4, 5, 6, np.float32)
+    assert e.value.status == abi.DIRECT_ERR_NO_DEVICE
+    from direct_amd import cluster
+    with pytest.raises(solver.DirectError) as e:
+        cluster.ClusterGenerator((8, 8, 8))
     assert e.value.status == abi.DIRECT_ERR_NO_DEVICE
 
 
