@@ -14,20 +14,21 @@ extern "C" int direct_ref_plan_batch(const direct_ddp_params_t*, const direct_dd
 using direct::DenseMatrix;
 using direct::DenseVector;
 
+extern "C" int direct_ref_solve_batch(const direct_ddp_params_t*, const direct_ddp_batch_in_t*, direct_ddp_batch_out_t*, int, double*, int);
 extern "C" int direct_ref_sample(int n_seg, const double* bez, const double* T, double dt, int capacity, int derivs,
                                  int* seg_first, double* pos, double* vel, double* acc, double* length, double* vmax,
                                  double* amax);
 
 int main() {
   const int N = 6, B = 2;
-  std::vector<decomp_cvx_space::FlightCorridor> cors(B);
+  std::vector<direct::PlainCorridor> cors(B);
   std::vector<DenseMatrix> pos, vel, acc, jer, bez0;
   for (int b = 0; b < B; b++) {
     DenseMatrix p(2, 3), z(2, 3);
     p(0, 0) = 1.0 + b; p(0, 1) = -2.0; p(0, 2) = 1.0;
     p(1, 0) = p(0, 0) + 2.5 * N; p(1, 1) = -2.0 + 0.3 * N; p(1, 2) = 1.2;
     for (int k = 0; k < N; k++) {
-      decomp_cvx_space::Polytope pl;
+      direct::PlainPolytope pl;
       const double cx = p(0, 0) + 2.5 * (k + 0.5), cy = -2.0 + 0.3 * (k + 0.5), cz = 1.1;
       // axis-aligned box of half-width (2.6, 1.5, 1.0) around the segment midpoint, plus one slanted cut
       const double hx = 2.6, hy = 1.5, hz = 1.0;
@@ -36,7 +37,7 @@ int main() {
       pl.appendPlane({0, 0, 1, -(cz + hz)}); pl.appendPlane({0, 0, -1, cz - hz});
       const double s = std::sqrt(0.5);
       pl.appendPlane({0, s, s, -(s * cy + s * cz + 1.2)});
-      pl.seed_coord = {p(0, 0) + 2.5 * k, -2.0 + 0.3 * k, 1.0};
+      pl.seed_coord = {{p(0, 0) + 2.5 * k, -2.0 + 0.3 * k, 1.0}};
       cors[b].appendPolytope(pl);
       cors[b].appendTime(2.2);
     }
@@ -48,7 +49,7 @@ int main() {
   std::vector<uint8_t> infeas(B, 1), line_failed(B, 1);
   direct::ddpTrajOptimizer<> opt0(dev), opt1(dev);
   // phase 0 (TRP:895-897)
-  auto rtn0 = opt0.polyCurveGeneration(cors, none, none, pos, vel, acc, jer, 3.0, 2.0, 2.0, 10.0, bez0, 1.0, 1.0, 1.0, 50,
+  auto rtn0 = opt0.polyCurveGenerationBatch(cors, none, none, pos, vel, acc, jer, 3.0, 2.0, 2.0, 10.0, bez0, 1.0, 1.0, 1.0, 50,
                                        infeas, true, false, line_failed, 2, false);
   std::vector<DenseMatrix> bez1;
   auto cors1 = cors;
@@ -61,7 +62,7 @@ int main() {
     bez1.push_back(opt0.getBezCoeff(b));  // TRP:918
   }
   // phase 1 (TRP:919-921)
-  auto rtn1 = opt1.polyCurveGeneration(cors1, none, none, pos, vel, acc, jer, 3.0, 2.0, 2.0, 10.0, bez1, 1.0, 100.0, 20.0, 100,
+  auto rtn1 = opt1.polyCurveGenerationBatch(cors1, none, none, pos, vel, acc, jer, 3.0, 2.0, 2.0, 10.0, bez1, 1.0, 100.0, 20.0, 100,
                                        infeas, false, false, line_failed, 2, false);
 
   // the oracle on the same flat inputs
@@ -91,15 +92,15 @@ int main() {
   }
   // the steps around the path: corridor message round trip and output sampling against the oracle
   {
-    for (size_t k = 0; k < cors[0].polyhedrons.size(); k++) cors[0].polyhedrons[k].center = {0.5 + k, -1.0, 1.0};
+    for (size_t k = 0; k < cors[0].polyhedrons.size(); k++) cors[0].polyhedrons[k].center = {{0.5 + k, -1.0, 1.0}};
     const std::vector<uint8_t> msg = direct::writeCorridorMsg(42, cors[0]);
-    decomp_cvx_space::FlightCorridor back;
+    direct::PlainCorridor back;
     int pid = 0;
     direct::readCorridorMsg(msg, back, pid, 16, 8);
     bool same = pid == 42 && back.polyhedrons.size() == cors[0].polyhedrons.size();
     for (size_t k = 0; same && k < back.polyhedrons.size(); k++) {
       const auto &a = back.polyhedrons[k], &b = cors[0].polyhedrons[k];
-      same = a.planes == b.planes && a.center.x == b.center.x && a.seed_coord.y == b.seed_coord.y;
+      same = a.planes == b.planes && a.center == b.center && a.seed_coord == b.seed_coord;
     }
     std::printf("corridor message: %zu bytes, round trip %s\n", msg.size(), same ? "ok" : "MISMATCH");
     if (!same) bad++;
@@ -117,6 +118,44 @@ int main() {
       for (int d = 0; d < 3; d++) err = std::fmax(err, std::fabs(pts[i][d] - pref[i * 3 + d]));
     std::printf("sampling: %zu points (oracle %d), max |dp| %.2e, length %.9f / %.9f\n", pts.size(), cnt, err, len, len_ref);
     if ((int)pts.size() != cnt || err > 1e-10 || std::fabs(len / len_ref - 1.0) > 1e-12) bad++;
+  }
+  // the reference's exact single-corridor signature (ddp_optimizer.h:267-289: bool& infeas, bool& line_failed) on a
+  // default-constructed optimiser (`new ddpTrajOptimizer()`, TRP:853): same answer as row 0 of the batch
+  {
+    direct::DdpDevice::configure_shared(1, N, 8, DIRECT_F64);
+    direct::ddpTrajOptimizer<> a, c;
+    bool inf = true, lf = true;
+    const int s0 = a.polyCurveGeneration(cors[0], none, none, pos[0], vel[0], acc[0], jer[0], 3.0, 2.0, 2.0, 10.0, bez0[0], 1.0, 1.0, 1.0,
+                                         50, inf, true, false, lf, 2, false);
+    const int s1 = c.polyCurveGeneration(cors1[0], none, none, pos[0], vel[0], acc[0], jer[0], 3.0, 2.0, 2.0, 10.0, a.getBezCoeff(), 1.0,
+                                         100.0, 20.0, 100, inf, false, false, lf, 2, false);
+    const bool ok = s0 == rtn0[0] && s1 == rtn1[0] && c.getIterUsed() == opt1.getIterUsed(0) &&
+                    c.getDDPObjective() == opt1.getDDPObjective(0) && lf == true && inf == (infeas[0] != 0);
+    std::printf("single-corridor overload: rtn %d/%d, cost %.9g, line_failed %d: %s\n", s0, s1, c.getDDPObjective(), (int)lf,
+                ok ? "ok" : "MISMATCH");
+    if (!ok) bad++;
+    // line_init_flag: `line_failed` is cleared only by the line-init success exit (ddp_optimizer.cpp:384)
+    direct::ddpTrajOptimizer<> l;
+    bool inf2 = true, lf2 = true;
+    const int s2 = l.polyCurveGeneration(cors[0], none, none, pos[0], vel[0], acc[0], jer[0], 3.0, 2.0, 2.0, 10.0, bez0[0], 1.0, 100.0, 20.0,
+                                         60, inf2, false, true, lf2, 2, false);
+    std::vector<int32_t> rl(1), il(1);
+    std::vector<uint8_t> lfo(1, 9);
+    direct_ddp_params_t pl{2.0, 2.0, 1.0, 100.0, 20.0, 60, 2, 0, 1, 0, 1, 0, 0};
+    std::vector<double> sd((size_t)N * 3);
+    for (int k = 0; k < N; k++)
+      for (int d = 0; d < 3; d++) sd[(size_t)k * 3 + d] = cors[0].polyhedrons[k].seed_coord[d];
+    direct_ddp_batch_in_t in1 = in;
+    in1.batch = 1; in1.seeds = sd.data();
+    std::vector<double> cl(1);
+    direct_ddp_batch_out_t ol{};
+    ol.rtn = rl.data(); ol.iter_used = il.data(); ol.line_failed_out = lfo.data(); ol.cost = cl.data();
+    direct_ref_solve_batch(&pl, &in1, &ol, 1, nullptr, 0);
+    const bool okl = s2 == rl[0] && l.getIterUsed() == il[0] && (lf2 ? 1 : 0) == (lfo[0] ? 1 : 0) &&
+                     std::fabs(l.getDDPObjective() / cl[0] - 1.0) < 1e-8;
+    std::printf("line-init: rtn %d/%d iters %d/%d line_failed %d/%d: %s\n", s2, rl[0], l.getIterUsed(), il[0], (int)lf2, (int)lfo[0],
+                okl ? "ok" : "MISMATCH");
+    if (!okl) bad++;
   }
   std::printf(bad ? "FAIL\n" : "PASS\n");
   return bad ? 1 : 0;
