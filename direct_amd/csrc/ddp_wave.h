@@ -1397,8 +1397,10 @@ struct Wave {
 #pragma unroll
         for (int a = 0; a < 10; a++) cmax = fmax(cmax, fabs(LV(m)[a]));
         LV(colmax) = cmax;
+        if (regi > 0) {  // lam = base^reg - 1 is exactly 0 at reg = 0 (the common case)
 #pragma unroll
-        for (int a = 0; a < 10; a++) LV(m)[a] += ((a == lane) ? lam : (Acc)0);
+          for (int a = 0; a < 10; a++) LV(m)[a] += ((a == lane) ? lam : (Acc)0);
+        }
       }
       const Acc qu_knot = RDLANE_V(colmax, 10);
       // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
@@ -1435,19 +1437,31 @@ struct Wave {
         st.opterr = INFINITY;
         return 0;
       }
-      // back substitution L^T X = [y | Y] in the right-hand-side lanes
+      // back substitution L^T X = [y | Y] in the right-hand-side lanes.  The multipliers L[j][i] (j > i) are final
+      // once the elimination is done and sit in LDS as row i of UY: uniform-address (broadcast) reads that no
+      // step of the substitution has to wait for, instead of 90 v_readlane on the VALU.  Three batches of rows
+      // keep the operand registers bounded (6 + 15 + 24 multipliers).
+      {
+        static constexpr int kLo[3] = {6, 3, 0}, kHi[3] = {9, 5, 2};
 #pragma unroll
-      for (int i = 9; i >= 0; i--) {
-        Acc urow[10];  // L[j][i], j > i: lane j's entry i (back substitution only overwrites entries >= i so far)
+        for (int bt = 0; bt < 3; bt++) {
+          Acc u[3][10];
 #pragma unroll
-        for (int j = i + 1; j < 10; j++) urow[j] = RDLANE(m, i, j);
-        const Acc dinv = rdiag[i];
-        LANES {
-          Acc acc = LV(m)[i];
+          for (int i = kHi[bt]; i >= kLo[bt]; i--)
 #pragma unroll
-          for (int j = i + 1; j < 10; j++) acc -= urow[j] * LV(m)[j];
-          LV(m)[i] = acc * dinv;
-          DDP_PIN(LV(m)[i]);
+            for (int j = i + 1; j < 10; j++) u[i - kLo[bt]][j] = L.UY[i * 20 + j];
+          DDP_LOADS_ISSUED();
+#pragma unroll
+          for (int i = kHi[bt]; i >= kLo[bt]; i--) {
+            const Acc dinv = rdiag[i];
+            LANES {
+              Acc acc = LV(m)[i];
+#pragma unroll
+              for (int j = i + 1; j < 10; j++) acc -= u[i - kLo[bt]][j] * LV(m)[j];
+              LV(m)[i] = acc * dinv;
+              DDP_PIN(LV(m)[i]);
+            }
+          }
         }
       }
       LANES {

@@ -70,19 +70,21 @@ struct Sched {
   int* done_epoch;    // [batch] chunks completed per trajectory
   int* err;           // [1] set to 1 when the spin limit is hit
   int chunk;
+  int prio;           // raise the wave priority of chunks that had to wait for their predecessor
 };
 // Draws the next ticket and waits for the previous chunk of its trajectory.  Returns the ticket, -1
 // when none are left, -2 when the ticket's trajectory has already finished (kDoneBit in done_epoch),
 // -3 - b when the wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early exits on purpose: inlined into the (huge) iterate
 // loop the structuriser turned the nested uniform loops into exec-masked ones.
-__device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsigned total) {
+__device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsigned total, int* waited) {
   unsigned tv = 0;
   if (threadIdx.x == 0) tv = __hip_atomic_fetch_add(S.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
   if (t >= total) return -1;
   const int e = (int)(t / nb), b = (int)(t - (unsigned)e * nb);
   int ready = (e == 0) ? 1 : 0, have = 0;
-  for (int spins = 0; !ready && spins < (1 << 22); spins++) {
+  int spins = 0;
+  for (; !ready && spins < (1 << 22); spins++) {
     int hv = 0;
     if (threadIdx.x == 0) hv = __hip_atomic_load(&S.done_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     have = __builtin_amdgcn_readfirstlane(hv);
@@ -96,6 +98,7 @@ __device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsig
   }
   if (have >= kDoneBit) return -2;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  *waited = spins > 1 ? 1 : 0;
   return (int)t;
 }
 template <typename St, int RPL>
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
   const unsigned total = nb * n_epochs;
 #pragma unroll 1
   for (;;) {
-    const int t = __builtin_amdgcn_readfirstlane(next_ticket(S, nb, total));
+    int waited = 0;
+    const int t = __builtin_amdgcn_readfirstlane(next_ticket(S, nb, total, &waited));
     if (t == -1) break;
     if (t == -2) continue;
     if (t <= -3) {  // timed out: retire the trajectory so that its later tickets are skipped at once
@@ -118,6 +122,12 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
     const int e = __builtin_amdgcn_readfirstlane((int)((unsigned)t / nb));
     const int b = __builtin_amdgcn_readfirstlane(t - e * (int)nb);
     W.b = b;
+    // A chunk whose predecessor was still running when its ticket was drawn belongs to a trajectory that lags the
+    // batch, i.e. to the critical chain of the launch: it gets the SIMD's issue priority over its co-resident waves.
+    if (S.prio) {
+      if (__builtin_amdgcn_readfirstlane(waited)) __builtin_amdgcn_s_setprio(3);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     W.load_state();
     if (!__builtin_amdgcn_readfirstlane(lds.st.done)) {
       const int left = n_iters - e * S.chunk;
@@ -258,6 +268,7 @@ struct direct_ddp_handle_s {
   int* sched = nullptr;
   int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device
   int sched_chunk = 1;   // outer-loop trips per ticket (DIRECT_DDP_CHUNK at create time; experiments)
+  int sched_prio = 1;    // chunks that had to wait for their predecessor run at raised wave priority (DIRECT_DDP_PRIO=0: off)
   bool dynamic = true;
   // current batch
   int B = 0;
@@ -339,6 +350,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.err = h->sched + 1;
       S.done_epoch = h->sched + 2;
       S.chunk = h->sched_chunk;
+      S.prio = h->sched_prio;
       (void)hipMemsetAsync(h->sched, 0, sizeof(int), h->stream);  // the error flag [1] is sticky: cleared in stage_inputs
       (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);
       RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
@@ -503,6 +515,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
                                             : resident_slots<float>(h, prop.multiProcessorCount);
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
+  if (const char* ev = getenv("DIRECT_DDP_PRIO")) h->sched_prio = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_SLOTS")) {  // experiments: fewer persistent waves than fit
     const int v = atoi(ev);
     if (v > 0 && v < h->sched_slots) h->sched_slots = v;
