@@ -7,6 +7,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "direct_ddp.hip")
 SRC_CLUSTER = os.path.join(_HERE, "csrc", "direct_cluster.hip")  # corridor-cluster generation (include/direct_cluster.h)
+SRC_QUAD = os.path.join(_HERE, "csrc", "direct_quad.hip")  # BASELINE-label model (include/direct_quad.h)
 import glob
 DEPS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))) + sorted(glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
 OUT = os.path.join(_HERE, "lib", "libdirect_ddp.so")
@@ -35,7 +36,7 @@ def build(force=False, extra_flags=()):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + [SRC, SRC_CLUSTER, "-o", OUT]
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + [SRC, SRC_CLUSTER, SRC_QUAD, "-o", OUT]
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
     noise = "'-load-store-opt' is not a recognized feature for this target"
     rest = [l for l in r.stderr.splitlines() if noise not in l]

@@ -1,0 +1,692 @@
+// BASELINE-label model on gfx950: batched Gauss-Newton iLQR for a 12-state / 4-control quadrotor
+// (include/direct_quad.h).  NO REFERENCE COUNTERPART: ntu-caokun/DIRECT has no such optimiser;
+// the outer-loop conventions are the reference's where they carry over (ddp_optimizer.cpp:297-310, 452-474, 666-670).
+//
+// One 64-lane wavefront (one workgroup) per trajectory, as on the main path.  Per knot everything lives in LDS:
+// V (12x12), A = I + dt f_x (12x12), B = dt f_u (12x4), VA, VB, the Q-function blocks and the gains; the 144-entry
+// products run one entry per lane in three passes of 12 FMAs.  Arithmetic is double for both storage types (the
+// value recursion over 100 knots), like the main path.  HBM per knot-iteration: x (12) + u (4) in, gains K (48) +
+// k (4) out and in again, the accepted x, u out: 152 words.  The sweeps are latency-bound (seven
+// LDS hand-offs per backward knot); with 608 B per knot-iteration nothing here is near the HBM roofline.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/direct_quad.h"
+
+namespace {
+
+constexpr int NX = DIRECT_QUAD_NX, NU = DIRECT_QUAD_NU;
+
+struct QConst {
+  double m, g, J[3], dt, q[NX], r[NU], qf[NX], reg_base, tol;
+  int iter_max, fixed_iters;
+};
+
+struct QState {  // per trajectory
+  double cost;
+  int reg, step, fp_failed, bp_failed, iter, done, fwd_passes, cur;
+};
+
+template <typename St>
+struct QBatch {
+  int B, N;
+  const St* x0;  // [B][12]
+  const St* xg;  // [B][12]
+  St* X[2];      // [B][N+1][12]
+  St* U[2];      // [B][N][4]
+  St* K;         // [B][N][4][12]
+  St* kf;        // [B][N][4]
+  QState* st;
+  QConst c;
+};
+
+struct QLds {
+  double V[144], Vn[144], A[144], VA[144], Qxx[144];
+  double Bm[48], VB[48], Qux[48], Kk[48], QuuK[48];
+  double Quu[16], Vx[12], Qx[12], xk[12], xn[12], dx[12], xnext[12];
+  double Qu[4], kk[4], Quuk[4], uk[4], un[4], trig[8], S[40], part[16];
+  QState st;
+};
+
+__device__ __forceinline__ double wsum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// entries of f_x / f_u that are not constants, from trig[] = {s_phi, c_phi, s_th, c_th, s_psi, c_psi}:
+// S[0..8] d vdot / d euler, S[9..17] d eulerdot / d euler, S[18..26] W, S[27..35] d omegadot / d omega, S[36..38] R e3 / m
+__device__ __forceinline__ double special_entry(const QConst& c, const double* x, const double* u, const double* t, int e) {
+  const double sph = t[0], cph = t[1], sth = t[2], cth = t[3], sps = t[4], cps = t[5];
+  const double a = u[0] / c.m, tth = sth / cth, sec2 = 1.0 / (cth * cth);
+  const double k0 = (c.J[2] - c.J[1]) / c.J[0], k1 = (c.J[0] - c.J[2]) / c.J[1], k2 = (c.J[1] - c.J[0]) / c.J[2];
+  switch (e) {
+    case 0: return a * (-sph * sth * cps + cph * sps);
+    case 1: return a * (cph * cth * cps);
+    case 2: return a * (-cph * sth * sps + sph * cps);
+    case 3: return a * (-sph * sth * sps - cph * cps);
+    case 4: return a * (cph * cth * sps);
+    case 5: return a * (cph * sth * cps + sph * sps);
+    case 6: return a * (-sph * cth);
+    case 7: return a * (-cph * sth);
+    case 8: return 0.0;
+    case 9: return cph * tth * x[10] - sph * tth * x[11];
+    case 10: return (sph * x[10] + cph * x[11]) * sec2;
+    case 11: return 0.0;
+    case 12: return -sph * x[10] - cph * x[11];
+    case 13: return 0.0;
+    case 14: return 0.0;
+    case 15: return (cph * x[10] - sph * x[11]) / cth;
+    case 16: return (sph * x[10] + cph * x[11]) * sth * sec2;
+    case 17: return 0.0;
+    case 18: return 1.0;
+    case 19: return sph * tth;
+    case 20: return cph * tth;
+    case 21: return 0.0;
+    case 22: return cph;
+    case 23: return -sph;
+    case 24: return 0.0;
+    case 25: return sph / cth;
+    case 26: return cph / cth;
+    case 27: return 0.0;
+    case 28: return -k0 * x[11];
+    case 29: return -k0 * x[10];
+    case 30: return -k1 * x[11];
+    case 31: return 0.0;
+    case 32: return -k1 * x[9];
+    case 33: return -k2 * x[10];
+    case 34: return -k2 * x[9];
+    case 35: return 0.0;
+    case 36: return (cph * sth * cps + sph * sps) / c.m;
+    case 37: return (cph * sth * sps - sph * cps) / c.m;
+    default: return (cph * cth) / c.m;
+  }
+}
+
+// component l of f(x, u) from trig[]
+__device__ __forceinline__ double dyn_entry(const QConst& c, const double* x, const double* u, const double* t, int l) {
+  const double sph = t[0], cph = t[1], sth = t[2], cth = t[3], sps = t[4], cps = t[5];
+  const double a = u[0] / c.m, tth = sth / cth;
+  switch (l) {
+    case 0: return x[3];
+    case 1: return x[4];
+    case 2: return x[5];
+    case 3: return a * (cph * sth * cps + sph * sps);
+    case 4: return a * (cph * sth * sps - sph * cps);
+    case 5: return a * (cph * cth) - c.g;
+    case 6: return x[9] + sph * tth * x[10] + cph * tth * x[11];
+    case 7: return cph * x[10] - sph * x[11];
+    case 8: return (sph * x[10] + cph * x[11]) / cth;
+    case 9: return (u[1] - (c.J[2] - c.J[1]) * x[10] * x[11]) / c.J[0];
+    case 10: return (u[2] - (c.J[0] - c.J[2]) * x[9] * x[11]) / c.J[1];
+    default: return (u[3] - (c.J[1] - c.J[0]) * x[9] * x[10]) / c.J[2];
+  }
+}
+
+// sin / cos of the three Euler angles of x[] into trig[0..5]: one sincos per angle, on three lanes
+__device__ __forceinline__ void trig_lanes(const double* x, double* trig, int lane) {
+  if (lane < 3) {
+    double s, c;
+    sincos(x[6 + lane], &s, &c);
+    trig[2 * lane] = s;
+    trig[2 * lane + 1] = c;
+  }
+}
+
+// one knot of a roll-out from LDS state L.xn with input L.un: cost contribution (wave-uniform) and L.xnext
+__device__ __forceinline__ double roll_knot(const QConst& c, QLds& L, const double* xg, int lane) {
+  double part = 0.0;
+  if (lane < NX) {
+    const double d = L.xn[lane] - xg[lane];
+    part = c.q[lane] * d * d;
+    L.xnext[lane] = L.xn[lane] + c.dt * dyn_entry(c, L.xn, L.un, L.trig, lane);
+  } else if (lane < NX + NU) {
+    const int i = lane - NX;
+    const double d = L.un[i] - (i == 0 ? c.m * c.g : 0.0);
+    part = c.r[i] * d * d;
+  }
+  return 0.5 * c.dt * wsum(part);
+}
+
+template <typename St>
+__device__ void q_begin(const QBatch<St>& Q, QLds& L, int b, int lane) {
+  const int N = Q.N;
+  __shared__ double xg[NX];
+  if (lane < NX) {
+    xg[lane] = (double)Q.xg[(size_t)b * NX + lane];
+    L.xn[lane] = (double)Q.x0[(size_t)b * NX + lane];
+  }
+  if (lane < NU) L.un[lane] = lane == 0 ? Q.c.m * Q.c.g : 0.0;  // the hover input
+  __syncthreads();
+  double cost = 0.0;
+  St* X = Q.X[0] + (size_t)b * (N + 1) * NX;
+  St* U = Q.U[0] + (size_t)b * N * NU;
+  for (int k = 0; k < N; k++) {
+    if (lane < NX) L.xn[lane] = (double)(St)L.xn[lane];  // the stored iterate is the iterate
+    __syncthreads();
+    trig_lanes(L.xn, L.trig, lane);
+    __syncthreads();
+    cost += roll_knot(Q.c, L, xg, lane);
+    if (lane < NX) X[(size_t)k * NX + lane] = (St)L.xn[lane];
+    if (lane < NU) U[(size_t)k * NU + lane] = (St)L.un[lane];
+    __syncthreads();
+    if (lane < NX) L.xn[lane] = L.xnext[lane];
+    __syncthreads();
+  }
+  double part = 0.0;
+  if (lane < NX) {
+    const double xs = (double)(St)L.xn[lane];
+    X[(size_t)N * NX + lane] = (St)xs;
+    part = Q.c.qf[lane] * (xs - xg[lane]) * (xs - xg[lane]);
+  }
+  cost += 0.5 * wsum(part);
+  if (lane == 0) {
+    QState s;
+    s.cost = cost; s.reg = 0; s.step = 0; s.fp_failed = 0; s.bp_failed = 0; s.iter = 0; s.done = 0; s.fwd_passes = 0; s.cur = 0;
+    Q.st[b] = s;
+  }
+}
+
+// backward sweep; returns 1 on success, 0 when a 4x4 LLT failed (the regulariser then grows, reference :297-310)
+template <typename St>
+__device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const double* xg) {
+  const QConst& c = Q.c;
+  const int N = Q.N, cur = L.st.cur;
+  if (lane == 0) {
+    int reg = L.st.reg;
+    if (L.st.fp_failed || L.st.bp_failed) reg += 1;
+    else if (L.st.step == 0) reg -= 1;
+    else if (L.st.step > 3) reg += 1;
+    L.st.reg = reg < 0 ? 0 : (reg > 24 ? 24 : reg);
+  }
+  __syncthreads();
+  double lam = 1.0;
+  for (int q = 0; q < L.st.reg; q++) lam *= c.reg_base;
+  lam -= 1.0;
+  const St* X = Q.X[cur] + (size_t)b * (N + 1) * NX;
+  const St* U = Q.U[cur] + (size_t)b * N * NU;
+  for (int e = lane; e < 144; e += 64) L.V[e] = (e / 12 == e % 12) ? c.qf[e / 12] : 0.0;
+  if (lane < NX) L.Vx[lane] = c.qf[lane] * ((double)X[(size_t)N * NX + lane] - xg[lane]);
+  __syncthreads();
+  for (int k = N - 1; k >= 0; k--) {
+    if (lane < NX) L.xk[lane] = (double)X[(size_t)k * NX + lane];
+    else if (lane < NX + NU) L.uk[lane - NX] = (double)U[(size_t)k * NU + lane - NX];
+    __syncthreads();
+    trig_lanes(L.xk, L.trig, lane);
+    __syncthreads();
+    if (lane < 39) L.S[lane] = special_entry(c, L.xk, L.uk, L.trig, lane);
+    __syncthreads();
+    // A = I + dt f_x, B = dt f_u
+    for (int e = lane; e < 144; e += 64) {
+      const int r = e / 12, cc = e % 12;
+      double v = r == cc ? 1.0 : 0.0;
+      if (r < 3) v += (cc == r + 3) ? c.dt : 0.0;
+      else if (r < 6) v += (cc >= 6 && cc < 9) ? c.dt * L.S[(r - 3) * 3 + cc - 6] : 0.0;
+      else if (r < 9) v += (cc >= 6 && cc < 9) ? c.dt * L.S[9 + (r - 6) * 3 + cc - 6] : ((cc >= 9) ? c.dt * L.S[18 + (r - 6) * 3 + cc - 9] : 0.0);
+      else v += (cc >= 9) ? c.dt * L.S[27 + (r - 9) * 3 + cc - 9] : 0.0;
+      L.A[e] = v;
+    }
+    if (lane < 48) {
+      const int r = lane / 4, cc = lane % 4;
+      double v = 0.0;
+      if (cc == 0 && r >= 3 && r < 6) v = c.dt * L.S[36 + r - 3];
+      if (r >= 9 && cc == r - 8) v = c.dt / c.J[r - 9];
+      L.Bm[lane] = v;
+    }
+    __syncthreads();
+    for (int e = lane; e < 144; e += 64) {  // VA = V A
+      const int r = e / 12, cc = e % 12;
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < 12; l++) acc += L.V[r * 12 + l] * L.A[l * 12 + cc];
+      L.VA[e] = acc;
+    }
+    if (lane < 48) {  // VB = V B
+      const int r = lane / 4, cc = lane % 4;
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < 12; l++) acc += L.V[r * 12 + l] * L.Bm[l * 4 + cc];
+      L.VB[lane] = acc;
+    }
+    __syncthreads();
+    for (int e = lane; e < 144; e += 64) {  // Qxx = lxx + A' VA
+      const int r = e / 12, cc = e % 12;
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < 12; l++) acc += L.A[l * 12 + r] * L.VA[l * 12 + cc];
+      L.Qxx[e] = acc + (r == cc ? c.dt * c.q[r] : 0.0);
+    }
+    if (lane < 48) {  // Qux = B' VA
+      const int i = lane / 12, j = lane % 12;
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < 12; l++) acc += L.Bm[l * 4 + i] * L.VA[l * 12 + j];
+      L.Qux[lane] = acc;
+    } else {  // Quu = luu + B' VB
+      const int e = lane - 48, i = e / 4, j = e % 4;
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < 12; l++) acc += L.Bm[l * 4 + i] * L.VB[l * 4 + j];
+      L.Quu[e] = acc + (i == j ? c.dt * c.r[i] : 0.0);
+    }
+    __syncthreads();
+    if (lane < NX) {  // Qx = lx + A' Vx
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < 12; l++) acc += L.A[l * 12 + lane] * L.Vx[l];
+      L.Qx[lane] = c.dt * c.q[lane] * (L.xk[lane] - xg[lane]) + acc;
+    } else if (lane < NX + NU) {  // Qu = lu + B' Vx
+      const int i = lane - NX;
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < 12; l++) acc += L.Bm[l * 4 + i] * L.Vx[l];
+      L.Qu[i] = c.dt * c.r[i] * (L.uk[i] - (i == 0 ? c.m * c.g : 0.0)) + acc;
+    }
+    __syncthreads();
+    // LLT of Quu + lam I: computed by every lane (wave-uniform), then one right-hand side per lane
+    double Lm[NU][NU];
+    int ok = 1;
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+      double d = L.Quu[j * NU + j] + lam;
+#pragma unroll
+      for (int l = 0; l < j; l++) d -= Lm[j][l] * Lm[j][l];
+      if (d <= 0.0) ok = 0;
+      const double dj = sqrt(d);
+      Lm[j][j] = dj;
+#pragma unroll
+      for (int i = j + 1; i < NU; i++) {
+        double v = L.Quu[i * NU + j];
+#pragma unroll
+        for (int l = 0; l < j; l++) v -= Lm[i][l] * Lm[j][l];
+        Lm[i][j] = v / dj;
+      }
+    }
+    if (!ok) {
+      if (lane == 0) L.st.bp_failed = 1;
+      __syncthreads();
+      return 0;
+    }
+    if (lane <= NX) {  // column 0: Qu -> k, columns 1..12: Qux[:, c-1] -> K[:, c-1]
+      double y[NU], z[NU];
+#pragma unroll
+      for (int i = 0; i < NU; i++) {
+        double v = lane == 0 ? L.Qu[i] : L.Qux[i * NX + lane - 1];
+#pragma unroll
+        for (int l = 0; l < i; l++) v -= Lm[i][l] * y[l];
+        y[i] = v / Lm[i][i];
+      }
+#pragma unroll
+      for (int i = NU - 1; i >= 0; i--) {
+        double v = y[i];
+#pragma unroll
+        for (int l = i + 1; l < NU; l++) v -= Lm[l][i] * z[l];
+        z[i] = v / Lm[i][i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU; i++) {
+        if (lane == 0) L.kk[i] = -z[i];
+        else L.Kk[i * NX + lane - 1] = -z[i];
+      }
+    }
+    __syncthreads();
+    if (lane < 48) {  // gains to HBM; Quu K
+      Q.K[((size_t)b * N + k) * 48 + lane] = (St)L.Kk[lane];
+      const int i = lane / 12, j = lane % 12;
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < NU; l++) acc += L.Quu[i * NU + l] * L.Kk[l * NX + j];
+      L.QuuK[lane] = acc;
+    } else if (lane < 52) {
+      const int i = lane - 48;
+      Q.kf[((size_t)b * N + k) * NU + i] = (St)L.kk[i];
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < NU; l++) acc += L.Quu[i * NU + l] * L.kk[l];
+      L.Quuk[i] = acc;
+    }
+    __syncthreads();
+    for (int e = lane; e < 144; e += 64) {  // value update with the UNREGULARISED Quu (reference :626-628)
+      const int i = e / 12, j = e % 12;
+      double acc = L.Qxx[e];
+#pragma unroll
+      for (int l = 0; l < NU; l++)
+        acc += L.Kk[l * NX + i] * L.QuuK[l * NX + j] + L.Kk[l * NX + i] * L.Qux[l * NX + j] + L.Qux[l * NX + i] * L.Kk[l * NX + j];
+      L.Vn[e] = acc;
+    }
+    if (lane < NX) {
+      double acc = L.Qx[lane];
+#pragma unroll
+      for (int l = 0; l < NU; l++) acc += L.Kk[l * NX + lane] * L.Quuk[l] + L.Kk[l * NX + lane] * L.Qu[l] + L.Qux[l * NX + lane] * L.kk[l];
+      L.dx[lane] = acc;  // Vx for the next knot, parked until V has been read by everyone
+    }
+    __syncthreads();
+    for (int e = lane; e < 144; e += 64) L.V[e] = 0.5 * (L.Vn[e] + L.Vn[(e % 12) * 12 + e / 12]);
+    if (lane < NX) L.Vx[lane] = L.dx[lane];
+    __syncthreads();
+  }
+  if (lane == 0) L.st.bp_failed = 0;
+  __syncthreads();
+  return 1;
+}
+
+template <typename St>
+__device__ void q_forward(const QBatch<St>& Q, QLds& L, int b, int lane, const double* xg) {
+  const QConst& c = Q.c;
+  const int N = Q.N, cur = L.st.cur, nxt = 1 - cur;
+  const St* X = Q.X[cur] + (size_t)b * (N + 1) * NX;
+  const St* U = Q.U[cur] + (size_t)b * N * NU;
+  St* Xt = Q.X[nxt] + (size_t)b * (N + 1) * NX;
+  St* Ut = Q.U[nxt] + (size_t)b * N * NU;
+  const double cost_old = L.st.cost;
+  for (int step = 0; step < 11; step++) {
+    double alpha = 1.0;
+    for (int q = 0; q < step; q++) alpha *= 0.5;
+    if (lane < NX) L.xn[lane] = (double)X[lane];
+    __syncthreads();
+    double cost = 0.0;
+    for (int k = 0; k < N; k++) {
+      if (lane < NX) L.dx[lane] = L.xn[lane] - (double)X[(size_t)k * NX + lane];
+      if (lane < 48) L.Kk[lane] = (double)Q.K[((size_t)b * N + k) * 48 + lane];
+      else if (lane < 52) {
+        L.kk[lane - 48] = (double)Q.kf[((size_t)b * N + k) * NU + lane - 48];
+        L.uk[lane - 48] = (double)U[(size_t)k * NU + lane - 48];
+      }
+      trig_lanes(L.xn, L.trig, lane);
+      __syncthreads();
+      if (lane < NU) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; j++) acc += L.Kk[lane * NX + j] * L.dx[j];
+        // rounded to the storage type before use: the recorded cost belongs to the iterate that is stored
+        L.un[lane] = (double)(St)(L.uk[lane] + alpha * L.kk[lane] + acc);
+      }
+      __syncthreads();
+      cost += roll_knot(c, L, xg, lane);
+      if (lane < NX) Xt[(size_t)k * NX + lane] = (St)L.xn[lane];
+      if (lane < NU) Ut[(size_t)k * NU + lane] = (St)L.un[lane];
+      __syncthreads();
+      if (lane < NX) L.xn[lane] = (double)(St)L.xnext[lane];
+      __syncthreads();
+    }
+    double part = 0.0;
+    if (lane < NX) {
+      Xt[(size_t)N * NX + lane] = (St)L.xn[lane];
+      part = c.qf[lane] * (L.xn[lane] - xg[lane]) * (L.xn[lane] - xg[lane]);
+    }
+    cost += 0.5 * wsum(part);
+    if (cost < cost_old) {  // strict decrease; NaN is rejected
+      if (lane == 0) {
+        L.st.cost = cost; L.st.step = step; L.st.fp_failed = 0; L.st.cur = nxt;
+      }
+      __syncthreads();
+      return;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) L.st.fp_failed = 1;
+  __syncthreads();
+}
+
+template <typename St>
+__global__ __launch_bounds__(64) void k_quad_begin(QBatch<St> Q) {
+  __shared__ QLds L;
+  q_begin(Q, L, blockIdx.x, threadIdx.x);
+}
+
+template <typename St>
+__global__ __launch_bounds__(64) void k_quad_iterate(QBatch<St> Q, int n_iters) {
+  __shared__ QLds L;
+  __shared__ double xg[NX];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) L.st = Q.st[b];
+  if (lane < NX) xg[lane] = (double)Q.xg[(size_t)b * NX + lane];
+  __syncthreads();
+  for (int it = 0; it < n_iters; it++) {
+    if (L.st.done || L.st.iter >= Q.c.iter_max) {
+      if (lane == 0) L.st.done = 1;
+      break;
+    }
+    int tries = 0;
+    while (!q_backward(Q, L, b, lane, xg)) {
+      if (++tries > 30) break;
+    }
+    const double prev = L.st.cost;
+    q_forward(Q, L, b, lane, xg);
+    if (lane == 0) {
+      L.st.fwd_passes++;
+      L.st.iter++;
+      if (!Q.c.fixed_iters && !L.st.fp_failed && prev - L.st.cost <= Q.c.tol * prev) L.st.done = 1;
+      if (L.st.iter >= Q.c.iter_max) L.st.done = 1;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (lane == 0) Q.st[b] = L.st;
+}
+
+template <typename St>
+__global__ void k_quad_emit(QBatch<St> Q, St* cost, int32_t* iters, St* x, St* u) {
+  const int b = blockIdx.x, N = Q.N;
+  const QState s = Q.st[b];
+  if (threadIdx.x == 0) {
+    if (cost) cost[b] = (St)s.cost;
+    if (iters) iters[b] = s.fwd_passes;
+  }
+  if (x)
+    for (int e = threadIdx.x; e < (N + 1) * NX; e += blockDim.x) x[(size_t)b * (N + 1) * NX + e] = Q.X[s.cur][(size_t)b * (N + 1) * NX + e];
+  if (u)
+    for (int e = threadIdx.x; e < N * NU; e += blockDim.x) u[(size_t)b * N * NU + e] = Q.U[s.cur][(size_t)b * N * NU + e];
+}
+
+thread_local std::string g_qerr;
+direct_status_t qfail(direct_status_t st, const std::string& msg) {
+  g_qerr = msg;
+  return st;
+}
+#define QHIP_TRY(expr)                                                                             \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return qfail(DIRECT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+}  // namespace
+
+struct direct_quad_handle_s {
+  int dtype = 0, device = 0, max_batch = 0, N = 0, B = 0;
+  size_t rsz = 4;
+  bool begun = false, timed = false;
+  void *x0 = nullptr, *xg = nullptr, *X[2] = {nullptr, nullptr}, *U[2] = {nullptr, nullptr}, *K = nullptr, *kf = nullptr;
+  void *o_cost = nullptr, *o_x = nullptr, *o_u = nullptr;
+  int32_t* o_iters = nullptr;
+  QState* st = nullptr;
+  QConst c = {};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<void*> allocs;
+};
+
+namespace {
+template <typename St>
+QBatch<St> make_q(direct_quad_handle_t h) {
+  QBatch<St> Q;
+  Q.B = h->B; Q.N = h->N; Q.x0 = (const St*)h->x0; Q.xg = (const St*)h->xg;
+  for (int i = 0; i < 2; i++) { Q.X[i] = (St*)h->X[i]; Q.U[i] = (St*)h->U[i]; }
+  Q.K = (St*)h->K; Q.kf = (St*)h->kf; Q.st = h->st; Q.c = h->c;
+  return Q;
+}
+direct_status_t set_params(direct_quad_handle_t h, const direct_quad_params_t* p) {
+  if (!p) return qfail(DIRECT_ERR_INVALID, "null params");
+  if (!(p->mass > 0) || !(p->dt > 0) || !(p->inertia[0] > 0) || !(p->inertia[1] > 0) || !(p->inertia[2] > 0) || p->iter_max < 0 ||
+      !(p->reg_base > 1.0))
+    return qfail(DIRECT_ERR_INVALID, "bad model parameters");
+  QConst& c = h->c;
+  c.m = p->mass; c.g = p->gravity; c.dt = p->dt; c.reg_base = p->reg_base; c.tol = p->tol;
+  c.iter_max = p->iter_max; c.fixed_iters = p->fixed_iters;
+  for (int i = 0; i < 3; i++) {
+    c.J[i] = p->inertia[i];
+    c.q[i] = p->q_pos; c.q[3 + i] = p->q_vel; c.q[6 + i] = p->q_ang; c.q[9 + i] = p->q_rate;
+    c.qf[i] = p->qf_pos; c.qf[3 + i] = p->qf_vel; c.qf[6 + i] = p->qf_ang; c.qf[9 + i] = p->qf_rate;
+  }
+  c.r[0] = p->r_thrust; c.r[1] = c.r[2] = c.r[3] = p->r_torque;
+  return DIRECT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* direct_quad_last_error(void) { return g_qerr.c_str(); }
+
+void direct_quad_default_params(direct_quad_params_t* p) {
+  if (!p) return;
+  p->mass = 0.98; p->gravity = 9.81;  // Quadrotor.cpp:16-17
+  p->inertia[0] = 2.64e-3; p->inertia[1] = 2.64e-3; p->inertia[2] = 4.96e-3;  // Quadrotor.cpp:18
+  p->dt = 0.05;
+  p->q_pos = 1.0; p->q_vel = 0.1; p->q_ang = 1.0; p->q_rate = 0.05;
+  p->r_thrust = 0.05; p->r_torque = 50.0;
+  p->qf_pos = 1000.0; p->qf_vel = 500.0; p->qf_ang = 500.0; p->qf_rate = 100.0;
+  p->reg_base = 4.0; p->tol = 1.0e-6; p->iter_max = 50; p->fixed_iters = 0;
+}
+
+direct_status_t direct_quad_create(int32_t dtype, int32_t device, int32_t max_batch, int32_t n_knots, direct_quad_handle_t* out) {
+  if (!out || max_batch <= 0 || n_knots <= 0 || (dtype != DIRECT_F32 && dtype != DIRECT_F64)) return qfail(DIRECT_ERR_INVALID, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return qfail(DIRECT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return qfail(DIRECT_ERR_INVALID, "bad device ordinal");
+  QHIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  QHIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return qfail(DIRECT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  direct_quad_handle_t h = new direct_quad_handle_s();
+  h->dtype = dtype; h->device = device; h->max_batch = max_batch; h->N = n_knots; h->rsz = dtype == DIRECT_F64 ? 8 : 4;
+  const size_t B = max_batch, N = n_knots, r = h->rsz;
+  direct_status_t st = DIRECT_OK;
+  auto A = [&](void** pp, size_t bytes) {
+    if (st != DIRECT_OK) return;
+    hipError_t e = hipMalloc(pp, bytes ? bytes : 16);
+    if (e != hipSuccess) { st = qfail(DIRECT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); return; }
+    h->allocs.push_back(*pp);
+  };
+  A(&h->x0, B * NX * r); A(&h->xg, B * NX * r);
+  for (int i = 0; i < 2; i++) { A(&h->X[i], B * (N + 1) * NX * r); A(&h->U[i], B * N * NU * r); }
+  A(&h->K, B * N * 48 * r); A(&h->kf, B * N * NU * r); A((void**)&h->st, B * sizeof(QState));
+  A(&h->o_cost, B * r); A((void**)&h->o_iters, B * 4); A(&h->o_x, B * (N + 1) * NX * r); A(&h->o_u, B * N * NU * r);
+  if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
+    st = qfail(DIRECT_ERR_DEVICE, "hipEventCreate failed");
+  if (st != DIRECT_OK) {
+    direct_quad_destroy(h);
+    return st;
+  }
+  *out = h;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_quad_destroy(direct_quad_handle_t h) {
+  if (!h) return DIRECT_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_quad_begin(direct_quad_handle_t h, const direct_quad_params_t* p, int32_t batch, int32_t mem, const void* x0,
+                                  const void* xg) {
+  if (!h || !x0 || !xg) return qfail(DIRECT_ERR_INVALID, "null argument");
+  if (batch <= 0 || batch > h->max_batch) return qfail(DIRECT_ERR_INVALID, "batch exceeds the handle's max_batch");
+  direct_status_t s = set_params(h, p);
+  if (s != DIRECT_OK) return s;
+  QHIP_TRY(hipSetDevice(h->device));
+  const hipMemcpyKind kind = mem == DIRECT_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  QHIP_TRY(hipMemcpyAsync(h->x0, x0, (size_t)batch * NX * h->rsz, kind, h->stream));
+  QHIP_TRY(hipMemcpyAsync(h->xg, xg, (size_t)batch * NX * h->rsz, kind, h->stream));
+  h->B = batch;
+  if (h->dtype == DIRECT_F64) hipLaunchKernelGGL(k_quad_begin<double>, dim3(batch), dim3(64), 0, h->stream, make_q<double>(h));
+  else hipLaunchKernelGGL(k_quad_begin<float>, dim3(batch), dim3(64), 0, h->stream, make_q<float>(h));
+  QHIP_TRY(hipGetLastError());
+  h->begun = true;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_quad_iterate(direct_quad_handle_t h, int32_t n_iters) {
+  if (!h) return qfail(DIRECT_ERR_INVALID, "null handle");
+  if (!h->begun) return qfail(DIRECT_ERR_INVALID, "direct_quad_begin has not been called");
+  QHIP_TRY(hipSetDevice(h->device));
+  QHIP_TRY(hipEventRecord(h->ev0, h->stream));
+  if (h->dtype == DIRECT_F64) hipLaunchKernelGGL(k_quad_iterate<double>, dim3(h->B), dim3(64), 0, h->stream, make_q<double>(h), n_iters);
+  else hipLaunchKernelGGL(k_quad_iterate<float>, dim3(h->B), dim3(64), 0, h->stream, make_q<float>(h), n_iters);
+  QHIP_TRY(hipGetLastError());
+  QHIP_TRY(hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_quad_solve_batch(direct_quad_handle_t h, const direct_quad_params_t* p, int32_t batch, int32_t mem, const void* x0,
+                                        const void* xg, void* cost, int32_t* iters, void* x, void* u) {
+  direct_status_t s = direct_quad_begin(h, p, batch, mem, x0, xg);
+  if (s != DIRECT_OK) return s;
+  s = direct_quad_iterate(h, p->iter_max);
+  if (s != DIRECT_OK) return s;
+  const bool host = mem == DIRECT_MEM_HOST;
+  const size_t B = batch, N = h->N, r = h->rsz;
+  void* dc = host ? (cost ? h->o_cost : nullptr) : cost;
+  int32_t* di = host ? (iters ? h->o_iters : nullptr) : iters;
+  void* dx = host ? (x ? h->o_x : nullptr) : x;
+  void* du = host ? (u ? h->o_u : nullptr) : u;
+  if (h->dtype == DIRECT_F64)
+    hipLaunchKernelGGL(k_quad_emit<double>, dim3(batch), dim3(256), 0, h->stream, make_q<double>(h), (double*)dc, di, (double*)dx, (double*)du);
+  else
+    hipLaunchKernelGGL(k_quad_emit<float>, dim3(batch), dim3(256), 0, h->stream, make_q<float>(h), (float*)dc, di, (float*)dx, (float*)du);
+  QHIP_TRY(hipGetLastError());
+  if (host) {
+    if (cost) QHIP_TRY(hipMemcpyAsync(cost, dc, B * r, hipMemcpyDeviceToHost, h->stream));
+    if (iters) QHIP_TRY(hipMemcpyAsync(iters, di, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (x) QHIP_TRY(hipMemcpyAsync(x, dx, B * (N + 1) * NX * r, hipMemcpyDeviceToHost, h->stream));
+    if (u) QHIP_TRY(hipMemcpyAsync(u, du, B * N * NU * r, hipMemcpyDeviceToHost, h->stream));
+    QHIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return DIRECT_OK;
+}
+
+direct_status_t direct_quad_get(direct_quad_handle_t h, void* x, void* u, void* K, void* kf, double* scalars) {
+  if (!h) return qfail(DIRECT_ERR_INVALID, "null handle");
+  if (!h->begun) return qfail(DIRECT_ERR_INVALID, "direct_quad_begin has not been called");
+  QHIP_TRY(hipSetDevice(h->device));
+  const size_t B = h->B, N = h->N, r = h->rsz;
+  std::vector<QState> st(B);
+  QHIP_TRY(hipMemcpyAsync(st.data(), h->st, B * sizeof(QState), hipMemcpyDeviceToHost, h->stream));
+  QHIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t b = 0; b < B; b++) {
+    const int cur = st[b].cur;
+    if (x) QHIP_TRY(hipMemcpyAsync((char*)x + b * (N + 1) * NX * r, (char*)h->X[cur] + b * (N + 1) * NX * r, (N + 1) * NX * r, hipMemcpyDeviceToHost, h->stream));
+    if (u) QHIP_TRY(hipMemcpyAsync((char*)u + b * N * NU * r, (char*)h->U[cur] + b * N * NU * r, N * NU * r, hipMemcpyDeviceToHost, h->stream));
+    if (scalars) {
+      double* o = scalars + b * 8;
+      o[0] = st[b].cost; o[1] = st[b].reg; o[2] = st[b].step; o[3] = st[b].fp_failed; o[4] = st[b].bp_failed;
+      o[5] = st[b].iter; o[6] = st[b].done; o[7] = st[b].fwd_passes;
+    }
+  }
+  if (K) QHIP_TRY(hipMemcpyAsync(K, h->K, B * N * 48 * r, hipMemcpyDeviceToHost, h->stream));
+  if (kf) QHIP_TRY(hipMemcpyAsync(kf, h->kf, B * N * NU * r, hipMemcpyDeviceToHost, h->stream));
+  QHIP_TRY(hipStreamSynchronize(h->stream));
+  return DIRECT_OK;
+}
+
+direct_status_t direct_quad_last_kernel_ms(direct_quad_handle_t h, double* ms) {
+  if (!h || !ms) return qfail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->timed) return qfail(DIRECT_ERR_INVALID, "nothing has been timed yet");
+  QHIP_TRY(hipEventSynchronize(h->ev1));
+  float t = 0.f;
+  QHIP_TRY(hipEventElapsedTime(&t, h->ev0, h->ev1));
+  *ms = (double)t;
+  return DIRECT_OK;
+}
+
+}  // extern "C"

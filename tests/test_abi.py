@@ -37,6 +37,11 @@ def test_library_exports_every_declared_symbol(built):
     for n in cnames:
         assert hasattr(lib, n), "libdirect_ddp.so does not export %s" % n
     assert set(cnames) == set(cluster.EXPORTS)
+    from direct_amd import quad
+    qnames = declared_functions(os.path.join(ROOT, "include", "direct_quad.h"))
+    for n in qnames:
+        assert hasattr(lib, n), "libdirect_ddp.so does not export %s" % n
+    assert set(qnames) == set(quad.EXPORTS)
 
 
 def test_struct_sizes_match_the_header(tmp_path):
@@ -54,6 +59,11 @@ def test_struct_sizes_match_the_header(tmp_path):
                    'sizeof(direct_rccl_id_t));return 0;}\n' % HEADER_CLUSTER)
     subprocess.check_call(["gcc", str(src), "-o", str(exe)])
     assert [int(x) for x in subprocess.check_output([str(exe)]).split()] == [C.sizeof(cluster.Config), 128]
+    from direct_amd import quad
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu\\n",sizeof(direct_quad_params_t));return 0;}\n'
+                   % os.path.join(ROOT, "include", "direct_quad.h"))
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    assert int(subprocess.check_output([str(exe)])) == C.sizeof(quad.Params)
 
 
 def _has_gpu():
