@@ -124,6 +124,41 @@ def hbm_copy_gbs(torch, dev):
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
+def label_model_line(torch, dev, B, with_cpu):
+    """The model BASELINE.json's metric string literally names (12-state / 4-control quadrotor, N = 100), reported
+    SEPARATELY: it has no reference counterpart (include/direct_quad.h).  Same batch size as the main workload, float
+    storage, a fixed 10 iLQR iterations per step, inputs resident in HBM."""
+    from direct_amd import quad
+    N, iters = 100, 10
+    x0, xg = quad.label_problems(B, seed=1000)
+    p = quad.default_params(iter_max=iters, fixed_iters=1)
+    q = quad.QuadSolver(B, N, np.float32, device=dev.index or 0)
+    tx0, txg = torch.from_numpy(x0.astype(np.float32)).to(dev), torch.from_numpy(xg.astype(np.float32)).to(dev)
+    cost, it = torch.zeros(B, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    ms = []
+    for rep in range(7):
+        q.solve_device(p, B, tx0.data_ptr(), txg.data_ptr(), cost.data_ptr(), it.data_ptr())
+        torch.cuda.synchronize()
+        if rep >= 2:
+            ms.append(q.last_kernel_ms())
+    n_it = int(it.sum().item())
+    k_ms = float(np.mean(ms))
+    byts = quad.ALGORITHMIC_WORDS_PER_KNOT_ITER * 4 * N * n_it
+    out = {"note": "NO REFERENCE COUNTERPART: the 12-state / 4-control quadrotor of BASELINE.json's metric string does not exist "
+                   "in ntu-caokun/DIRECT (SURVEY.md section 0); Gauss-Newton iLQR, explicit Euler dt 0.05, parity only against "
+                   "this repo's own CPU checker",
+           "value": n_it / (k_ms * 1e-3), "unit": "iter/s", "workload": "%d trajectories, N=%d knots, f32 storage, fixed %d iterations" % (B, N, iters),
+           "kernel_ms": k_ms, "roofline": {"bound": "hbm", "achieved": byts / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": byts / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts}}
+    q.close()
+    if with_cpu:
+        from oracle import quadapi
+        t = time.perf_counter()
+        r = quadapi.solve_batch(p, N, x0[:64], xg[:64], n_threads=1)
+        out["cpu_single_thread_iter_per_s"] = float(r["iters"].sum() / (time.perf_counter() - t))
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -312,6 +347,9 @@ def main():
                    "iterations_max": int(fp.max()), "iterations_min": int(fp.min()),
                    "rtn_histogram": {str(int(v)): int(c) for v, c in zip(*np.unique(rt, return_counts=True))}}
         hbm_copy = hbm_copy_gbs(torch, dev)
+    label = None
+    if not args.no_secondary and rank == 0:
+        label = label_model_line(torch, dev, B, not args.no_cpu_baseline and world == 1)
 
     if rank == 0:
         words = problems.algorithmic_words(batch1.n_planes, batch1.n_seg, infeasible=False)
@@ -356,6 +394,8 @@ def main():
                                                 "workload, all 64 lanes of an instruction counted) x this run's kernel rate"}
         if natural is not None:
             line["natural_exit"] = natural
+        if label is not None:
+            line["label_model"] = label
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
