@@ -305,6 +305,11 @@ def main():
     bc, bidx, owner, blk = distributed.gather_best(lc, first + li if li >= 0 else -1, block)
     torch.cuda.synchronize()
     gather = {"torch_ms": (time.perf_counter() - tg) * 1e3, "best_cost": bc, "best_index": bidx, "owner": owner}
+    # RCCL writes a version banner to the C stdout when a communicator is created: keep this process's stdout
+    # for the ONE JSON line by pointing fd 1 at stderr while the library talks to RCCL
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
     try:
         uid = [s.rccl_unique_id() if rank == 0 else None]
         if world > 1:
@@ -324,6 +329,11 @@ def main():
         gather.update({"c_abi_rccl_ms": c_ms, "c_abi_matches_torch": bool(same), "rccl_ranks": world})
     except Exception as e:  # noqa: BLE001 - the bench line must survive a gather failure; it is reported, not hidden
         gather.update({"c_abi_error": repr(e)})
+    finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     devices = [local]
     if world > 1:
         got = [None] * world
@@ -398,7 +408,7 @@ def main():
             line["label_model"] = label
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     s.close()
     if world > 1:
         dist.barrier()
