@@ -307,6 +307,11 @@ struct WaveLds {
   // T-derivative, rows 18..20: the jerk Gram matrix R acting on u and its T-derivative (see ctrl_off()).
   Real WbE[126], WdE[126];
   Real Rc[9];             // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1)
+  // Per-lane role descriptors of the backward sweep's assembly phases, packed (init_tables; fixed for the
+  // launch).  They depend on the lane alone, but `lane` is laundered per phase (see LANES) so that the indices are
+  // not hoisted into a hundred live registers - which made every knot re-derive them with ~40 integer
+  // instructions per phase.  One ds_read_b32 and a few bit-field extracts replace that.
+  int lt[5][64];
   // per knot, both sweeps
   Real tp[8];             // powers of T
   Real z[kXS];
@@ -656,6 +661,32 @@ struct Wave {
         L.WbE[108 + a * 6 + 3 + a2] = (Real)(ca * cb / (double)(a + a2 + 1));
         L.WdE[108 + a * 6 + a2] = (Real)0;  // d/dT: (a + a2 + 1) Rc, one power less
         L.WdE[108 + a * 6 + 3 + a2] = (Real)(ca * cb / (double)(a + a2 + 1)) * (Real)(a + a2 + 1);
+      }
+      {  // lt[0..3]: phase H (18x18 block of the condensed system); lt[4]: value recursion of phase R2
+        const int l62 = lane < 63 ? lane : 62;  // lane 63 redoes lane 62
+        const int pr = l62 / 3, d = l62 % 3;
+        const int i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
+        const int i2 = i + pr - (6 * i - (i * (i - 1)) / 2);
+        const int p = 3 * i + d;
+        const int hasq = i >= 3 ? 1 : 0;
+        L.lt[0][lane] = i | (i2 << 3) | (d << 6) | (hasq << 8) | ((hasq ? (i - 3) * 3 + (i2 - 3) : 0) << 9) |
+                        ((hasq ? i + i2 - 5 : 0) << 13);
+        for (int d2 = 0; d2 < 3; d2++) {
+          const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
+          const int sidx = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);  // xx,xy,xz,yy,yz,zz
+          const int q = 3 * i2 + d2;
+          // [Hxu; Huu] is one 19x10 block behind Hxx: entry (p, q >= 9) sits at 81 + 10 p + (q - 9)
+          const int o1 = q < 9 ? p * 9 + q : p * 10 + q + 72;
+          const int o2 = q < 9 ? q * 9 + p : (p < 9 ? o1 : q * 10 + p + 72);
+          L.lt[1 + d2][lane] = sidx | (q << 3) | (o1 << 8) | (o2 << 17) | ((p <= q ? 1 : 0) << 26) | ((d2 == d ? 1 : 0) << 27);
+        }
+        const int l45 = lane < 45 ? lane : 44;  // upper triangle (a, c2 >= a) of the 9x9 value matrix
+        int a = 0, rem = l45;
+        while (rem >= 9 - a) {
+          rem -= 9 - a;
+          a++;
+        }
+        L.lt[4][lane] = a | ((a + rem) << 4);
       }
       if (lane < 5) {  // pseudo-planes (n, o) of the non-plane rows: +/-v - vmax, +/-a - amax, -T + 0.3 (DDP:1237-1279)
         Real* q = &L.pl[4 * Lds::kPMax + 4 * lane];
@@ -1248,11 +1279,8 @@ struct Wave {
       // operands are loaded once for three entries, and the velocity / acceleration rows (which only touch
       // d2 == d) need no second pass over the stored block.
       LANES {
-        const int l62 = lane < 63 ? lane : 62;  // lane 63 redoes lane 62
-        const int pr = l62 / 3, d = l62 % 3;
-        const int i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
-        const int i2 = i + pr - (6 * i - (i * (i - 1)) / 2);
-        const int p = 3 * i + d;
+        const int w0 = L.lt[0][lane];  // i | i2 << 3 | d << 6 | hasq << 8 | Rc index << 9 | T-power index << 13
+        const int i = w0 & 7, i2 = (w0 >> 3) & 7, d = (w0 >> 6) & 3;
         Acc ww[6], adv = 0;
         Real hh3[3];
         {
@@ -1288,13 +1316,12 @@ struct Wave {
           DDP_PIN(adv);  // or the FMAs sink below the later batches' loads and all 27 operands stay live
         }
         adv *= sig;
-        const bool hasq = i >= 3;
-        const Real rc1 = L.Rc[hasq ? (i - 3) * 3 + (i2 - 3) : 0], tp1 = L.tp[hasq ? i + i2 - 5 : 0];
+        const bool hasq = (w0 >> 8) & 1;
+        const Real rc1 = L.Rc[(w0 >> 9) & 15], tp1 = L.tp[(w0 >> 13) & 7];
 #pragma unroll
         for (int d2 = 0; d2 < 3; d2++) {
-          const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
-          const int sidx = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);  // xx,xy,xz,yy,yz,zz
-          const int q = 3 * i2 + d2;
+          const int wd = L.lt[1 + d2][lane];  // S index | q << 3 | o1 << 8 | o2 << 17 | (p <= q) << 26 | (d2 == d) << 27
+          const int sidx = wd & 7, q = (wd >> 3) & 31;
           Acc sp6[6], vz3[3];
 #pragma unroll
           for (int cr = 0; cr < 6; cr++) sp6[cr] = L.Sp[cr * 6 + sidx];
@@ -1306,18 +1333,15 @@ struct Wave {
           for (int cr = 0; cr < 6; cr++) ada += ww[cr] * sp6[cr];
 #pragma unroll
           for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
-          const bool dd = d2 == d;
+          const bool dd = (wd >> 27) & 1;
           const Acc quu = (hasq && dd) ? wsn * rc1 * tp1 : (Acc)0;
           Acc v = zvz + quu + sig * ada;
           v = dd ? v + adv : v;
-          // Hxx | Hxu | Huu are consecutive members: element offsets from Hxx[0] (81, 171), integer selects
-          // [Hxu; Huu] is one 19x10 block behind Hxx: entry (p, q >= 9) sits at 81 + 10 p + (q - 9)
+          // Hxx | Hxu | Huu are consecutive members: element offsets from Hxx[0] (see init_tables)
           Acc* Hb = L.Hxx;
-          const int o1 = q < 9 ? p * 9 + q : p * 10 + q + 72;
-          const int o2 = q < 9 ? q * 9 + p : (p < 9 ? o1 : q * 10 + p + 72);
-          if (p <= q) {  // i == i2: the lower triangle of the diagonal block belongs to the lane of the other axis
-            Hb[o1] = v;
-            Hb[o2] = v;
+          if ((wd >> 26) & 1) {  // p <= q; i == i2: the lower triangle of the diagonal block belongs to the lane of the other axis
+            Hb[(wd >> 8) & 511] = v;
+            Hb[(wd >> 17) & 511] = v;
           }
         }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
@@ -1524,13 +1548,8 @@ struct Wave {
         // are identically  Vxx = Hxx - Y'Y - lam Ku'Ku,   Vx = Hx - Y'y - lam Ku'ku   (10-term dots instead
         // of two 10x10x9 products).  V / Vx are dead since phases R1 / H: overwritten in place.
         {
-          const int l45 = lane < 45 ? lane : 44;
-          int a = 0, rem = l45;
-          while (rem >= 9 - a) {
-            rem -= 9 - a;
-            a++;
-          }
-          const int c2 = a + rem;
+          const int wv = L.lt[4][lane];
+          const int a = wv & 15, c2 = wv >> 4;
           const int aa = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
           // lanes 0..44: (colA, colB) = Y columns 1+a, 1+c2;  lanes 45..53: Y column 1+aa against y (column 0)
           const int cA = lane < 45 ? 1 + a : 1 + aa, cB = lane < 45 ? 1 + c2 : 0;
