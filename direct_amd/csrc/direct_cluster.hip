@@ -291,8 +291,10 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
   const int c = cd[i], cx = px(c), cy = py(c), cz = pz(c), n_clu = E->n_cluster;
   int bad = 0;
   for (int base = 0; base < n_clu; base += 256) {
-    const int t = base + tid;
-    if (t < n_clu) bad |= ray_blocked(D, fl, cx, cy, cz, cl[t]);
+    // newest cluster voxels first, like the reference's loop (cluster_engine_cpu.cpp:41): they lie next to the
+    // candidate shell and are the likeliest to reject, so the early exit below comes sooner (the result is an AND)
+    const int t = n_clu - 1 - (base + tid);
+    if (t >= 0) bad |= ray_blocked(D, fl, cx, cy, cz, cl[t]);
     if (!full && __syncthreads_or(bad)) {  // a rejected candidate's rays towards other candidates are never consulted
       if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = 0;
       return;

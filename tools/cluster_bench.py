@@ -1,0 +1,40 @@
+"""Corridor-cluster generation: batched polygonGeneration on the device against the CPU oracle on the same seeds.
+usage: python tools/cluster_bench.py [n_seeds] [X Y Z]    (run through gpurun; add rocprofv3 --kernel-trace --stats for
+per-kernel times).  Prints one JSON line."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from direct_amd import cluster, problems  # noqa: E402
+from oracle import clusterapi as ca  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dims = tuple(int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (200, 200, 40)
+grid, seeds = problems.make_voxel_map(dims, seed=7, n_pillars=170, n_boxes=70, n_rings=12)
+seeds = seeds[:n]
+gen = cluster.ClusterGenerator(dims, max_batch=n, cluster_capacity=50000, candidate_capacity=10000)
+gen.set_map(grid)
+gen.polygon_generation(seeds[:2])   # warm up
+ts = []
+for rep in range(3):
+    t = time.perf_counter()
+    r = gen.polygon_generation(seeds, 1000, 50)
+    ts.append(time.perf_counter() - t)
+kms = gen.last_ms()
+ca.use_reference_convex_test(ca.ref_lib() is not None)
+m = min(n, 8)
+t = time.perf_counter()
+ref = [ca.polygon_generation(grid, s, 1000, 50) for s in seeds[:m]]
+cpu = (time.perf_counter() - t) / m
+ca.use_reference_convex_test(False)
+same = all(np.array_equal(r["clusters"][b], ref[b][1]) for b in range(m))
+rays = 0   # rays cast = sum over rounds of candidates x (cluster + earlier candidates): not tracked on the device; report voxels instead
+print(json.dumps({"seeds": n, "map": dims, "obstacle_frac": float(grid.mean()), "rtn_ok": int((r["rtn"] == 0).sum()),
+                  "cluster_voxels_mean": float(r["cluster_num"].mean()), "rounds_mean": float(r["iters"].mean()),
+                  "device_wall_ms_best": min(ts) * 1e3, "device_event_ms": kms, "device_ms_per_seed": min(ts) * 1e3 / n,
+                  "cpu_oracle_ms_per_seed": cpu * 1e3, "cpu_kind": "reference serialConvexTest + restated loops, 1 thread",
+                  "bit_identical_to_cpu_on_first_%d" % m: bool(same)}))
+gen.close()
