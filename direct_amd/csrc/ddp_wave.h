@@ -572,10 +572,10 @@ struct Wave {
       const int r = (pkv[i] & 255) - 1;
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0; their results are masked
       p.s[i] = sk[rc];
-      if (infeas) p.y[i] = yk[rc];
+      if (infeas || fwd) p.y[i] = yk[rc];  // feasible forward pass: q = s / c of the old iterate (written by phase R1)
       if (fwd) {
         p.ks[i] = ksk[rc];
-        if (infeas) p.ky[i] = kyk[rc];
+        p.ky[i] = kyk[rc];                 // feasible mode: c of the old iterate (written by phase R1)
       }
     }
     if (fwd) {
@@ -1182,6 +1182,10 @@ struct Wave {
             D = s * cinv;
             g = -mu * cinv;  // s - r/c
             LV(e_mu) = fmax(LV(e_mu), in ? fabs(rv) : (Real)0);
+            if (in) {  // for the forward trials of this iteration (the y / ky arrays are free in feasible mode)
+              SpU(sp.Y[0], k)[r] = (St)D;
+              SpU(sp.KY, k)[r] = (St)c;
+            }
           }
           LV(rc)[i] = c;
           LV(rr)[i] = rv;
@@ -1654,8 +1658,8 @@ struct Wave {
           for (int i = 0; i < RPL; i++) {
             LV(rs)[i] = (Real)LV(pre).s[i];
             LV(rks)[i] = (Real)LV(pre).ks[i];
-            LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
-            LV(rky)[i] = infeas ? (Real)LV(pre).ky[i] : (Real)0;
+            LV(ry)[i] = (Real)LV(pre).y[i];    // infeasible: y, ky; feasible: s / c and c of the old iterate
+            LV(rky)[i] = (Real)LV(pre).ky[i];
             LV(pkc)[i] = LV(pkn)[i];
           }
         }
@@ -1724,7 +1728,7 @@ struct Wave {
             const int l62 = lane < 63 ? lane : 62;
             const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
             const int crd = cr < 15 ? cr : 14;  // the d/dT table has no rows for the dynamics / cost (unused there)
-            Real vo = 0, dvo = 0, vn = 0, gf = 0;
+            Real dvo = 0, vn = 0, gf = 0;
             // Summed over the exponent j = i - o instead of the coefficient index i (same terms, same
             // order: the i < o terms have zero weight): the power T^j is then the same for every lane and
             // comes from a uniform register instead of three LDS table reads per term.
@@ -1748,22 +1752,17 @@ struct Wave {
               for (int jj = 0; jj < 3; jj++) {
                 const int j = 3 * half + jj;
                 const Real w = wb6[jj] * pwo[j];
-                vo += w * zo6[jj];
                 gf += w * dz6[jj];
                 dvo += wd6[jj] * pwo[j < 1 ? 0 : j - 1] * zo6[jj];
                 vn += wb6[jj] * pwn[j] * zn6[jj];
               }
             }
             const Real un = L.zn[9 + (lane < 54 ? 0 : l62 - 54)], dT = L.dz[18];
-            if (lane < 45) {
-              L.val[lane] = vo;
-              L.G[lane] = gf + dvo * dT;
-            }
+            if (lane < 45) L.G[lane] = gf + dvo * dT;
             Real* dst = lane < 45 ? &L.valn[l62] : (lane < 54 ? &L.xnx[l62 - 45] : &L.qp[l62 - 54]);
             *dst = lane < 54 ? vn : vn * un;  // u_a[d] * (R u)_a[d]: the nine of them sum to u'Ru (DDP:1294-1305)
           }
           if (lane == 63) {
-            L.val[45] = L.z[18];
             L.valn[45] = L.zn[18];
             L.G[45] = L.dz[18];
           }
@@ -1798,8 +1797,10 @@ struct Wave {
                 sn[r] = (St)snew;
               }
             } else {  // DDP:694-703
-              const Real co = row_c(L.val, rk);
-              snew = (Real)(St)(s + alpha * LV(rks)[i] - (s * frcp(co)) * az);
+              // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them once
+              // (phase R1) instead of every trial re-deriving them from the old control values
+              const Real co = LV(rky)[i];
+              snew = (Real)(St)(s + alpha * LV(rks)[i] - LV(ry)[i] * az);
               LV(bad) |= (in && (cn > omt * co || snew < omt * s)) ? 1 : 0;
               LV(plog).mul(in ? -cn : (Real)1);
               if (in) sn[r] = (St)snew;
