@@ -1168,7 +1168,7 @@ struct Wave {
           const int r = rk.r;
           const bool in = r >= 0;
           Real c = row_c(L.val, rk), s = LV(rs)[i], y = LV(ry)[i];
-          Real D, g, rv;
+          Real D, g, rv, frcp_reuse = (Real)0;
           if (infeas) {  // DDP:535-539, 554
             Real rm = s * y - mu;
             rv = s * (c + y) - rm;  // rhat
@@ -1179,6 +1179,7 @@ struct Wave {
           } else {  // DDP:583-587, 601
             rv = s * c + mu;
             Real cinv = frcp(c);
+            frcp_reuse = cinv;
             D = s * cinv;
             g = -mu * cinv;  // s - r/c
             LV(e_mu) = fmax(LV(e_mu), in ? fabs(rv) : (Real)0);
@@ -1187,8 +1188,10 @@ struct Wave {
               SpU(sp.KY, k)[r] = (St)c;
             }
           }
-          LV(rc)[i] = c;
-          LV(rr)[i] = rv;
+          // for phase R2: infeasible mode needs c and rhat; feasible mode only the two quotients r / c and s / c, so
+          // that the slack gain ks = -(r + s cu ku) / c costs no second reciprocal there
+          LV(rc)[i] = infeas ? c : D;
+          LV(rr)[i] = infeas ? rv : rv * frcp_reuse;
           if (in) {
             L.drow[r] = (St)D;
             L.grow[r] = (St)g;
@@ -1536,8 +1539,8 @@ struct Wave {
               ksg[r] = ks;
               kyg[r] = ky;
             }
-          } else {  // DDP:611
-            const St ks = (St)(-((rv + s * cuku) * frcp(c)));
+          } else {  // DDP:611: -(r + s cu ku) / c with rv = r / c and c = s / c carried from phase R1
+            const St ks = (St)(-(rv + c * cuku));
             if (r >= 0) ksg[r] = ks;
           }
         }
