@@ -920,7 +920,7 @@ direct_status_t direct_ddp_gather_best(direct_ddp_handle_t h, void* nccl_comm, i
     HIP_TRY(hipMalloc(&h->g_recs, (size_t)n_ranks * sizeof(BestRec)));
     HIP_TRY(hipMalloc(&h->g_blocks, (size_t)n_ranks * blk));
     HIP_TRY(hipMalloc(&h->g_win, sizeof(BestRec) + 16));
-    HIP_TRY(hipMalloc(&h->g_in, (size_t)h->max_batch * (nm * 19 * r + r + 4) + blk));
+    HIP_TRY(hipMalloc(&h->g_in, (size_t)h->max_batch * (nm * 19 * r + r + 4) + blk + 256));  // + the 16-byte alignment of each staged array
     h->g_ranks = n_ranks;
   }
   const void *dc = cost, *db = bez, *dT = T;
