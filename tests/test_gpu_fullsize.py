@@ -74,14 +74,17 @@ def test_free_space_full_batch_fp32(built, free_batch):
     sub = free_batch.select(np.arange(512, 768))
     s0, s1 = s.plan(p0, p1, sub)
     assert np.array_equal(s1.bez, g1.bez[512:768]) and np.array_equal(s1.iter_used, g1.iter_used[512:768])
-    # sample parity against the fp64 oracle
+    # sample parity against the fp64 oracle: 32 problems spread over the batch.  rtn == 1 is a stagnation exit
+    # ((dJ)^2 < 0.01 J, ddp_optimizer.cpp:374), not a KKT point, and about one N = 100 problem in thirty is
+    # ill-conditioned enough for float storage to stop tens of iterations away from fp64 (measured on this sample:
+    # median 1.3e-7, 90 % 1.3e-6, one problem 0.64; tools/f32_fullsize_dev.py) - hence quantiles, not a maximum
+    idx = np.arange(0, B, 128)
+    r0, r1 = refapi.plan_batch(p0, p1, free_batch.select(idx))
+    assert (g1.rtn[idx] == r1.rtn).mean() >= 0.9
+    dev = np.abs(g1.cost[idx] / r1.cost - 1)
+    assert np.median(dev) < 1e-5 and np.quantile(dev, 0.85) < 1e-3, np.sort(dev)[::-1][:5]
     idx = np.array([0, 777, 2048, 4095])
     r0, r1 = refapi.plan_batch(p0, p1, free_batch.select(idx))
-    conv = (r1.rtn == 1) & (g1.rtn[idx] == 1)
-    assert conv.any()
-    # rtn == 1 is a stagnation exit ((dJ)^2 < 0.01 J, ddp_optimizer.cpp:374), not a KKT point: fp32 and
-    # fp64 may stop a few iterations apart, so the objective at exit agrees only to a few percent
-    assert np.abs(g1.cost[idx] / r1.cost - 1)[conv].max() < 3e-2
     # at a FIXED iteration count the two precisions follow the same path much more closely
     pf = abi.phase1_params(iter_max=6, fixed_iters=1)
     b1 = free_batch.select(idx).with_init(None, T0=np.where((r0.rtn == 2)[:, None], r0.T, free_batch.T0[idx]),

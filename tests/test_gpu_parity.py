@@ -65,8 +65,12 @@ def test_whole_solve_matches_golden_fp64(built, name):
     s.close()
 
 
-@pytest.mark.parametrize("name", ["free_n5", "corridor_n8", "corridor_n8_minvo", "free_n6_tp1"])
+@pytest.mark.parametrize("name", helpers.CASES)
 def test_whole_solve_fp32_tolerance(built, name):
+    """DIRECT_F32 (float storage, double arithmetic) on the golden cases: SURVEY.md 8(c)'s whole-solve tolerances for
+    fp32 (cost 1e-3, durations 1e-3) with a decade to spare on the cost; measured 1.4e-5 / 3e-4 at worst
+    (tools/f32_golden_dev.py).  The distribution over random problems, with its ill-conditioned tail, is bounded in
+    tests/test_gpu_soak.py::test_float_storage_deviation_distribution."""
     g, batch = helpers.load_case(name)
     p0, p1 = helpers.case_params(name)
     s = make_solver(batch, np.float32)
@@ -77,10 +81,9 @@ def test_whole_solve_fp32_tolerance(built, name):
     b1 = helpers.phase1_batch(g, batch)
     f1 = s.solve(p1, b1.with_init(None, T0=b1.T0, infeas_in=b1.infeas_in, init_poly=g["p0_poly"]))
     assert (f1.rtn == g["p1_rtn"].astype(int)).all()
-    assert np.abs(f1.cost / g["p1_cost"] - 1).max() < 2e-2, np.abs(f1.cost / g["p1_cost"] - 1).max()
-    assert helpers.rel(f1.T, g["p1_T"]) < 5e-2
-    same = f1.iter_used == g["p1_iter_used"].astype(int)
-    assert np.abs(f1.cost / g["p1_cost"] - 1)[same].max(initial=0) < 1e-3
+    assert np.abs(f1.cost / g["p1_cost"] - 1).max() < 1e-4, np.abs(f1.cost / g["p1_cost"] - 1).max()
+    assert helpers.rel(f1.T, g["p1_T"]) < 1e-3
+    assert np.abs(f1.iter_used - g["p1_iter_used"].astype(int)).max() <= 3
     s.close()
 
 
