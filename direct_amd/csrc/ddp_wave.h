@@ -254,7 +254,8 @@ inline int emu_any(const int* v) {
 // ---- per-solve constants (by-value arguments of polyCurveGeneration, DDPH:275-289) ------------
 struct SolveConst {
   double max_vel, max_acc, w_snap, w_term, w_time, reg_base, shift, tol;
-  int iter_max, time_power, zero_init, line_init, minvo, fixed_iters, exact_dt, pad;
+  int iter_max, time_power, zero_init, line_init, minvo, fixed_iters, exact_dt;
+  int pair_trials;  // scheduling only: evaluate line-search steps 1..10 two per sweep (results are unchanged)
 };
 
 // ---- per-trajectory solver state (algParam + the scalar members of fwdPass / bwdPass) ---------
@@ -283,9 +284,10 @@ struct Batch {
   const Real* init_poly;
   const Real* seeds;     // [B][nmax][3] Polytope.seed_coord (line-init only)
   const uint8_t* infeas_in;
-  Real* X[2];   // [B][nmax+1][kXS]: x_k (9), u_k (10), position low words (3), pad
-  Real* S[2];   // [B][nmax][ncs]
-  Real* Y[2];   // [B][nmax][ncs]
+  // Three iterate buffers: `cur` and two trial buffers (the line search evaluates two step sizes per sweep)
+  Real* X[3];   // [B][nmax+1][kXS]: x_k (9), u_k (10), position low words (3), pad
+  Real* S[3];   // [B][nmax][ncs]
+  Real* Y[3];   // [B][nmax][ncs]
   Real* KU;     // [B][nmax][100]: ku (10), Ku (10x9 row-major)
   Real* KS;     // [B][nmax][ncs]
   Real* KY;     // [B][nmax][ncs]
@@ -297,10 +299,17 @@ struct Batch {
 constexpr int kXS = 24;  // knot record stride of X: x (9), u (10), low parts of the position (3), pad (2)
 typedef double Acc;      // accumulator type of the condensed system (see WaveLds)
 
+// state of one line-search trial of the forward pass (LDS)
+template <typename Real>
+struct FwdTrial {
+  Real tpn[8], zn[kXS], dz[kXS], xn[12], xnx[12], valn[48], qp[12], G[48];
+};
+
 // ---- LDS (one per wave) ------------------------------------------------------------------------
 // RowT: type of the per-row D / g staging arrays (the storage type: float halves them in DIRECT_F32).
 template <typename Real, typename RowT, int RPL>
 struct WaveLds {
+  typedef FwdTrial<Real> FwdT;
   static constexpr int kPMax = (64 * RPL - 55) / 6 > kPLim ? kPLim : (64 * RPL - 55) / 6;  // planes per knot
   TrajState st;
   // value / d-dT base tables with Ek_inv folded in (fixed for the launch).  Rows 15..17: [F|G] and its
@@ -359,8 +368,8 @@ struct WaveLds {
       };
     };
     struct {  // ---- forward pass / evaluation sweep only
-      Real tpn[8], zn[kXS], dz[kXS], xn[12], xnx[12], valn[48], qp[12];
       Real KUr[100];  // gains of the knot as stored in HBM
+      FwdT ft[2];     // two line-search trials (step sizes alpha and alpha / 2) share a sweep
     };
   };
 };
@@ -498,17 +507,18 @@ struct Wave {
   typedef DDP_GLOBAL const St GCSt;
   typedef DDP_GLOBAL const int32_t GCInt;
   struct SweepPtrs {
-    GSt *X[2], *S[2], *Y[2];  // [0] = buffer `cur`, [1] = the trial buffer
+    GSt *X[3], *S[3], *Y[3];  // [0] = buffer `cur`, [1], [2] = the trial buffers (cur + 1, cur + 2 mod 3)
     GSt *KS, *KY, *KU;
     GCSt* planes;
     GCInt* n_planes;
   };
   SweepPtrs sp;
   DDP_DEV void set_sweep_ptrs(int cur) {
-    for (int i = 0; i < 2; i++) {
-      sp.X[i] = (GSt*)B.X[i ? 1 - cur : cur];
-      sp.S[i] = (GSt*)B.S[i ? 1 - cur : cur];
-      sp.Y[i] = (GSt*)B.Y[i ? 1 - cur : cur];
+    for (int i = 0; i < 3; i++) {
+      const int bi = cur + i < 3 ? cur + i : cur + i - 3;
+      sp.X[i] = (GSt*)B.X[bi];
+      sp.S[i] = (GSt*)B.S[bi];
+      sp.Y[i] = (GSt*)B.Y[bi];
       DDP_OPAQUE_S(sp.X[i]);
       DDP_OPAQUE_S(sp.S[i]);
       DDP_OPAQUE_S(sp.Y[i]);
@@ -771,10 +781,10 @@ struct Wave {
     for (int a2 = 0; a2 < 3; a2++) acc += L.Rc[a * 3 + a2] * tpw[a + a2 + 1] * zz[9 + 3 * a2 + d];
     return acc * zz[9 + a9];
   }
-  DDP_DEV double knot_cost(Real T) const {  // q from the nine partial products in L.qp
+  DDP_DEV double knot_cost(Real T, const Real* qp) const {  // q from the nine partial products in qp
     Real acc = 0;
 #pragma unroll
-    for (int a = 0; a < 9; a++) acc += L.qp[a];
+    for (int a = 0; a < 9; a++) acc += qp[a];
     Real q = (Real)0.5 * (Real)B.k.w_snap * acc;
     if (B.k.time_power == 2) q += (Real)0.5 * T * (Real)B.k.w_time * T;
     else q += (Real)0.5 * (Real)B.k.w_time * T;
@@ -812,12 +822,12 @@ struct Wave {
       WSYNC();
       LANES {
         if (lane < 45) L.val[lane] = ctrl_val(L.z, L.tp, lane / 3, lane % 3);
-        else if (lane < 54) { if (do_roll) L.xnx[lane - 45] = next_x(L.z, L.tp, lane - 45); }
-        else if (lane < 63) L.qp[lane - 54] = jerk_part(L.z, L.tp, lane - 54);
+        else if (lane < 54) { if (do_roll) L.ft[0].xnx[lane - 45] = next_x(L.z, L.tp, lane - 45); }
+        else if (lane < 63) L.ft[0].qp[lane - 54] = jerk_part(L.z, L.tp, lane - 54);
         else L.val[45] = T;
       }
       WSYNC();
-      qsum += knot_cost(T);
+      qsum += knot_cost(T, L.ft[0].qp);
       LANES {
         const St* yk = Sp_(B.Y[buf], k);
         for (int i = 0; i < RPL; i++) {
@@ -837,7 +847,7 @@ struct Wave {
           }
         }
         LV(plog).norm();
-        if (do_roll && lane < 9) stx(Xp(buf, k + 1), lane, L.xnx[lane]);
+        if (do_roll && lane < 9) stx(Xp(buf, k + 1), lane, L.ft[0].xnx[lane]);
       }
       WSYNC();
     }
@@ -1609,10 +1619,341 @@ struct Wave {
   }
 
   // ---- forward pass (DDP:647-778) ---------------------------------------------------------------
+  // The filter test and update of one completed trial (DDP:737-757), one entry per lane: a serial scan would chain one
+  // HBM round trip per entry.  Returns 1 and appends (logcost, err) when no entry dominates the trial.
+  DDP_DEV int filter_accept(double* filt, int nfilter, double logcost, double err, int& nkeep) {
+    int rejected = 0;
+    for (int base = 0; base < nfilter && !rejected; base += 64) {
+      PLV(int, rej);
+      LANES {
+        const int idx = base + lane;
+        const bool valid = idx < nfilter;
+        const double f0 = valid ? filt[2 * idx] : 0.0, f1 = valid ? filt[2 * idx + 1] : 0.0;
+        LV(rej) = (valid && logcost >= f0 && err >= f1) ? 1 : 0;
+      }
+      rejected = WAVE_ANY(rej);
+    }
+    if (rejected) return 0;
+    nkeep = 0;
+    for (int base = 0; base < nfilter; base += 64) {
+      PLV(int, keep);
+      PLV(int, pos);
+      PLV(double, e0);
+      PLV(double, e1);
+      LANES {
+        const int idx = base + lane;
+        const bool valid = idx < nfilter;
+        LV(e0) = valid ? filt[2 * idx] : 0.0;
+        LV(e1) = valid ? filt[2 * idx + 1] : 0.0;
+        LV(keep) = (valid && (logcost > LV(e0) || err > LV(e1))) ? 1 : 0;
+      }
+      int total;
+      WAVE_PREFIX_COUNT(keep, pos, total);
+      LANES {
+        if (LV(keep)) {  // compaction in place: nkeep + pos <= base + lane
+          filt[2 * (nkeep + LV(pos))] = LV(e0);
+          filt[2 * (nkeep + LV(pos)) + 1] = LV(e1);
+        }
+      }
+      nkeep += total;
+    }
+    filt[2 * nkeep] = logcost;  // wave-uniform stores
+    filt[2 * nkeep + 1] = err;
+    return 1;
+  }
+
+  // One line-search trial's wave-uniform bookkeeping.
+  struct Trial {
+    int alive, step, neg;
+    double stepsize, qsum;
+  };
+
+  // what an accepted trial leaves behind
+  struct Accept {
+    int accepted, nkeep, step, neg, buf, viol;
+    double stepsize, cost, costq, logcost, err, sumlog, errsum;
+  };
+
+  // One round of the line search: NT trials (step indices step0 .. step0 + NT - 1) in one sweep over the knots.
+  // NT = 1 is the plain forward roll; NT = 2 shares everything that belongs to the old iterate between two trials.
+  template <int NT>
+  DDP_DEV void fwd_round(int step0, int cur, int infeas, Real omt, double mu_d, int nfilter, double* filt, Accept& A) {
+    Real alpha[NT];
+    Trial tr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      tr[t].alive = 1;
+      tr[t].step = step0 + t;
+      tr[t].neg = 0;
+      tr[t].qsum = 0.0;
+      tr[t].stepsize = 1.0;
+      for (int q = 0; q < tr[t].step; q++) tr[t].stepsize *= 0.5;  // DDP:670
+      alpha[t] = DDP_UNIFORM_R((Real)tr[t].stepsize);
+    }
+    PLA(LogProd<Real>, plog, NT);
+    PLA(Real, serr, NT);
+    PLA(int, nviol, NT);
+    LANES {
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        LV(plog)[t].init(); LV(serr)[t] = 0; LV(nviol)[t] = 0;
+        if (lane < 9) L.ft[t].xn[lane] = ldx(XpU(0, 0), lane);
+      }
+    }
+    WSYNC();
+    int Pn = DDP_UNIFORM_I(npU(0));
+    int Pnn = npU(N > 1 ? 1 : 0);
+    PLV(Pre, pre);
+    PLA(int, pkn, RPL);
+    PLA(int, pkc, RPL);
+    LANES { prefetch(LV(pre), LV(pkn), 0, lane, cur, 0, Pn, true, infeas); }
+#pragma unroll 1
+    for (int k_ = 0; k_ < N; k_++) {
+      int k = k_;  // see bwd_sweep()
+      DDP_LAUNDER_S(k);
+      const int P = Pn;
+      DDP_MARK("F_L");
+      PLA(Real, rs, RPL);
+      PLA(Real, ry, RPL);
+      PLA(Real, rks, RPL);
+      PLA(Real, rky, RPL);
+      LANES {
+        commit(LV(pre), lane, P, true);
+        for (int i = 0; i < RPL; i++) {
+          LV(rs)[i] = (Real)LV(pre).s[i];
+          LV(rks)[i] = (Real)LV(pre).ks[i];
+          LV(ry)[i] = (Real)LV(pre).y[i];    // infeasible: y, ky; feasible: s / c and c of the old iterate
+          LV(rky)[i] = (Real)LV(pre).ky[i];
+          LV(pkc)[i] = LV(pkn)[i];
+        }
+      }
+      // the old T straight from lane 18's prefetch register (no LDS round trip)
+      const Real To = (Real)RDLANE_M(pre, zh, 18);
+      if (k + 1 < N) {
+        Pn = DDP_UNIFORM_I(Pnn);
+        Pnn = npU(k + 2 < N ? k + 2 : k + 1);
+        const int same = (Pn == P) ? 1 : 0;
+        LANES { prefetch(LV(pre), LV(pkn), same, lane, cur, k + 1, Pn, true, infeas); }
+      }
+      WSYNC();
+    DDP_MARK("F_D");
+      // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the new T
+      const Real To2 = DDP_UNIFORM_R(To * To), To4 = DDP_UNIFORM_R(To2 * To2);
+      Real pwo[6];  // T^j, j = 0..5, of the old iterate as wave-uniform operands (same values as the tables)
+#pragma unroll
+      for (int j = 0; j < 6; j++) pwo[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(To, To2, To4, j));
+      Real Tn[NT];
+      Real pwn[NT][6];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        Tn[t] = (Real)0;
+        if (tr[t].alive) {
+          typename Lds::FwdT& F = L.ft[t];
+          PLV(Real, unew);
+          PLV(Real, dxl);
+          LANES {
+            const int l9 = lane < 9 ? lane : 8;
+            const Real xv = F.xn[l9];
+            LV(dxl) = xv - L.z[l9];
+            if (lane < 9) {
+              F.dz[lane] = LV(dxl);
+              F.zn[lane] = xv;
+            }
+          }
+          Real dx[9];  // dx is the same for the ten u lanes: broadcast from lanes 0..8 instead of 18 LDS reads each
+#pragma unroll
+          for (int c = 0; c < 9; c++) dx[c] = RDLANE_V(dxl, c);
+          LANES {
+            LV(unew) = (Real)0;
+            if (lane >= 9 && lane < 19) {
+              const int a = lane - 9;
+              Real kr[9];
+#pragma unroll
+              for (int c = 0; c < 9; c++) kr[c] = L.KUr[10 + a * 9 + c];
+              const Real zl = L.z[lane], kf = L.KUr[a];
+              DDP_LOADS_ISSUED();
+              Real acc = 0;
+#pragma unroll
+              for (int c = 0; c < 9; c++) acc += kr[c] * dx[c];
+              F.dz[lane] = acc;
+              // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
+              // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
+              const Real un = (Real)(St)(zl + alpha[t] * kf + acc);
+              F.zn[lane] = un;
+              LV(unew) = un;
+            }
+          }
+          Tn[t] = RDLANE_V(unew, 18);
+          const Real Tn2 = DDP_UNIFORM_R(Tn[t] * Tn[t]), Tn4 = DDP_UNIFORM_R(Tn2 * Tn2);
+          LANES { F.tpn[lane & 7] = pow3(Tn[t], Tn2, Tn4, lane & 7); }
+#pragma unroll
+          for (int j = 0; j < 6; j++) pwn[t][j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(Tn[t], Tn2, Tn4, j));
+          if (Tn[t] < 0) tr[t].neg = 1;
+        }
+      }
+      WSYNC();
+    DDP_MARK("F_T");
+      // ---- T: control values at the new iterate, A*[dx; Ku dx], x+, jerk cost
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        if (tr[t].alive) {
+          typename Lds::FwdT& F = L.ft[t];
+          LANES {
+            {  // lanes 0..44: control values; 45..53: x+ (rows of [F|G]); 54..62: jerk-cost products (rows of R)
+              const int l62 = lane < 63 ? lane : 62;
+              const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
+              const int crd = cr < 15 ? cr : 14;  // the d/dT table has no rows for the dynamics / cost (unused there)
+              Real dvo = 0, vn = 0, gf = 0;
+              // Summed over the exponent j = i - o instead of the coefficient index i (same terms, same
+              // order: the i < o terms have zero weight): the power T^j is then the same for every lane and
+              // comes from a uniform register instead of three LDS table reads per term.
+#pragma unroll
+              for (int half = 0; half < 2; half++) {  // two batches of 15 operands
+                Real wb6[3], wd6[3], zo6[3], dz6[3], zn6[3];
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) {
+                  const int j = 3 * half + jj;
+                  const bool on = (j < 4) || (j + o < 6);  // o <= 2
+                  const int i = on ? j + o : 5;
+                  const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[crd * 6 + i];
+                  wb6[jj] = on ? wbv : (Real)0;
+                  wd6[jj] = on ? wdv : (Real)0;
+                  zo6[jj] = L.z[3 * i + d];
+                  dz6[jj] = F.dz[3 * i + d];
+                  zn6[jj] = F.zn[3 * i + d];
+                }
+                DDP_LOADS_ISSUED();
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) {
+                  const int j = 3 * half + jj;
+                  const Real w = wb6[jj] * pwo[j];
+                  gf += w * dz6[jj];
+                  dvo += wd6[jj] * pwo[j < 1 ? 0 : j - 1] * zo6[jj];
+                  vn += wb6[jj] * pwn[t][j] * zn6[jj];
+                }
+              }
+              const Real un = F.zn[9 + (lane < 54 ? 0 : l62 - 54)], dT = F.dz[18];
+              if (lane < 45) F.G[lane] = gf + dvo * dT;
+              Real* dst = lane < 45 ? &F.valn[l62] : (lane < 54 ? &F.xnx[l62 - 45] : &F.qp[l62 - 54]);
+              *dst = lane < 54 ? vn : vn * un;  // u_a[d] * (R u)_a[d]: the nine of them sum to u'Ru (DDP:1294-1305)
+            }
+            if (lane == 63) {
+              F.valn[45] = F.zn[18];
+              F.G[45] = F.dz[18];
+            }
+          }
+        }
+      }
+      WSYNC();
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        if (tr[t].alive) tr[t].qsum += knot_cost(Tn[t], L.ft[t].qp);
+    DDP_MARK("F_R");
+      // ---- R: rows: s+, y+, c+, fraction-to-boundary tests
+      PLA(int, bad, NT);
+      LANES {
+#pragma unroll
+        for (int t = 0; t < NT; t++) LV(bad)[t] = 0;
+        for (int i = 0; i < RPL; i++) {
+          // branch-free rows: empty slots alias row 0, their stores / reductions are masked
+          const RowK<Real> rk = row_unpack(LV(pkc)[i]);
+          const int r = rk.r;
+          const bool in = r >= 0;
+          const Real s = LV(rs)[i];
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+            if (tr[t].alive) {
+              typename Lds::FwdT& F = L.ft[t];
+              GSt* sn = SpU(sp.S[1 + t], k);
+              const Real az = row_lin(F.G, rk);
+              const Real cn = row_c(F.valn, rk);
+              Real snew;
+              if (infeas) {  // DDP:680-687
+                GSt* yn = SpU(sp.Y[1 + t], k);
+                const Real y = LV(ry)[i];
+                const Real ynew = (Real)(St)(y + alpha[t] * LV(rky)[i] - az);
+                snew = (Real)(St)(s + alpha[t] * LV(rks)[i] + (s * frcp(y)) * az);
+                LV(bad)[t] |= (in && (ynew < omt * y || snew < omt * s)) ? 1 : 0;
+                LV(plog)[t].mul(in ? ynew : (Real)1);
+                LV(serr)[t] += in ? fabs(cn + ynew) : (Real)0;
+                if (in) {
+                  yn[r] = (St)ynew;
+                  sn[r] = (St)snew;
+                }
+              } else {  // DDP:694-703
+                // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
+                // once (phase R1) instead of every trial re-deriving them from the old control values
+                const Real co = LV(rky)[i];
+                snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - LV(ry)[i] * az);
+                LV(bad)[t] |= (in && (cn > omt * co || snew < omt * s)) ? 1 : 0;
+                LV(plog)[t].mul(in ? -cn : (Real)1);
+                if (in) sn[r] = (St)snew;
+              }
+              LV(nviol)[t] += (in && cn >= (Real)2.0e-4) ? 1 : 0;
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          if (tr[t].alive) {
+            LV(plog)[t].norm();
+            if (lane < 19) stx(XpU(1 + t, k), lane, L.ft[t].zn[lane]);
+            if (lane < 9) L.ft[t].xn[lane] = L.ft[t].xnx[lane];
+          }
+        }
+      }
+      int any_alive = 0;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {  // a trial that violates the fraction-to-boundary rule at this knot is over (DDP:689-703)
+        PLV(int, bt);
+        LANES { LV(bt) = LV(bad)[t]; }
+        if (tr[t].alive && WAVE_ANY(bt)) tr[t].alive = 0;
+        any_alive |= tr[t].alive;
+      }
+      WSYNC();
+      if (!any_alive) break;
+    }
+    DDP_MARK("F_END");
+    // acceptance in step order: the first surviving trial that the filter lets through (DDP:716-757)
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (!A.accepted && tr[t].alive) {
+        PLV(Real, slog);
+        PLV(Real, se1);
+        PLV(int, nv1);
+        LANES {
+          if (lane < 9) {
+            stx(XpU(1 + t, N), lane, L.ft[t].xn[lane]);
+            L.z[lane] = L.ft[t].xn[lane] - B.xd[(size_t)b * 9 + lane];
+          }
+        }
+        WSYNC();
+        const double pterm = terminal_sq();
+        WSYNC();
+        LANES {
+          LV(slog) = LV(plog)[t].value();
+          LV(se1) = LV(serr)[t];
+          LV(nv1) = LV(nviol)[t];
+        }
+        const double cost_t = tr[t].qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
+        const double sumlog_t = WAVE_SUM_D(slog), errsum_t = WAVE_SUM_D(se1);
+        const int viol_t = WAVE_SUM_I(nv1);
+        const double logcost_t = cost_t - mu_d * sumlog_t;  // DDP:718-732
+        const double err_t = infeas ? fmax(B.k.tol, errsum_t) : 0.0;
+        if (filter_accept(filt, nfilter, logcost_t, err_t, A.nkeep)) {
+          A.accepted = 1;
+          A.step = tr[t].step; A.neg = tr[t].neg; A.stepsize = tr[t].stepsize; A.buf = 1 + t;
+          A.cost = cost_t; A.costq = tr[t].qsum; A.logcost = logcost_t; A.err = err_t; A.sumlog = sumlog_t; A.errsum = errsum_t;
+          A.viol = viol_t;
+        }
+      }
+    }
+  }
+
   DDP_DEV_NOINLINE void fwd_pass() {
     DDP_LAUNDER_S(b);
     DDP_LAUNDER_S(N);
-    const int cur = DDP_UNIFORM_I(st.cur), nxt = 1 - cur;
+    const int cur = DDP_UNIFORM_I(st.cur);
     set_sweep_ptrs(cur);
     const int infeas = DDP_UNIFORM_I(st.infeas);
     const double mu_d = st.mu;
@@ -1620,281 +1961,45 @@ struct Wave {
     const Real omt = DDP_UNIFORM_R((Real)(1.0 - tau_d));
     const int nfilter = DDP_UNIFORM_I(st.nfilter);
     double* filt = B.filt + (size_t)b * B.fcap * 2;
-    int accepted = 0, step = 0;
-    double cost = 0, costq = 0, logcost = 0, err = 0, sumlog = 0, errsum = 0, stepsize = 0;
-    int viol = 0, neg = 0, nkeep = 0;
+    // Step sizes 2^0 .. 2^-10 are tried in order (DDP:666-670) and the first that passes is taken.  The trials of one
+    // iteration are independent of each other (same gains, same nominal iterate, the filter only changes on
+    // acceptance), so from the second attempt on TWO of them share a sweep: everything that belongs to the old iterate
+    // (prefetch, gains, row descriptors, c and s/c, the old powers of T) is loaded once, and the two dependent chains
+    // interleave in a wave that is otherwise latency-bound.  Acceptance is still decided in step order, each trial's
+    // arithmetic is exactly the single-trial arithmetic, and each writes its own trial buffer: results are bitwise
+    // those of the sequential search.  Rounds: {0}, {1,2}, {3,4}, ... {9,10}.
+    const int pair = (B.k.pair_trials && !infeas) ? 1 : 0;
+    Accept A;
+    A.accepted = 0; A.nkeep = 0; A.step = 0; A.neg = 0; A.buf = 1; A.viol = 0;
+    A.stepsize = 0.0; A.cost = 0.0; A.costq = 0.0; A.logcost = 0.0; A.err = 0.0; A.sumlog = 0.0; A.errsum = 0.0;
+    int next_step = 0;
 #pragma unroll 1
-    for (step = 0; step < 11; step++) {
-      stepsize = 1.0;
-      for (int q = 0; q < step; q++) stepsize *= 0.5;  // DDP:670
-      const Real alpha = DDP_UNIFORM_R((Real)stepsize);
-      PLV(LogProd<Real>, plog);
-      PLV(Real, slog);
-      PLV(Real, serr);
-      PLV(int, nviol);
-      LANES {
-        LV(plog).init(); LV(serr) = 0; LV(nviol) = 0;
-        if (lane < 9) L.xn[lane] = ldx(XpU(0, 0), lane);
+    while (next_step < 11 && !A.accepted) {
+      if (pair && next_step > 0 && next_step + 1 < 11) {
+        fwd_round<2>(next_step, cur, infeas, omt, mu_d, nfilter, filt, A);
+        next_step += 2;
+      } else {
+        fwd_round<1>(next_step, cur, infeas, omt, mu_d, nfilter, filt, A);
+        next_step += 1;
       }
-      WSYNC();
-      double qsum = 0.0;
-      int failed = 0;
-      neg = 0;
-      int Pn = DDP_UNIFORM_I(npU(0));
-      int Pnn = npU(N > 1 ? 1 : 0);
-      PLV(Pre, pre);
-      PLA(int, pkn, RPL);
-      PLA(int, pkc, RPL);
-      LANES { prefetch(LV(pre), LV(pkn), 0, lane, cur, 0, Pn, true, infeas); }
-#pragma unroll 1
-      for (int k_ = 0; k_ < N; k_++) {
-        int k = k_;  // see bwd_sweep()
-        DDP_LAUNDER_S(k);
-        const int P = Pn;
-        DDP_MARK("F_L");
-        PLA(Real, rs, RPL);
-        PLA(Real, ry, RPL);
-        PLA(Real, rks, RPL);
-        PLA(Real, rky, RPL);
-        LANES {
-          commit(LV(pre), lane, P, true);
-          for (int i = 0; i < RPL; i++) {
-            LV(rs)[i] = (Real)LV(pre).s[i];
-            LV(rks)[i] = (Real)LV(pre).ks[i];
-            LV(ry)[i] = (Real)LV(pre).y[i];    // infeasible: y, ky; feasible: s / c and c of the old iterate
-            LV(rky)[i] = (Real)LV(pre).ky[i];
-            LV(pkc)[i] = LV(pkn)[i];
-          }
-        }
-        // the old T straight from lane 18's prefetch register (no LDS round trip)
-        const Real To = (Real)RDLANE_M(pre, zh, 18);
-        if (k + 1 < N) {
-          Pn = DDP_UNIFORM_I(Pnn);
-          Pnn = npU(k + 2 < N ? k + 2 : k + 1);
-          const int same = (Pn == P) ? 1 : 0;
-          LANES { prefetch(LV(pre), LV(pkn), same, lane, cur, k + 1, Pn, true, infeas); }
-        }
-        WSYNC();
-      DDP_MARK("F_D");
-        // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the new T
-        PLV(Real, unew);
-        PLV(Real, dxl);
-        LANES {
-          const int l9 = lane < 9 ? lane : 8;
-          const Real xv = L.xn[l9];
-          LV(dxl) = xv - L.z[l9];
-          if (lane < 9) {
-            L.dz[lane] = LV(dxl);
-            L.zn[lane] = xv;
-          }
-        }
-        Real dx[9];  // dx is the same for the ten u lanes: broadcast from lanes 0..8 instead of 18 LDS reads each
-#pragma unroll
-        for (int c = 0; c < 9; c++) dx[c] = RDLANE_V(dxl, c);
-        LANES {
-          LV(unew) = (Real)0;
-          if (lane >= 9 && lane < 19) {
-            const int a = lane - 9;
-            Real kr[9];
-#pragma unroll
-            for (int c = 0; c < 9; c++) kr[c] = L.KUr[10 + a * 9 + c];
-            const Real zl = L.z[lane], kf = L.KUr[a];
-            DDP_LOADS_ISSUED();
-            Real acc = 0;
-#pragma unroll
-            for (int c = 0; c < 9; c++) acc += kr[c] * dx[c];
-            L.dz[lane] = acc;
-            // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
-            // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
-            const Real un = (Real)(St)(zl + alpha * kf + acc);
-            L.zn[lane] = un;
-            LV(unew) = un;
-          }
-        }
-        const Real Tn = RDLANE_V(unew, 18);
-        const Real To2 = DDP_UNIFORM_R(To * To), To4 = DDP_UNIFORM_R(To2 * To2);
-        const Real Tn2 = DDP_UNIFORM_R(Tn * Tn), Tn4 = DDP_UNIFORM_R(Tn2 * Tn2);
-        LANES { L.tpn[lane & 7] = pow3(Tn, Tn2, Tn4, lane & 7); }
-        // T^j, j = 0..5, of the old and the new iterate as wave-uniform operands (same values as the tables)
-        Real pwo[6], pwn[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          pwo[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(To, To2, To4, j));
-          pwn[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(Tn, Tn2, Tn4, j));
-        }
-        WSYNC();
-        if (Tn < 0) neg = 1;
-      DDP_MARK("F_T");
-        // ---- T: control values at the old and the new iterate, A*[dx; Ku dx], x+, jerk cost
-        LANES {
-          {  // lanes 0..44: control values; 45..53: x+ (rows of [F|G]); 54..62: jerk-cost products (rows of R)
-            const int l62 = lane < 63 ? lane : 62;
-            const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
-            const int crd = cr < 15 ? cr : 14;  // the d/dT table has no rows for the dynamics / cost (unused there)
-            Real dvo = 0, vn = 0, gf = 0;
-            // Summed over the exponent j = i - o instead of the coefficient index i (same terms, same
-            // order: the i < o terms have zero weight): the power T^j is then the same for every lane and
-            // comes from a uniform register instead of three LDS table reads per term.
-#pragma unroll
-            for (int half = 0; half < 2; half++) {  // two batches of 15 operands
-              Real wb6[3], wd6[3], zo6[3], dz6[3], zn6[3];
-#pragma unroll
-              for (int jj = 0; jj < 3; jj++) {
-                const int j = 3 * half + jj;
-                const bool on = (j < 4) || (j + o < 6);  // o <= 2
-                const int i = on ? j + o : 5;
-                const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[crd * 6 + i];
-                wb6[jj] = on ? wbv : (Real)0;
-                wd6[jj] = on ? wdv : (Real)0;
-                zo6[jj] = L.z[3 * i + d];
-                dz6[jj] = L.dz[3 * i + d];
-                zn6[jj] = L.zn[3 * i + d];
-              }
-              DDP_LOADS_ISSUED();
-#pragma unroll
-              for (int jj = 0; jj < 3; jj++) {
-                const int j = 3 * half + jj;
-                const Real w = wb6[jj] * pwo[j];
-                gf += w * dz6[jj];
-                dvo += wd6[jj] * pwo[j < 1 ? 0 : j - 1] * zo6[jj];
-                vn += wb6[jj] * pwn[j] * zn6[jj];
-              }
-            }
-            const Real un = L.zn[9 + (lane < 54 ? 0 : l62 - 54)], dT = L.dz[18];
-            if (lane < 45) L.G[lane] = gf + dvo * dT;
-            Real* dst = lane < 45 ? &L.valn[l62] : (lane < 54 ? &L.xnx[l62 - 45] : &L.qp[l62 - 54]);
-            *dst = lane < 54 ? vn : vn * un;  // u_a[d] * (R u)_a[d]: the nine of them sum to u'Ru (DDP:1294-1305)
-          }
-          if (lane == 63) {
-            L.valn[45] = L.zn[18];
-            L.G[45] = L.dz[18];
-          }
-        }
-        WSYNC();
-        qsum += knot_cost(Tn);
-      DDP_MARK("F_R");
-        // ---- R: rows: s+, y+, c+, fraction-to-boundary tests
-        PLV(int, bad);
-        LANES {
-          LV(bad) = 0;
-          GSt* sn = SpU(sp.S[1], k);
-          GSt* yn = SpU(sp.Y[1], k);
-          for (int i = 0; i < RPL; i++) {
-            // branch-free rows: empty slots alias row 0, their stores / reductions are masked
-            const RowK<Real> rk = row_unpack(LV(pkc)[i]);
-            const int r = rk.r;
-            const bool in = r >= 0;
-            const Real az = row_lin(L.G, rk);
-            const Real cn = row_c(L.valn, rk);
-            const Real s = LV(rs)[i];
-            Real snew;
-            if (infeas) {  // DDP:680-687
-              const Real y = LV(ry)[i];
-              const Real ynew = (Real)(St)(y + alpha * LV(rky)[i] - az);
-              snew = (Real)(St)(s + alpha * LV(rks)[i] + (s * frcp(y)) * az);
-              LV(bad) |= (in && (ynew < omt * y || snew < omt * s)) ? 1 : 0;
-              LV(plog).mul(in ? ynew : (Real)1);
-              LV(serr) += in ? fabs(cn + ynew) : (Real)0;
-              if (in) {
-                yn[r] = (St)ynew;
-                sn[r] = (St)snew;
-              }
-            } else {  // DDP:694-703
-              // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them once
-              // (phase R1) instead of every trial re-deriving them from the old control values
-              const Real co = LV(rky)[i];
-              snew = (Real)(St)(s + alpha * LV(rks)[i] - LV(ry)[i] * az);
-              LV(bad) |= (in && (cn > omt * co || snew < omt * s)) ? 1 : 0;
-              LV(plog).mul(in ? -cn : (Real)1);
-              if (in) sn[r] = (St)snew;
-            }
-            LV(nviol) += (in && cn >= (Real)2.0e-4) ? 1 : 0;
-          }
-          LV(plog).norm();
-          if (lane < 19) stx(XpU(1, k), lane, L.zn[lane]);
-          if (lane < 9) L.xn[lane] = L.xnx[lane];
-        }
-        failed = WAVE_ANY(bad);
-        WSYNC();
-        if (failed) break;
-      }
-      DDP_MARK("F_END");
-      if (failed) continue;
-      LANES {
-        if (lane < 9) {
-          stx(XpU(1, N), lane, L.xn[lane]);
-          L.z[lane] = L.xn[lane] - B.xd[(size_t)b * 9 + lane];
-        }
-      }
-      WSYNC();
-      const double pterm = terminal_sq();
-      WSYNC();
-      LANES { LV(slog) = LV(plog).value(); }
-      costq = qsum;
-      cost = qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
-      sumlog = WAVE_SUM_D(slog);
-      errsum = WAVE_SUM_D(serr);
-      viol = WAVE_SUM_I(nviol);
-      logcost = cost - mu_d * sumlog;  // DDP:718-732
-      err = infeas ? fmax(B.k.tol, errsum) : 0.0;
-      // filter (DDP:737-757), one entry per lane: a serial scan would chain one HBM round trip per entry
-      int rejected = 0;
-      for (int base = 0; base < nfilter && !rejected; base += 64) {
-        PLV(int, rej);
-        LANES {
-          const int idx = base + lane;
-          const bool valid = idx < nfilter;
-          const double f0 = valid ? filt[2 * idx] : 0.0, f1 = valid ? filt[2 * idx + 1] : 0.0;
-          LV(rej) = (valid && logcost >= f0 && err >= f1) ? 1 : 0;
-        }
-        rejected = WAVE_ANY(rej);
-      }
-      if (rejected) continue;
-      nkeep = 0;
-      for (int base = 0; base < nfilter; base += 64) {
-        PLV(int, keep);
-        PLV(int, pos);
-        PLV(double, e0);
-        PLV(double, e1);
-        LANES {
-          const int idx = base + lane;
-          const bool valid = idx < nfilter;
-          LV(e0) = valid ? filt[2 * idx] : 0.0;
-          LV(e1) = valid ? filt[2 * idx + 1] : 0.0;
-          LV(keep) = (valid && (logcost > LV(e0) || err > LV(e1))) ? 1 : 0;
-        }
-        int total;
-        WAVE_PREFIX_COUNT(keep, pos, total);
-        LANES {
-          if (LV(keep)) {  // compaction in place: nkeep + pos <= base + lane
-            filt[2 * (nkeep + LV(pos))] = LV(e0);
-            filt[2 * (nkeep + LV(pos)) + 1] = LV(e1);
-          }
-        }
-        nkeep += total;
-      }
-      filt[2 * nkeep] = logcost;  // wave-uniform stores
-      filt[2 * nkeep + 1] = err;
-      accepted = 1;
-      break;
     }
-    if (!accepted) {  // DDP:760-762
+    if (!A.accepted) {  // DDP:760-762
       st.fp_failed = 1;
       st.stepsize = 0.0;
     } else {  // DDP:763-776
-      st.nfilter = nkeep + 1;
-      st.cost = cost;
-      st.costq = costq;
-      st.logcost = logcost;
-      st.err = err;
-      st.sumlog = sumlog;
-      st.errsum = errsum;
-      st.viol = viol;
-      st.neg_time = neg;
-      st.stepsize = stepsize;
-      st.step = step;
+      st.nfilter = A.nkeep + 1;
+      st.cost = A.cost;
+      st.costq = A.costq;
+      st.logcost = A.logcost;
+      st.err = A.err;
+      st.sumlog = A.sumlog;
+      st.errsum = A.errsum;
+      st.viol = A.viol;
+      st.neg_time = A.neg;
+      st.stepsize = A.stepsize;
+      st.step = A.step;
       st.fp_failed = 0;
-      st.cur = nxt;
+      st.cur = cur + A.buf < 3 ? cur + A.buf : cur + A.buf - 3;
     }
   }
 

@@ -247,7 +247,7 @@ struct direct_ddp_handle_s {
   void* seeds = nullptr;
   int32_t *n_seg = nullptr, *n_planes = nullptr;
   uint8_t *infeas_in = nullptr, *infeas_next = nullptr;
-  void *X[2] = {nullptr, nullptr}, *S[2] = {nullptr, nullptr}, *Y[2] = {nullptr, nullptr};
+  void *X[3] = {nullptr, nullptr, nullptr}, *S[3] = {nullptr, nullptr, nullptr}, *Y[3] = {nullptr, nullptr, nullptr};
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
   double* filt = nullptr;
   TrajState* st = nullptr;
@@ -268,6 +268,7 @@ struct direct_ddp_handle_s {
   int* sched = nullptr;
   int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device
   int sched_chunk = 1;   // outer-loop trips per ticket (DIRECT_DDP_CHUNK at create time; experiments)
+  int pair_trials = -1;  // two line-search steps per forward sweep from the second attempt on: -1 auto, DIRECT_DDP_PAIR=0|1 forces
   int sched_prio = 1;    // chunks that had to wait for their predecessor run at raised wave priority (DIRECT_DDP_PRIO=0: off)
   bool dynamic = true;
   // current batch
@@ -303,7 +304,7 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   B.init_poly = (const Real*)in.init_poly;
   B.seeds = (const Real*)in.seeds;
   B.infeas_in = in.infeas_in;
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 3; i++) {
     B.X[i] = (Real*)h->X[i]; B.S[i] = (Real*)h->S[i]; B.Y[i] = (Real*)h->Y[i];
   }
   B.KU = (Real*)h->KU; B.KS = (Real*)h->KS; B.KY = (Real*)h->KY; B.filt = h->filt; B.st = h->st;
@@ -315,6 +316,9 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   k.tol = 1.0e-7;                        // ddp_optimizer.cpp:43
   k.iter_max = p.iter_max; k.time_power = p.time_power; k.zero_init = p.zero_init;
   k.line_init = p.line_init; k.minvo = p.minvo; k.fixed_iters = p.fixed_iters; k.exact_dt = p.exact_dt;
+  // two trials per sweep pay off where the launch is bound by its slowest chain (batch up to twice the resident
+  // waves: +4 % at B = 4096) and cost ~1 % where it is throughput-bound; results are identical either way
+  k.pair_trials = h->pair_trials >= 0 ? h->pair_trials : ((h->sched_slots > 0 && in.batch <= 2 * h->sched_slots) ? 1 : 0);
   return B;
 }
 
@@ -498,7 +502,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r); A(&h->init_poly, B * nm * 18 * r);
   A(&h->seeds, B * nm * 3 * r);
   A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B); A(&h->infeas_next, B);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 3; i++) {
     A(&h->X[i], B * (nm + 1) * kXS * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
   }
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
@@ -516,6 +520,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
                                             : resident_slots<float>(h, prop.multiProcessorCount);
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
   if (const char* ev = getenv("DIRECT_DDP_PRIO")) h->sched_prio = atoi(ev);
+  if (const char* ev = getenv("DIRECT_DDP_PAIR")) h->pair_trials = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_SLOTS")) {  // experiments: fewer persistent waves than fit
     const int v = atoi(ev);
     if (v > 0 && v < h->sched_slots) h->sched_slots = v;

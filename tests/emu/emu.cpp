@@ -17,7 +17,7 @@ template <typename Real>   // Real = storage type here; the compute type is chos
 struct Emu {
   Batch<Real> B;
   int compute64 = 0;
-  std::vector<Real> x0, xd, T0, planes, init_bez, init_poly, seeds, X0, X1, S0, S1, Y0, Y1, KU, KS, KY;
+  std::vector<Real> x0, xd, T0, planes, init_bez, init_poly, seeds, X0, X1, X2, S0, S1, S2, Y0, Y1, Y2, KU, KS, KY;
   std::vector<int32_t> n_seg, n_planes;
   std::vector<uint8_t> infeas_in;
   std::vector<double> filt;
@@ -71,8 +71,9 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   E->infeas_in.assign(B, (uint8_t)p->infeas);
   if (in->infeas_in) E->infeas_in.assign(in->infeas_in, in->infeas_in + B);
   size_t nx = (size_t)B * (nm + 1) * kXS, ns = (size_t)B * nm * ncm;
-  E->X0.assign(nx, 0); E->X1.assign(nx, 0);
-  E->S0.assign(ns, 0); E->S1.assign(ns, 0); E->Y0.assign(ns, 0); E->Y1.assign(ns, 0);
+  E->X0.assign(nx, 0); E->X1.assign(nx, 0); E->X2.assign(nx, 0);
+  E->S0.assign(ns, 0); E->S1.assign(ns, 0); E->S2.assign(ns, 0);
+  E->Y0.assign(ns, 0); E->Y1.assign(ns, 0); E->Y2.assign(ns, 0);
   E->KU.assign((size_t)B * nm * 100, 0); E->KS.assign(ns, 0); E->KY.assign(ns, 0);
   E->filt.assign((size_t)B * Bt.fcap * 2, 0.0);
   E->st.assign(B, TrajState());
@@ -82,14 +83,16 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   Bt.init_poly = in->init_poly ? E->init_poly.data() : nullptr;
   Bt.seeds = in->seeds ? E->seeds.data() : nullptr;
   Bt.infeas_in = E->infeas_in.data();
-  Bt.X[0] = E->X0.data(); Bt.X[1] = E->X1.data(); Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data();
-  Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
+  Bt.X[0] = E->X0.data(); Bt.X[1] = E->X1.data(); Bt.X[2] = E->X2.data();
+  Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data(); Bt.S[2] = E->S2.data();
+  Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.Y[2] = E->Y2.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
   Bt.KY = E->KY.data(); Bt.filt = E->filt.data(); Bt.st = E->st.data();
   SolveConst& k = Bt.k;
   k.max_vel = p->max_vel; k.max_acc = p->max_acc; k.w_snap = p->w_snap; k.w_term = p->w_terminal;
   k.w_time = p->w_time; k.reg_base = p->zero_init ? 1.6 : 4.0; k.shift = p->minvo ? 0.0 : 2.0e-4;
   k.tol = 1.0e-7; k.iter_max = p->iter_max; k.time_power = p->time_power; k.zero_init = p->zero_init;
   k.line_init = p->line_init; k.minvo = p->minvo; k.fixed_iters = p->fixed_iters; k.exact_dt = p->exact_dt;
+  k.pair_trials = getenv("DIRECT_EMU_PAIR") ? atoi(getenv("DIRECT_EMU_PAIR")) : 1;
   dispatch(*E, [&](auto& W) {
     W.init_tables();
     memset(&W.st, 0, sizeof(W.st));

@@ -194,6 +194,22 @@ def test_ticket_scheduler_is_bitwise_equal_to_one_workgroup_per_trajectory(built
     assert res["dynamic"][1].iter_used.max() > 1
 
 
+def test_paired_line_search_trials_are_bitwise_equal_to_the_sequential_search(built, corridor_batch, monkeypatch):
+    """From the second attempt on two step sizes share a forward sweep (fwd_round<2>): each trial's arithmetic and the
+    order of acceptance are those of the sequential search, so every output must be bit-identical - natural exits,
+    both phases, 4096 polyhedron corridors (mean 2.4 trials per iteration, up to 11)."""
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIRECT_DDP_PAIR", mode)
+        s = solver.DdpSolver(B, N, corridor_batch.p_max, np.float32)
+        res[mode] = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=40), corridor_batch.astype(np.float32))
+        s.close()
+    for a, b in zip(res["0"], res["1"]):
+        for f in ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert res["1"][1].iter_used.max() > 5
+
+
 def test_output_sampling_of_the_full_batch(built, free_batch):
     """direct_traj_sample_batch on 4096 solved trajectories: size-independent properties of the samples
     (the oracle is checked on a random subset)."""
