@@ -500,7 +500,7 @@ struct Wave {
   // every 64-bit address product stays on the scalar unit (under SGPR pressure `b` ends up in a VGPR and
   // each address would otherwise cost several quarter-rate v_mad_u64_u32).
   // The array bases themselves are read from the kernel arguments ONCE per sweep (set_sweep_ptrs) and made
-  // opaque: the iterate buffers are selected by a run-time index (cur / 1 - cur), which otherwise costs a
+  // opaque: the iterate buffers are selected by a run-time index (cur, cur + 1, cur + 2 mod 3), which otherwise costs a
   // scalar load from the kernarg segment - and an lgkmcnt(0) stall that also drains the LDS queue - in
   // every knot.  An opaque SGPR pair can at worst be spilled to a VGPR lane (two v_readlane to restore).
   typedef DDP_GLOBAL St GSt;
@@ -532,7 +532,7 @@ struct Wave {
     DDP_OPAQUE_S(sp.n_planes);
   }
   DDP_DEV size_t rowU(int k) const { return (size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k); }
-  // sel: 0 = the current iterate buffer, 1 = the trial buffer
+  // sel: 0 = the current iterate buffer, 1 / 2 = the trial buffers
   DDP_DEV GSt* XpU(int sel, int k) const { return sp.X[sel] + (size_t)(unsigned)DDP_UNIFORM_I(b * (B.nmax + 1) + k) * kXS; }
   DDP_DEV GSt* SpU(GSt* base, int k) const { return base + rowU(k) * B.ncs; }
   DDP_DEV GCSt* planesU(int k) const { return sp.planes + rowU(k) * (B.pmax * 4); }
