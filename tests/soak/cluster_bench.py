@@ -1,5 +1,5 @@
 """Corridor-cluster generation: batched polygonGeneration on the device against the CPU oracle on the same seeds.
-usage: python tools/cluster_bench.py [n_seeds] [X Y Z]    (run through gpurun; add rocprofv3 --kernel-trace --stats for
+usage: python tests/soak/cluster_bench.py [n_seeds] [X Y Z]    (run through gpurun; add rocprofv3 --kernel-trace --stats for
 per-kernel times).  Prints one JSON line."""
 import json
 import sys

@@ -96,6 +96,13 @@ def test_product_package_does_not_import_the_oracle():
                 assert "DIRECT_EMULATE" not in txt or f == "ddp_wave.h", (dirpath, f)
 
 
+def test_tools_do_not_use_the_oracle():
+    """tools/ are measurement helpers of the product path; scripts that need the oracle live under tests/soak/."""
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh", ".hip")):
+            assert "oracle" not in open(os.path.join(ROOT, "tools", f)).read(), f
+
+
 def test_create_rejects_bad_configs(built):
     lib = solver.lib()
     h = C.c_void_p()

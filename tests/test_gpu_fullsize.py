@@ -77,7 +77,7 @@ def test_free_space_full_batch_fp32(built, free_batch):
     # sample parity against the fp64 oracle: 32 problems spread over the batch.  rtn == 1 is a stagnation exit
     # ((dJ)^2 < 0.01 J, ddp_optimizer.cpp:374), not a KKT point, and about one N = 100 problem in thirty is
     # ill-conditioned enough for float storage to stop tens of iterations away from fp64 (measured on this sample:
-    # median 1.3e-7, 90 % 1.3e-6, one problem 0.64; tools/f32_fullsize_dev.py) - hence quantiles, not a maximum
+    # median 1.3e-7, 90 % 1.3e-6, one problem 0.64; tests/soak/f32_fullsize_dev.py) - hence quantiles, not a maximum
     idx = np.arange(0, B, 128)
     r0, r1 = refapi.plan_batch(p0, p1, free_batch.select(idx))
     assert (g1.rtn[idx] == r1.rtn).mean() >= 0.9

@@ -69,7 +69,7 @@ def test_whole_solve_matches_golden_fp64(built, name):
 def test_whole_solve_fp32_tolerance(built, name):
     """DIRECT_F32 (float storage, double arithmetic) on the golden cases: SURVEY.md 8(c)'s whole-solve tolerances for
     fp32 (cost 1e-3, durations 1e-3) with a decade to spare on the cost; measured 1.4e-5 / 3e-4 at worst
-    (tools/f32_golden_dev.py).  The distribution over random problems, with its ill-conditioned tail, is bounded in
+    (tests/soak/f32_golden_dev.py).  The distribution over random problems, with its ill-conditioned tail, is bounded in
     tests/test_gpu_soak.py::test_float_storage_deviation_distribution."""
     g, batch = helpers.load_case(name)
     p0, p1 = helpers.case_params(name)
