@@ -155,7 +155,8 @@ def label_model_line(torch, dev, B, with_cpu):
         from oracle import quadapi
         t = time.perf_counter()
         r = quadapi.solve_batch(p, N, x0[:64], xg[:64], n_threads=1)
-        out["cpu_single_thread_iter_per_s"] = float(r["iters"].sum() / (time.perf_counter() - t))
+        out["cpu_baseline"] = {"value": float(r["iters"].sum() / (time.perf_counter() - t)), "unit": "iter/s", "cores": 1,
+                               "kind": "port", "sample": "64 of the trajectories, this repo's own CPU checker (no reference exists)"}
     return out
 
 
