@@ -867,6 +867,42 @@ struct Wave {
     st.neg_time = neg;
   }
 
+  // The forward trials of a feasible-mode iteration read c and s / c of the nominal iterate from the y / ky arrays,
+  // where a COMPLETED backward sweep leaves them.  When the backward pass has given up (21 failures at the largest
+  // regulariser, DDP:297-310) the reference still runs its forward pass on whatever gains there are; the rows of the
+  // knots the last sweep never reached are then rebuilt here, from the iterate, as the reference's forward pass
+  // recomputes them (DDP:696).  Off the hot path: it runs only on the way to rtn = -4.
+  DDP_DEV void refresh_row_cache() {
+    const int buf = st.cur;
+    for (int k = 0; k < N; k++) {
+      const int P = np_(k);
+      LANES {
+        if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
+        for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
+      }
+      WSYNC();
+      const Real T = L.z[18];
+      LANES { if (lane < 8) L.tp[lane] = powi(T, lane); }
+      WSYNC();
+      LANES {
+        if (lane < 45) L.val[lane] = ctrl_val(L.z, L.tp, lane / 3, lane % 3);
+        else if (lane == 63) L.val[45] = T;
+      }
+      WSYNC();
+      LANES {
+        for (int i = 0; i < RPL; i++) {
+          const RowK<Real> rk = row_slot(i, lane, P);
+          if (rk.r >= 0) {
+            const Real c = row_c(L.val, rk), sv = (Real)Sp_(B.S[buf], k)[rk.r];
+            Sp_(B.KY, k)[rk.r] = (St)c;
+            Sp_(B.Y[buf], k)[rk.r] = (St)(sv * frcp(c));
+          }
+        }
+      }
+      WSYNC();
+    }
+  }
+
   // resetfilter (DDP:1636-1662) from the sums of the current iterate
   DDP_DEV void reset_filter() {
     double logcost = st.cost - st.mu * st.sumlog;
@@ -2011,6 +2047,7 @@ struct Wave {
       else st.bp_no_upd = 0;
       if (st.bp_no_upd > 20) break;
     }
+    if (st.bp_failed && !st.infeas) refresh_row_cache();
     fwd_pass();
     st.fwd_passes++;
     if (st.neg_time) {  // DDP:317-326

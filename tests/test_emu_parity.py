@@ -168,3 +168,18 @@ def test_emulated_begin_rejects_bad_sizes_row_by_row():
     assert (got.rtn[rows] == abi.RTN_INVALID).all() and not got.bez[rows].any() and not got.T[rows].any()
     for i in (0, 3, 5):
         assert got.rtn[i] == want.rtn[i] and np.array_equal(got.bez[i], want.bez[i])
+
+
+def test_backward_pass_stuck_exit_matches_oracle():
+    """rtn = -4 (DDP:392-396): the backward pass fails 21 times at the largest regulariser and the reference still
+    runs its forward pass.  In feasible mode the kernels then rebuild the per-row values the forward trials read
+    (Wave::refresh_row_cache) instead of trusting a sweep that never completed."""
+    b = problems.make_batch("corridor", 32, 8, seed=1)
+    bb = b.with_init(np.zeros((32, 8, 18)), T0=b.T0 * 3.0, infeas_in=np.zeros(32, np.uint8))
+    p = abi.phase1_params(iter_max=60)
+    r, _ = refapi.solve_batch(p, bb)
+    e = emuapi.solve_batch(p, bb)
+    assert (r.rtn == -4).sum() >= 1
+    assert (e.rtn == r.rtn).all() and (e.iter_used == r.iter_used).all() and (e.fwd_passes == r.fwd_passes).all()
+    ok = np.isfinite(r.cost)
+    assert np.abs(e.cost[ok] / r.cost[ok] - 1).max() < 1e-8
