@@ -270,12 +270,13 @@ typedef enum {
   DIRECT_FIELD_X = 0,      /* [b][n_seg_max+1][9] */
   DIRECT_FIELD_U = 1,      /* [b][n_seg_max][10] */
   DIRECT_FIELD_S = 2,      /* [b][n_seg_max][nc_max] */
-  DIRECT_FIELD_Y = 3,      /* [b][n_seg_max][nc_max] */
+  DIRECT_FIELD_Y = 3,      /* [b][n_seg_max][nc_max]; the dual iterate exists in infeasible mode only (in feasible
+                              mode the array is scratch: s/c of the nominal iterate for the line search) */
   DIRECT_FIELD_C = 4,      /* [b][n_seg_max][nc_max] (recomputed from x,u on read) */
   DIRECT_FIELD_KU = 5,     /* [b][n_seg_max][10] */
   DIRECT_FIELD_KUU = 6,    /* [b][n_seg_max][10][9] */
   DIRECT_FIELD_KS = 7,     /* [b][n_seg_max][nc_max] */
-  DIRECT_FIELD_KY = 8,     /* [b][n_seg_max][nc_max] */
+  DIRECT_FIELD_KY = 8,     /* [b][n_seg_max][nc_max]; infeasible mode only (feasible mode: scratch, c of the iterate) */
   DIRECT_FIELD_SCALARS = 9 /* [b][16]: cost,costq,logcost,err,mu,reg,opterr,stepsize,
                               step,fp_failed,bp_failed,rtn,iter,done,filter_n,infeas */
 } direct_field_t;
