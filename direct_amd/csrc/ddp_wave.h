@@ -97,7 +97,11 @@ inline T emu_uniform(T x, int line) {
 #define DDP_UNIFORM_R(x) direct::uniform_real(x)
 // re-materialise a wave-uniform value: stops LICM from hoisting everything derived from it (slab
 // pointers, strides) out of the outer iteration loop, where it would stay live across both sweeps
+#ifdef DBG_NOL
+#define DDP_LAUNDER_S(x) ((void)0)
+#else
 #define DDP_LAUNDER_S(x) asm volatile("" : "+s"(x))
+#endif
 // Compiler-only memory barrier placed after a block of LDS operand loads: the scheduler otherwise
 // sinks each load next to its use (3 loads, wait, 2 FMAs, 3 loads, wait ...) and every wait exposes
 // a full LDS round trip; with the barrier all loads of the block are in flight before the first wait.
@@ -109,7 +113,11 @@ inline T emu_uniform(T x, int line) {
 // A wave-uniform value the compiler must treat as an opaque SGPR operand.  Without it a lane-dependent
 // select between two kernel-argument fields is turned into ONE lane-indexed vector load from the kernarg
 // segment, i.e. a full memory round trip (and a vmcnt(0) that also drains the prefetch) in the row loop.
+#ifdef DBG_NOO
+#define DDP_OPAQUE_S(x) ((void)0)
+#else
 #define DDP_OPAQUE_S(x) asm("" : "+s"(x))
+#endif
 #define DDP_UMUL24(a, b) __umul24(a, b)  // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
 // A pointer that went through an empty asm is a generic pointer to the compiler (FLAT loads, which also
 // count on lgkmcnt); the sweep's array bases are therefore typed as global-memory pointers.
@@ -130,23 +138,27 @@ constexpr int kPLim = 32;  // DIRECT_P_LIMIT
 
 #if !defined(DIRECT_EMULATE)
 #if defined(DDP_TIMING)
-__device__ unsigned long long g_phase_cycles[32];
+__device__ unsigned long long g_phase_cycles[64];
 __device__ unsigned long long g_phase_last;
 __device__ __forceinline__ constexpr int phase_id(const char* n) {
   // B_L 0 B_T1 1 B_T2 2 B_R1 3 B_S 4 B_S2 5 B_H 6 B_C 7 B_G 8 B_R2 9 B_END 10 F_L 11 F_D 12 F_T 13 F_R 14 F_END 15
+  if (n[0] == 'Z') return 19;
+  if (n[0] == 'X') return n[2] == 'T' ? 16 : n[2] == 'G' ? 17 : 18;  // X_T ticket wait, X_G state load + sweep prologue, X_A after the forward pass
   return n[0] == 'B' ? (n[2] == 'L' ? 0 : n[2] == 'T' ? (n[3] == '1' ? 1 : 2) : n[2] == 'R' ? (n[3] == '1' ? 3 : 9)
                         : n[2] == 'S' ? (n[3] == '2' ? 5 : 4) : n[2] == 'H' ? 6 : n[2] == 'C' ? 7 : n[2] == 'G' ? 8 : 10)
                      : (n[2] == 'L' ? 11 : n[2] == 'D' ? 12 : n[2] == 'T' ? 13 : n[2] == 'R' ? 14 : 15);
 }
 // time since the previous mark is charged to the phase that ENDS here (= the previous mark's phase)
+__device__ int g_phase_last_id;
 __device__ __forceinline__ void phase_tick(const char* name) {
   if (blockIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     unsigned long long t = __builtin_readcyclecounter();
-    static __device__ int last_id;
+    int& last_id = g_phase_last_id;
     if (threadIdx.x == 0) {
+      if (name[0] == 'Z') g_phase_last = t;  // first mark of a launch: nothing to charge
       g_phase_cycles[last_id] += t - g_phase_last;
-      g_phase_cycles[16 + last_id] += 1;
+      g_phase_cycles[32 + last_id] += 1;
       g_phase_last = t;
       last_id = phase_id(name);
     }
@@ -269,11 +281,33 @@ struct TrajState {
   int neg_time, nseg, nc0, npos;  // npos: rows with c > 0 in the last evaluation sweep (DDP:255-269)
 };
 
+// ---- shared line search (scheduling only, see Wave::fwd_pass) -----------------------------------
+// What one completed line-search trial reports: enough for the filter test and for the state an accepted trial
+// leaves behind.  Wave-uniform; a helper wave hands it to the trajectory's owner through HelpSlot::res.
+struct TrialRes {
+  int alive, step, neg, viol;
+  double stepsize, qsum, cost, sumlog, errsum;
+  double pad;
+};
+// One per trajectory.  The owner of a trajectory opens its line search to other waves after step 0 failed; waves
+// that are waiting for this very trajectory (k_iterate_dyn) claim rounds of it instead of sleeping.
+struct HelpSlot {
+  int gen;         // 0: closed; else the tag of the open line search (release-published by the owner)
+  int next_round;  // next unclaimed round, 1..5 = steps (1,2) .. (9,10); owner and helpers draw from it
+  int active;      // helpers inside the protocol; the owner closes with gen = 0 and waits for 0
+  int cancel;      // an earlier step was accepted: running rounds stop at the next knot
+  int cur, seq;    // the nominal iterate's buffer; the owner's tag counter
+  double mu;
+  int done[8];     // done[r] == gen: res[2r-1], res[2r] hold round r's results (release-published by its runner)
+  TrialRes res[12];
+};
+constexpr int kMaxBuf = 11;  // iterate buffers: `cur` + one per concurrently evaluated step (3 without helpers)
+
 // ---- device-resident batch (all pointers are device memory) -----------------------------------
 template <typename Real>
 struct Batch {
   int B, nmax, pmax, ncs;  // ncs = row stride of S/Y/KS/KY (>= 6*pmax+55)
-  int fcap, pad0, pad1, pad2;
+  int fcap, nbuf, pad1, pad2;  // nbuf: iterate buffers in use (3, or kMaxBuf with the shared line search)
   const int32_t* n_seg;
   const Real* x0;
   const Real* xd;
@@ -284,15 +318,17 @@ struct Batch {
   const Real* init_poly;
   const Real* seeds;     // [B][nmax][3] Polytope.seed_coord (line-init only)
   const uint8_t* infeas_in;
-  // Three iterate buffers: `cur` and two trial buffers (the line search evaluates two step sizes per sweep)
-  Real* X[3];   // [B][nmax+1][kXS]: x_k (9), u_k (10), position low words (3), pad
-  Real* S[3];   // [B][nmax][ncs]
-  Real* Y[3];   // [B][nmax][ncs]
+  // Iterate buffers: `cur` and the trial buffers (step t of a line search writes buffer trial_buf(cur, t))
+  Real* X[kMaxBuf];   // [B][nmax+1][kXS]: x_k (9), u_k (10), position low words (3), pad
+  Real* S[kMaxBuf];   // [B][nmax][ncs]
+  Real* Y[kMaxBuf];   // [B][nmax][ncs]
   Real* KU;     // [B][nmax][100]: ku (10), Ku (10x9 row-major)
   Real* KS;     // [B][nmax][ncs]
   Real* KY;     // [B][nmax][ncs]
   double* filt; // [B][fcap][2]
   TrajState* st;
+  HelpSlot* help;  // [B], or null: every line search stays with its owner
+  int* sched_err;  // the launch's sticky error flag (spin limits of the shared line search)
   SolveConst k;
 };
 
@@ -507,15 +543,22 @@ struct Wave {
   typedef DDP_GLOBAL const St GCSt;
   typedef DDP_GLOBAL const int32_t GCInt;
   struct SweepPtrs {
-    GSt *X[3], *S[3], *Y[3];  // [0] = buffer `cur`, [1], [2] = the trial buffers (cur + 1, cur + 2 mod 3)
+    GSt *X[3], *S[3], *Y[3];  // [0] = buffer `cur`, [1], [2] = the trial buffers of the round being evaluated
     GSt *KS, *KY, *KU;
     GCSt* planes;
     GCInt* n_planes;
   };
   SweepPtrs sp;
-  DDP_DEV void set_sweep_ptrs(int cur) {
+  // buffer written by step `step` of a line search around buffer `cur`: any two consecutive steps differ
+  DDP_DEV int trial_buf(int cur, int step) const {
+    const int bi = cur + 1 + step % (B.nbuf - 1);
+    return bi >= B.nbuf ? bi - B.nbuf : bi;
+  }
+  DDP_DEV void set_sweep_ptrs(int cur, int t0 = -1, int t1 = -1) {
     for (int i = 0; i < 3; i++) {
-      const int bi = cur + i < 3 ? cur + i : cur + i - 3;
+      int bi = i == 0 ? cur : (i == 1 ? t0 : t1);
+      if (bi < 0) bi = cur;
+      bi = DDP_UNIFORM_I(bi);
       sp.X[i] = (GSt*)B.X[bi];
       sp.S[i] = (GSt*)B.S[bi];
       sp.Y[i] = (GSt*)B.Y[bi];
@@ -1698,34 +1741,175 @@ struct Wave {
     return 1;
   }
 
-  // One line-search trial's wave-uniform bookkeeping.
-  struct Trial {
-    int alive, step, neg;
-    double stepsize, qsum;
-  };
-
   // what an accepted trial leaves behind
   struct Accept {
     int accepted, nkeep, step, neg, buf, viol;
     double stepsize, cost, costq, logcost, err, sumlog, errsum;
   };
 
+  // ---- shared line search: the owner's and the helpers' halves of the HelpSlot protocol (device only) ----------
+  // All of it is wave-uniform: lane 0 performs the atomic, the value is broadcast.  Agent scope throughout: owner and
+  // helper may sit on different XCDs.
+#if !defined(DIRECT_EMULATE)
+  static __device__ __forceinline__ int a_load(int* p) {
+    int v = 0;
+    if (threadIdx.x == 0) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(v);
+  }
+  static __device__ __forceinline__ void a_store(int* p, int v) {
+    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  static __device__ __forceinline__ int a_add(int* p, int v) {
+    int o = 0;
+    if (threadIdx.x == 0) o = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(o);
+  }
+  DDP_DEV void proto_error() const { a_store(B.sched_err, 1); }
+  // owner: open the line search around buffer `cur` to helpers.  Everything a helper reads (gains, the nominal
+  // iterate, the row cache) was written by this wave before the release fence.
+  DDP_DEV void share_open(HelpSlot* hs, int cur, double mu, int tag) {
+    if (threadIdx.x == 0) {
+      hs->cur = cur;
+      hs->mu = mu;
+      __hip_atomic_store(&hs->next_round, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hs->cancel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    a_store(&hs->gen, tag);
+  }
+  // owner: close it.  After this no helper reads the gains or writes a trial buffer of this trajectory.
+  // (store gen / fence / load active here, add active / fence / load gen in help_enter: one of the two sees the other)
+  DDP_DEV void share_close(HelpSlot* hs) {
+    a_store(&hs->cancel, 1);
+    a_store(&hs->gen, 0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    int spins = 0;
+    while (a_load(&hs->active) != 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) {
+        proto_error();
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  DDP_DEV int share_claim(HelpSlot* hs) { return a_add(&hs->next_round, 1); }
+  DDP_DEV int share_cancelled(HelpSlot* hs) { return a_load(&hs->cancel); }
+  // helper: join the open line search of trajectory `b`, if there is one
+  DDP_DEV int help_enter(HelpSlot* hs, int& cur, double& mu, int& tag) {
+    const int g = a_load(&hs->gen);
+    if (!g) return 0;
+    a_add(&hs->active, 1);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    const int g2 = a_load(&hs->gen), c = a_load(&hs->cancel);
+    if (g2 != g || c) {
+      a_add(&hs->active, -1);
+      return 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int cv = 0, ml = 0, mh = 0;
+    if (threadIdx.x == 0) {
+      cv = hs->cur;
+      ml = __double2loint(hs->mu);
+      mh = __double2hiint(hs->mu);
+    }
+    cur = __builtin_amdgcn_readfirstlane(cv);
+    mu = __hiloint2double(__builtin_amdgcn_readfirstlane(mh), __builtin_amdgcn_readfirstlane(ml));
+    tag = g;
+    return 1;
+  }
+  DDP_DEV void help_leave(HelpSlot* hs) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the trial buffers this wave wrote
+    a_add(&hs->active, -1);
+  }
+  // runner of round r (steps 2r-1, 2r): hand the results to the owner
+  DDP_DEV void post_results(HelpSlot* hs, int r, const TrialRes* res, int tag) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {  // field by field: the records stay in registers
+        TrialRes* d = &hs->res[2 * r - 1 + t];
+        d->alive = res[t].alive; d->step = res[t].step; d->neg = res[t].neg; d->viol = res[t].viol;
+        d->stepsize = res[t].stepsize; d->qsum = res[t].qsum; d->cost = res[t].cost;
+        d->sumlog = res[t].sumlog; d->errsum = res[t].errsum;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    a_store(&hs->done[r], tag);
+  }
+  // owner: wait for round r (claimed by a helper, which always completes it unless the search is cancelled)
+  DDP_DEV int fetch_results(HelpSlot* hs, int r, int tag, TrialRes* out) {
+#ifdef DBG_B5
+    return 0;
+#endif
+    int spins = 0;
+    while (a_load(&hs->done[r]) != tag) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1 << 22)) {
+        proto_error();
+        return 0;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int* src = (const int*)&hs->res[2 * r - 1];  // two records = 32 words, one per lane
+    const int v = src[threadIdx.x & 31];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int o = 16 * t;
+      out[t].alive = __builtin_amdgcn_readlane(v, o);
+      out[t].step = __builtin_amdgcn_readlane(v, o + 1);
+      out[t].neg = __builtin_amdgcn_readlane(v, o + 2);
+      out[t].viol = __builtin_amdgcn_readlane(v, o + 3);
+      out[t].stepsize = __hiloint2double(__builtin_amdgcn_readlane(v, o + 5), __builtin_amdgcn_readlane(v, o + 4));
+      out[t].qsum = __hiloint2double(__builtin_amdgcn_readlane(v, o + 7), __builtin_amdgcn_readlane(v, o + 6));
+      out[t].cost = __hiloint2double(__builtin_amdgcn_readlane(v, o + 9), __builtin_amdgcn_readlane(v, o + 8));
+      out[t].sumlog = __hiloint2double(__builtin_amdgcn_readlane(v, o + 11), __builtin_amdgcn_readlane(v, o + 10));
+      out[t].errsum = __hiloint2double(__builtin_amdgcn_readlane(v, o + 13), __builtin_amdgcn_readlane(v, o + 12));
+    }
+    return 1;
+  }
+#ifdef DBG_B2
+  DDP_DEV HelpSlot* help_slot() const { return nullptr; }
+#else
+  DDP_DEV HelpSlot* help_slot() const { return B.help ? &B.help[b] : nullptr; }
+#endif
+#else  // the emulator runs one wave: nothing to share
+  DDP_DEV void share_open(HelpSlot*, int, double, int) {}
+  DDP_DEV void share_close(HelpSlot*) {}
+  DDP_DEV int share_claim(HelpSlot*) { return 0; }
+  DDP_DEV int share_cancelled(HelpSlot*) { return 0; }
+  DDP_DEV int help_enter(HelpSlot*, int&, double&, int&) { return 0; }
+  DDP_DEV void help_leave(HelpSlot*) {}
+  DDP_DEV void post_results(HelpSlot*, int, const TrialRes*, int) {}
+  DDP_DEV int fetch_results(HelpSlot*, int, int, TrialRes*) { return 0; }
+  DDP_DEV HelpSlot* help_slot() const { return nullptr; }
+#endif
+
   // One round of the line search: NT trials (step indices step0 .. step0 + NT - 1) in one sweep over the knots.
   // NT = 1 is the plain forward roll; NT = 2 shares everything that belongs to the old iterate between two trials.
+  // Leaves res[t] (wave-uniform) and the trial iterates in buffers trial_buf(cur, step0 + t).  `poll` != 0 (helpers):
+  // the round is abandoned when the owner cancels the search.
   template <int NT>
-  DDP_DEV void fwd_round(int step0, int cur, int infeas, Real omt, double mu_d, int nfilter, double* filt, Accept& A) {
+  DDP_DEV void run_round(int step0, int cur, int infeas, Real omt, TrialRes* res, int poll, HelpSlot* hs) {
+    set_sweep_ptrs(cur, trial_buf(cur, step0), trial_buf(cur, step0 + NT - 1));
     Real alpha[NT];
-    Trial tr[NT];
+    TrialRes* tr = res;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       tr[t].alive = 1;
       tr[t].step = step0 + t;
       tr[t].neg = 0;
+      tr[t].viol = 0;
       tr[t].qsum = 0.0;
+      tr[t].cost = 0.0;
+      tr[t].sumlog = 0.0;
+      tr[t].errsum = 0.0;
       tr[t].stepsize = 1.0;
       for (int q = 0; q < tr[t].step; q++) tr[t].stepsize *= 0.5;  // DDP:670
       alpha[t] = DDP_UNIFORM_R((Real)tr[t].stepsize);
     }
+#if !defined(DIRECT_EMULATE)
+    int cancel_v = 0;  // the cancel flag as of one knot ago (the load is issued a knot ahead, like the prefetch)
+#endif
     PLA(LogProd<Real>, plog, NT);
     PLA(Real, serr, NT);
     PLA(int, nviol, NT);
@@ -1745,10 +1929,20 @@ struct Wave {
     LANES { prefetch(LV(pre), LV(pkn), 0, lane, cur, 0, Pn, true, infeas); }
 #pragma unroll 1
     for (int k_ = 0; k_ < N; k_++) {
-      int k = k_;  // see bwd_sweep()
+      int k = DDP_UNIFORM_I(k_);  // see bwd_sweep(); the loop has several exits and the counter may not be provably uniform
       DDP_LAUNDER_S(k);
       const int P = Pn;
       DDP_MARK("F_L");
+#if !defined(DIRECT_EMULATE)
+      if (poll) {
+        if (__builtin_amdgcn_readfirstlane(cancel_v)) {
+#pragma unroll
+          for (int t = 0; t < NT; t++) tr[t].alive = 0;
+          break;
+        }
+        cancel_v = __hip_atomic_load(&hs->cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#endif
       PLA(Real, rs, RPL);
       PLA(Real, ry, RPL);
       PLA(Real, rks, RPL);
@@ -1950,10 +2144,10 @@ struct Wave {
       if (!any_alive) break;
     }
     DDP_MARK("F_END");
-    // acceptance in step order: the first surviving trial that the filter lets through (DDP:716-757)
+    // totals of the trials that survived every knot (DDP:716-732)
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      if (!A.accepted && tr[t].alive) {
+      if (tr[t].alive) {
         PLV(Real, slog);
         PLV(Real, se1);
         PLV(int, nv1);
@@ -1971,54 +2165,112 @@ struct Wave {
           LV(se1) = LV(serr)[t];
           LV(nv1) = LV(nviol)[t];
         }
-        const double cost_t = tr[t].qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
-        const double sumlog_t = WAVE_SUM_D(slog), errsum_t = WAVE_SUM_D(se1);
-        const int viol_t = WAVE_SUM_I(nv1);
-        const double logcost_t = cost_t - mu_d * sumlog_t;  // DDP:718-732
-        const double err_t = infeas ? fmax(B.k.tol, errsum_t) : 0.0;
-        if (filter_accept(filt, nfilter, logcost_t, err_t, A.nkeep)) {
-          A.accepted = 1;
-          A.step = tr[t].step; A.neg = tr[t].neg; A.stepsize = tr[t].stepsize; A.buf = 1 + t;
-          A.cost = cost_t; A.costq = tr[t].qsum; A.logcost = logcost_t; A.err = err_t; A.sumlog = sumlog_t; A.errsum = errsum_t;
-          A.viol = viol_t;
-        }
+        tr[t].cost = tr[t].qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
+        tr[t].sumlog = WAVE_SUM_D(slog);
+        tr[t].errsum = WAVE_SUM_D(se1);
+        tr[t].viol = WAVE_SUM_I(nv1);
       }
     }
   }
 
-  DDP_DEV_NOINLINE void fwd_pass() {
+  // the filter's verdict on one completed trial (DDP:718-757); acceptance goes strictly in step order
+  DDP_DEV void consider(const TrialRes& r, int cur, int infeas, double mu_d, int nfilter, double* filt, Accept& A) {
+    if (A.accepted || !r.alive) return;
+    const double logcost_t = r.cost - mu_d * r.sumlog;  // DDP:718-732
+    const double err_t = infeas ? fmax(B.k.tol, r.errsum) : 0.0;
+    if (filter_accept(filt, nfilter, logcost_t, err_t, A.nkeep)) {
+      A.accepted = 1;
+      A.step = r.step; A.neg = r.neg; A.stepsize = r.stepsize; A.buf = trial_buf(cur, r.step);
+      A.cost = r.cost; A.costq = r.qsum; A.logcost = logcost_t; A.err = err_t; A.sumlog = r.sumlog; A.errsum = r.errsum;
+      A.viol = r.viol;
+    }
+  }
+
+  // Step sizes 2^0 .. 2^-10 are tried in order (DDP:666-670) and the first that passes is taken.  The trials of one
+  // iteration are independent of each other (same gains, same nominal iterate, the filter only changes on
+  // acceptance), which is used twice, both times without touching the arithmetic of a trial or the order in which
+  // the trials are judged - results are bitwise those of the sequential search:
+  //  * from the second attempt on TWO of them share a sweep (rounds {0}, {1,2}, {3,4}, ... {9,10}): everything that
+  //    belongs to the old iterate (prefetch, gains, row descriptors, c and s/c, the old powers of T) is loaded once, and
+  //    the two dependent chains interleave in a wave that is otherwise latency-bound;
+  //  * with B.help, once step 0 has failed the rounds are handed out through HelpSlot::next_round: waves that wait
+  //    for this trajectory's chunk to finish (k_iterate_dyn) run later rounds at the same time as the owner runs round
+  //    1, each into its own trial buffers, and report TrialRes records.  `helper` != 0 is that other side: no filter,
+  //    no TrajState, parameters from the slot.
+  DDP_DEV_NOINLINE void fwd_pass(int helper = 0) {
     DDP_LAUNDER_S(b);
     DDP_LAUNDER_S(N);
-    const int cur = DDP_UNIFORM_I(st.cur);
-    set_sweep_ptrs(cur);
-    const int infeas = DDP_UNIFORM_I(st.infeas);
-    const double mu_d = st.mu;
+    HelpSlot* hs = help_slot();
+    int cur = 0, infeas = 0, tag = 0;
+    double mu_d = 0.0;
+    if (helper) {
+      if (!help_enter(hs, cur, mu_d, tag)) return;
+    } else {
+      cur = DDP_UNIFORM_I(st.cur);
+      infeas = DDP_UNIFORM_I(st.infeas);
+      mu_d = st.mu;
+      tag = DDP_UNIFORM_I(st.fwd_passes) + 1;
+    }
     const double tau_d = fmax(0.99, 1.0 - mu_d);
     const Real omt = DDP_UNIFORM_R((Real)(1.0 - tau_d));
-    const int nfilter = DDP_UNIFORM_I(st.nfilter);
+    const int nfilter = helper ? 0 : DDP_UNIFORM_I(st.nfilter);
     double* filt = B.filt + (size_t)b * B.fcap * 2;
-    // Step sizes 2^0 .. 2^-10 are tried in order (DDP:666-670) and the first that passes is taken.  The trials of one
-    // iteration are independent of each other (same gains, same nominal iterate, the filter only changes on
-    // acceptance), so from the second attempt on TWO of them share a sweep: everything that belongs to the old iterate
-    // (prefetch, gains, row descriptors, c and s/c, the old powers of T) is loaded once, and the two dependent chains
-    // interleave in a wave that is otherwise latency-bound.  Acceptance is still decided in step order, each trial's
-    // arithmetic is exactly the single-trial arithmetic, and each writes its own trial buffer: results are bitwise
-    // those of the sequential search.  Rounds: {0}, {1,2}, {3,4}, ... {9,10}.
-    const int pair = (B.k.pair_trials && !infeas) ? 1 : 0;
+    const int pair = (helper || (B.k.pair_trials && !infeas)) ? 1 : 0;
+#ifdef DBG_B4
+    const int share = 0;
+#else
+    const int share = (!helper && pair && hs != nullptr) ? 1 : 0;
+#endif
+    const int last_round = pair ? 5 : 10;  // rounds: {0}, then pairs (2r-1, 2r) or single steps r
     Accept A;
-    A.accepted = 0; A.nkeep = 0; A.step = 0; A.neg = 0; A.buf = 1; A.viol = 0;
+    A.accepted = 0; A.nkeep = 0; A.step = 0; A.neg = 0; A.buf = cur; A.viol = 0;
     A.stepsize = 0.0; A.cost = 0.0; A.costq = 0.0; A.logcost = 0.0; A.err = 0.0; A.sumlog = 0.0; A.errsum = 0.0;
-    int next_step = 0;
+    int r_eval = 0;  // owner: the first round whose results have not been judged yet
+    int opened = 0;
 #pragma unroll 1
-    while (next_step < 11 && !A.accepted) {
-      if (pair && next_step > 0 && next_step + 1 < 11) {
-        fwd_round<2>(next_step, cur, infeas, omt, mu_d, nfilter, filt, A);
-        next_step += 2;
-      } else {
-        fwd_round<1>(next_step, cur, infeas, omt, mu_d, nfilter, filt, A);
-        next_step += 1;
+    while (true) {
+      int mine = (helper || opened) ? share_claim(hs) : r_eval;
+      if (mine > last_round) mine = -1;
+      if (helper && (mine < 0 || share_cancelled(hs))) break;
+      TrialRes res[2];
+      res[0].alive = 0;
+      res[1].alive = 0;
+      if (mine >= 0) {
+        if (pair && mine > 0) run_round<2>(2 * mine - 1, cur, infeas, omt, res, helper, hs);
+        else run_round<1>(mine, cur, infeas, omt, res, 0, hs);
+      }
+      if (helper) {
+        post_results(hs, mine, res, tag);
+        continue;
+      }
+      const int upto = mine >= 0 ? mine : last_round;
+      int broken = 0;
+#pragma unroll 1
+      for (; r_eval <= upto && !A.accepted; r_eval++) {
+        if (r_eval == mine) {
+          consider(res[0], cur, infeas, mu_d, nfilter, filt, A);
+          consider(res[1], cur, infeas, mu_d, nfilter, filt, A);
+        } else {  // a helper's round
+          TrialRes o[2];
+          if (!fetch_results(hs, r_eval, tag, o)) {
+            broken = 1;
+            break;
+          }
+          consider(o[0], cur, infeas, mu_d, nfilter, filt, A);
+          consider(o[1], cur, infeas, mu_d, nfilter, filt, A);
+        }
+      }
+      if (A.accepted || broken || mine < 0 || r_eval > last_round) break;
+      if (share && !opened) {
+        share_open(hs, cur, mu_d, tag);
+        opened = 1;
       }
     }
+    if (helper) {
+      help_leave(hs);
+      return;
+    }
+    if (opened) share_close(hs);
     if (!A.accepted) {  // DDP:760-762
       st.fp_failed = 1;
       st.stepsize = 0.0;
@@ -2035,20 +2287,25 @@ struct Wave {
       st.stepsize = A.stepsize;
       st.step = A.step;
       st.fp_failed = 0;
-      st.cur = cur + A.buf < 3 ? cur + A.buf : cur + A.buf - 3;
+      st.cur = A.buf;
     }
   }
 
   // ---- one trip of the outer loop (DDP:295-412).  Sets st.done when the loop breaks. ------------
-  DDP_DEV void iterate_once() {
-    while (true) {  // DDP:297-310
-      if (bwd_sweep()) break;
-      if (st.reg == 24 && st.bp_failed) st.bp_no_upd++;
-      else st.bp_no_upd = 0;
-      if (st.bp_no_upd > 20) break;
+  // helper != 0: no trip at all - this wave joins the line search that trajectory b's owner has open (fwd_pass)
+  DDP_DEV void iterate_once(int helper = 0) {
+    if (!helper) {
+      while (true) {  // DDP:297-310
+        if (bwd_sweep()) break;
+        if (st.reg == 24 && st.bp_failed) st.bp_no_upd++;
+        else st.bp_no_upd = 0;
+        if (st.bp_no_upd > 20) break;
+      }
+      if (st.bp_failed && !st.infeas) refresh_row_cache();
     }
-    if (st.bp_failed && !st.infeas) refresh_row_cache();
-    fwd_pass();
+    fwd_pass(helper);
+    if (helper) return;
+    DDP_MARK("X_A");
     st.fwd_passes++;
     if (st.neg_time) {  // DDP:317-326
       st.rtn = -3;
@@ -2102,15 +2359,18 @@ struct Wave {
     }
   }
 
-  DDP_DEV void iterate(int n_iters) {
+  DDP_DEV void iterate(int n_iters, int helper = 0) {
 #pragma unroll 1
     for (int it = 0; it < n_iters; it++) {
-      if (DDP_UNIFORM_I(st.done)) break;
-      if (st.iter >= B.k.iter_max) {
-        st.done = 1;
-        break;
+      if (!helper) {
+        if (DDP_UNIFORM_I(st.done)) break;
+        if (st.iter >= B.k.iter_max) {
+          st.done = 1;
+          break;
+        }
       }
-      iterate_once();
+      iterate_once(helper);
+      if (helper) break;
       if (!st.done) {
         st.iter++;
         if (st.iter >= B.k.iter_max) st.done = 1;

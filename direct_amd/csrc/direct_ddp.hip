@@ -72,24 +72,46 @@ struct Sched {
   int chunk;
   int prio;           // raise the wave priority of chunks that had to wait for their predecessor
 };
-// Draws the next ticket and waits for the previous chunk of its trajectory.  Returns the ticket, -1
-// when none are left, -2 when the ticket's trajectory has already finished (kDoneBit in done_epoch),
-// -3 - b when the wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early exits on purpose: inlined into the (huge) iterate
-// loop the structuriser turned the nested uniform loops into exec-masked ones.
-__device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsigned total, int* waited) {
-  unsigned tv = 0;
-  if (threadIdx.x == 0) tv = __hip_atomic_fetch_add(S.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
+// The next piece of work for a persistent wave.  `held` < 0: draws the next ticket (epoch, trajectory) = (t / batch,
+// t % batch); else continues to wait with ticket `held` in hand.  Waits for the previous chunk of the ticket's trajectory.
+// Returns the ticket, with *help = 0 when its chunk can run now, or *help = 1 when the predecessor is still running and
+// has opened its line search to helpers (ddp_wave.h, fwd_pass): the caller runs a round of it and comes back with the
+// ticket.  -1: no tickets left; -2: the ticket's trajectory has already finished (kDoneBit in done_epoch); -3 - b: the
+// wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early
+// exits on purpose: inlined into the (huge) iterate loop the structuriser turned the nested uniform loops into
+// exec-masked ones.
+__device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, unsigned nb, unsigned total, int held,
+                                                   int* waited, int* help) {
+  unsigned t = (unsigned)held;
+  if (held < 0) {
+    unsigned tv = 0;
+    if (threadIdx.x == 0) tv = __hip_atomic_fetch_add(S.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
+    *waited = 0;
+  }
+  *help = 0;
   if (t >= total) return -1;
   const int e = (int)(t / nb), b = (int)(t - (unsigned)e * nb);
-  int ready = (e == 0) ? 1 : 0, have = 0;
+  int ready = (e == 0) ? 1 : 0, have = 0, wanted = 0;
   int spins = 0;
-  for (; !ready && spins < (1 << 22); spins++) {
-    int hv = 0;
-    if (threadIdx.x == 0) hv = __hip_atomic_load(&S.done_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (; !ready && !wanted && spins < (1 << 22); spins++) {
+    int hv = 0, g = 0, r = 0;
+    if (threadIdx.x == 0) {
+      hv = __hip_atomic_load(&S.done_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slots) {
+        g = __hip_atomic_load(&slots[b].gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = __hip_atomic_load(&slots[b].next_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     have = __builtin_amdgcn_readfirstlane(hv);
     ready = (have >= e) ? 1 : 0;
-    if (!ready) __builtin_amdgcn_s_sleep(32);
+    wanted = (!ready && __builtin_amdgcn_readfirstlane((g != 0 && r <= 5) ? 1 : 0)) ? 1 : 0;
+    if (!ready && !wanted) __builtin_amdgcn_s_sleep(32);
+  }
+  if (spins > 1 || wanted) *waited = 1;
+  if (wanted) {
+    *help = 1;
+    return (int)t;
   }
   if (!ready) {  // a scheduling bug: never a hang, and never a chunk run on a trajectory whose previous chunk
                  // may still be in flight elsewhere.  The flag is sticky until the next solve (direct_ddp.h).
@@ -98,7 +120,6 @@ __device__ __attribute__((noinline)) int next_ticket(Sched S, unsigned nb, unsig
   }
   if (have >= kDoneBit) return -2;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  *waited = spins > 1 ? 1 : 0;
   return (int)t;
 }
 template <typename St, int RPL>
@@ -109,10 +130,16 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
   const unsigned nb = (unsigned)B.B;
   const unsigned n_epochs = (unsigned)((n_iters + S.chunk - 1) / S.chunk);
   const unsigned total = nb * n_epochs;
+  DDP_MARK("Z_0");
+  int held = -1, waited = 0;
 #pragma unroll 1
   for (;;) {
-    int waited = 0;
-    const int t = __builtin_amdgcn_readfirstlane(next_ticket(S, nb, total, &waited));
+    int help_v = 0;
+    DDP_MARK("X_T");
+    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, nb, total, held, &waited, &help_v));
+    const int help = __builtin_amdgcn_readfirstlane(help_v);
+    DDP_MARK("X_G");
+    held = -1;
     if (t == -1) break;
     if (t == -2) continue;
     if (t <= -3) {  // timed out: retire the trajectory so that its later tickets are skipped at once
@@ -123,20 +150,30 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
     const int b = __builtin_amdgcn_readfirstlane(t - e * (int)nb);
     W.b = b;
     // A chunk whose predecessor was still running when its ticket was drawn belongs to a trajectory that lags the
-    // batch, i.e. to the critical chain of the launch: it gets the SIMD's issue priority over its co-resident waves.
+    // batch, i.e. to the critical chain of the launch: it - and whoever helps it - gets the SIMD's issue priority over
+    // the co-resident waves.
     if (S.prio) {
       if (__builtin_amdgcn_readfirstlane(waited)) __builtin_amdgcn_s_setprio(3);
       else __builtin_amdgcn_s_setprio(0);
     }
-    W.load_state();
-    if (!__builtin_amdgcn_readfirstlane(lds.st.done)) {
+    // One call site of Wave::iterate for both kinds of work (the sweeps are inlined into it).
+    int run = 1, n = 1;
+    if (help) {
+      held = t;  // the ticket stays in hand
+      W.N = __builtin_amdgcn_readfirstlane(B.n_seg[b]);
+    } else {
+      W.load_state();
+      run = __builtin_amdgcn_readfirstlane(lds.st.done) ? 0 : 1;
       const int left = n_iters - e * S.chunk;
-      W.iterate(left < S.chunk ? left : S.chunk);
-      W.store_state();
+      n = left < S.chunk ? left : S.chunk;
     }
-    const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (threadIdx.x == 0) __hip_atomic_store(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (run) W.iterate(n, help);
+    if (!help) {
+      if (run) W.store_state();
+      const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (threadIdx.x == 0) __hip_atomic_store(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -247,7 +284,10 @@ struct direct_ddp_handle_s {
   void* seeds = nullptr;
   int32_t *n_seg = nullptr, *n_planes = nullptr;
   uint8_t *infeas_in = nullptr, *infeas_next = nullptr;
-  void *X[3] = {nullptr, nullptr, nullptr}, *S[3] = {nullptr, nullptr, nullptr}, *Y[3] = {nullptr, nullptr, nullptr};
+  void *X[direct::kMaxBuf] = {}, *S[direct::kMaxBuf] = {}, *Y[direct::kMaxBuf] = {};
+  int nbuf = 3;              // iterate buffers allocated: 3, or kMaxBuf when the line search can be shared
+  HelpSlot* help = nullptr;  // [max_batch], with nbuf == kMaxBuf
+  int help_mode = -1;        // shared line search: -1 auto (whenever trials are paired), DIRECT_DDP_HELP=0|1 forces
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
   double* filt = nullptr;
   TrajState* st = nullptr;
@@ -304,9 +344,12 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   B.init_poly = (const Real*)in.init_poly;
   B.seeds = (const Real*)in.seeds;
   B.infeas_in = in.infeas_in;
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < h->nbuf; i++) {
     B.X[i] = (Real*)h->X[i]; B.S[i] = (Real*)h->S[i]; B.Y[i] = (Real*)h->Y[i];
   }
+  B.nbuf = h->nbuf;
+  B.help = nullptr;  // set by the dynamic launch only
+  B.sched_err = h->sched + 1;
   B.KU = (Real*)h->KU; B.KS = (Real*)h->KS; B.KY = (Real*)h->KY; B.filt = h->filt; B.st = h->st;
   SolveConst& k = B.k;
   k.max_vel = p.max_vel; k.max_acc = p.max_acc; k.w_snap = p.w_snap; k.w_term = p.w_terminal;
@@ -357,6 +400,11 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.prio = h->sched_prio;
       (void)hipMemsetAsync(h->sched, 0, sizeof(int), h->stream);  // the error flag [1] is sticky: cleared in stage_inputs
       (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);
+      // shared line search: wherever trials are paired (the chain-bound regime), unless forced either way
+      if (h->help && (h->help_mode >= 0 ? h->help_mode : Bt.k.pair_trials) && Bt.k.pair_trials) {
+        (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
+        Bt.help = h->help;
+      }
       RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
     } else {
       RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n);
@@ -502,9 +550,20 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r); A(&h->init_poly, B * nm * 18 * r);
   A(&h->seeds, B * nm * 3 * r);
   A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B); A(&h->infeas_next, B);
-  for (int i = 0; i < 3; i++) {
+  h->dynamic = !(cfg->reserved & DIRECT_FLAG_STATIC_SCHEDULE);
+  if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
+  h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
+                                            : resident_slots<float>(h, prop.multiProcessorCount);
+  if (const char* ev = getenv("DIRECT_DDP_HELP")) h->help_mode = atoi(ev);
+  // The shared line search needs a trial buffer per step.  It only ever runs where trials are paired, i.e. (unless
+  // forced) for batches up to twice the resident waves: larger handles keep the three-buffer layout.
+  const bool can_help = h->dynamic && h->sched_slots > 0 && h->help_mode != 0 &&
+                        (h->help_mode > 0 || cfg->max_batch <= 2 * h->sched_slots);
+  h->nbuf = can_help ? kMaxBuf : 3;
+  for (int i = 0; i < h->nbuf; i++) {
     A(&h->X[i], B * (nm + 1) * kXS * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
   }
+  if (can_help) A(&h->help, B * sizeof(HelpSlot));
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
   A(&h->st, B * sizeof(TrajState));
   A(&h->o.rtn, B * 4); A(&h->o.iter_used, B * 4); A(&h->o.fwd_passes, B * 4);
@@ -514,10 +573,6 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
   A(&h->best_idx, 16); A(&h->best_cost, 16);
   A(&h->sched, (B + 2) * sizeof(int));
-  h->dynamic = !(cfg->reserved & DIRECT_FLAG_STATIC_SCHEDULE);
-  if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
-  h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
-                                            : resident_slots<float>(h, prop.multiProcessorCount);
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
   if (const char* ev = getenv("DIRECT_DDP_PRIO")) h->sched_prio = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_PAIR")) h->pair_trials = atoi(ev);
@@ -967,14 +1022,14 @@ direct_status_t direct_ddp_gather_best(direct_ddp_handle_t h, void* nccl_comm, i
 
 #if defined(DDP_TIMING)
 // debug builds only (not declared in the header): per-phase cycle totals of workgroup 0
-direct_status_t direct_ddp_debug_phase_cycles(unsigned long long* out32, int reset) {
+direct_status_t direct_ddp_debug_phase_cycles(unsigned long long* out64, int reset) {
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[64] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(direct::g_phase_cycles), z, sizeof z));
     return DIRECT_OK;
   }
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(direct::g_phase_cycles), 32 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(direct::g_phase_cycles), 64 * sizeof(unsigned long long)));
   return DIRECT_OK;
 }
 #endif

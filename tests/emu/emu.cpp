@@ -87,6 +87,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data(); Bt.S[2] = E->S2.data();
   Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.Y[2] = E->Y2.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
   Bt.KY = E->KY.data(); Bt.filt = E->filt.data(); Bt.st = E->st.data();
+  Bt.nbuf = 3; Bt.help = nullptr; Bt.sched_err = nullptr;
   SolveConst& k = Bt.k;
   k.max_vel = p->max_vel; k.max_acc = p->max_acc; k.w_snap = p->w_snap; k.w_term = p->w_terminal;
   k.w_time = p->w_time; k.reg_base = p->zero_init ? 1.6 : 4.0; k.shift = p->minvo ? 0.0 : 2.0e-4;
