@@ -97,11 +97,7 @@ inline T emu_uniform(T x, int line) {
 #define DDP_UNIFORM_R(x) direct::uniform_real(x)
 // re-materialise a wave-uniform value: stops LICM from hoisting everything derived from it (slab
 // pointers, strides) out of the outer iteration loop, where it would stay live across both sweeps
-#ifdef DBG_NOL
-#define DDP_LAUNDER_S(x) ((void)0)
-#else
 #define DDP_LAUNDER_S(x) asm volatile("" : "+s"(x))
-#endif
 // Compiler-only memory barrier placed after a block of LDS operand loads: the scheduler otherwise
 // sinks each load next to its use (3 loads, wait, 2 FMAs, 3 loads, wait ...) and every wait exposes
 // a full LDS round trip; with the barrier all loads of the block are in flight before the first wait.
@@ -113,11 +109,7 @@ inline T emu_uniform(T x, int line) {
 // A wave-uniform value the compiler must treat as an opaque SGPR operand.  Without it a lane-dependent
 // select between two kernel-argument fields is turned into ONE lane-indexed vector load from the kernarg
 // segment, i.e. a full memory round trip (and a vmcnt(0) that also drains the prefetch) in the row loop.
-#ifdef DBG_NOO
-#define DDP_OPAQUE_S(x) ((void)0)
-#else
 #define DDP_OPAQUE_S(x) asm("" : "+s"(x))
-#endif
 #define DDP_UMUL24(a, b) __umul24(a, b)  // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
 // A pointer that went through an empty asm is a generic pointer to the compiler (FLAT loads, which also
 // count on lgkmcnt); the sweep's array bases are therefore typed as global-memory pointers.
@@ -1838,9 +1830,6 @@ struct Wave {
   }
   // owner: wait for round r (claimed by a helper, which always completes it unless the search is cancelled)
   DDP_DEV int fetch_results(HelpSlot* hs, int r, int tag, TrialRes* out) {
-#ifdef DBG_B5
-    return 0;
-#endif
     int spins = 0;
     while (a_load(&hs->done[r]) != tag) {
       __builtin_amdgcn_s_sleep(4);
@@ -1867,11 +1856,7 @@ struct Wave {
     }
     return 1;
   }
-#ifdef DBG_B2
-  DDP_DEV HelpSlot* help_slot() const { return nullptr; }
-#else
   DDP_DEV HelpSlot* help_slot() const { return B.help ? &B.help[b] : nullptr; }
-#endif
 #else  // the emulator runs one wave: nothing to share
   DDP_DEV void share_open(HelpSlot*, int, double, int) {}
   DDP_DEV void share_close(HelpSlot*) {}
@@ -2216,11 +2201,7 @@ struct Wave {
     const int nfilter = helper ? 0 : DDP_UNIFORM_I(st.nfilter);
     double* filt = B.filt + (size_t)b * B.fcap * 2;
     const int pair = (helper || (B.k.pair_trials && !infeas)) ? 1 : 0;
-#ifdef DBG_B4
-    const int share = 0;
-#else
     const int share = (!helper && pair && hs != nullptr) ? 1 : 0;
-#endif
     const int last_round = pair ? 5 : 10;  // rounds: {0}, then pairs (2r-1, 2r) or single steps r
     Accept A;
     A.accepted = 0; A.nkeep = 0; A.step = 0; A.neg = 0; A.buf = cur; A.viol = 0;

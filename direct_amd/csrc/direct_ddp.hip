@@ -150,10 +150,10 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
     const int b = __builtin_amdgcn_readfirstlane(t - e * (int)nb);
     W.b = b;
     // A chunk whose predecessor was still running when its ticket was drawn belongs to a trajectory that lags the
-    // batch, i.e. to the critical chain of the launch: it - and whoever helps it - gets the SIMD's issue priority over
-    // the co-resident waves.
+    // batch, i.e. to the critical chain of the launch: it gets the SIMD's issue priority over the co-resident waves
+    // (raising its helpers too made no difference).
     if (S.prio) {
-      if (__builtin_amdgcn_readfirstlane(waited)) __builtin_amdgcn_s_setprio(3);
+      if (!help && __builtin_amdgcn_readfirstlane(waited)) __builtin_amdgcn_s_setprio(3);
       else __builtin_amdgcn_s_setprio(0);
     }
     // One call site of Wave::iterate for both kinds of work (the sweeps are inlined into it).
@@ -287,7 +287,7 @@ struct direct_ddp_handle_s {
   void *X[direct::kMaxBuf] = {}, *S[direct::kMaxBuf] = {}, *Y[direct::kMaxBuf] = {};
   int nbuf = 3;              // iterate buffers allocated: 3, or kMaxBuf when the line search can be shared
   HelpSlot* help = nullptr;  // [max_batch], with nbuf == kMaxBuf
-  int help_mode = -1;        // shared line search: -1 auto (whenever trials are paired), DIRECT_DDP_HELP=0|1 forces
+  int help_mode = -1;        // shared line search: -1 auto (batches up to 1.5 x the resident waves), DIRECT_DDP_HELP=0|1 forces
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
   double* filt = nullptr;
   TrajState* st = nullptr;
@@ -400,8 +400,9 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.prio = h->sched_prio;
       (void)hipMemsetAsync(h->sched, 0, sizeof(int), h->stream);  // the error flag [1] is sticky: cleared in stage_inputs
       (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);
-      // shared line search: wherever trials are paired (the chain-bound regime), unless forced either way
-      if (h->help && (h->help_mode >= 0 ? h->help_mode : Bt.k.pair_trials) && Bt.k.pair_trials) {
+      // shared line search: where the launch is bound by its slowest chain (measured: +5 .. +13 % for batches up to
+      // 4/3 of the resident waves, -1.4 % at twice the resident waves), unless forced either way
+      if (h->help && (h->help_mode >= 0 ? h->help_mode : (2 * h->B <= 3 * h->sched_slots)) && Bt.k.pair_trials) {
         (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
         Bt.help = h->help;
       }

@@ -210,6 +210,37 @@ def test_paired_line_search_trials_are_bitwise_equal_to_the_sequential_search(bu
     assert res["1"][1].iter_used.max() > 5
 
 
+def test_shared_line_search_is_bitwise_equal_to_the_owner_only_search(built, corridor_batch, free_batch, monkeypatch):
+    """Waves that wait for a trajectory's chunk run later rounds of its line search into their own trial buffers and
+    report TrialRes records (ddp_wave.h HelpSlot): which wave evaluated a step must not show anywhere - natural exits
+    and the fixed-20 bench launch, every output bit-identical, no scheduler error - and the feature must really have
+    been exercised (the launch is not slower than the owner-only one by more than noise is a bench matter, not tested)."""
+    res, fixed = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIRECT_DDP_HELP", mode)
+        s = solver.DdpSolver(B, N, corridor_batch.p_max, np.float32)
+        res[mode] = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=40), corridor_batch.astype(np.float32))
+        assert s.sched_error() == 0
+        s.close()
+        fb = free_batch.astype(np.float32)
+        s = solver.DdpSolver(B, N, fb.p_max, np.float32)
+        g0 = s.solve(abi.phase0_params(), fb)
+        b1 = fb.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, fb.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
+        for _ in range(3):  # the interleaving differs from launch to launch
+            g1 = s.solve(abi.phase1_params(iter_max=20, fixed_iters=1), b1)
+            assert s.sched_error() == 0
+            fixed.setdefault(mode, []).append(g1)
+        s.close()
+    fields = ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez")
+    for a, b in zip(res["0"], res["1"]):
+        for f in fields:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    for g in fixed["0"][1:] + fixed["1"]:
+        for f in fields:
+            assert np.array_equal(getattr(fixed["0"][0], f), getattr(g, f)), f
+    assert int(fixed["1"][0].fwd_passes.sum()) == B * 20
+
+
 def test_output_sampling_of_the_full_batch(built, free_batch):
     """direct_traj_sample_batch on 4096 solved trajectories: size-independent properties of the samples
     (the oracle is checked on a random subset)."""

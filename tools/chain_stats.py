@@ -1,3 +1,4 @@
+"""Per-trajectory chain composition of the bench launch (needs build_variants/chain.so from tools/chain_build.py)."""
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, ".")
 from direct_amd import abi, problems, solver
@@ -18,12 +19,12 @@ st = buf[:B * w].reshape(B, w)
 # fields: 10 doubles (20 ints) + 24 ints... locate the new fields: after int neg_time,nseg,nc0,npos -> offset
 off = 20 + 20   # doubles(10) -> 20 ints; then 5 rows of 4 ints
 cb = st[:, off:off+2].copy().view(np.int64)[:, 0]; cf = st[:, off+2:off+4].copy().view(np.int64)[:, 0]
-nr, nb = st[:, off+4], st[:, off+5]
+nr, nf = st[:, off+4], st[:, off+5]
 tot = cb + cf
-print("kernel ms %.2f; per-trajectory busy Mcycles (100 MHz counter x?)" % ms)
+print("kernel ms %.2f; sum of totals / 3072 slots = %.1f Mcycles (work bound); per-trajectory Mcycles:" % (ms, tot.sum() / 3072 / 1e6))
 for name, a in (("bwd", cb), ("fwd", cf), ("total", tot)):
     print(name, "min/med/p90/max", np.percentile(a, [0, 50, 90, 100]) / 1e6)
-print("rounds med/p90/max", np.percentile(nr, [50, 90, 100]), "bwd sweeps med/max", np.median(nb), nb.max())
+print("rounds run by the owner med/p90/max", np.percentile(nr, [50, 90, 100]), "| fetched from helpers: total", int(nf.sum()), "max", nf.max())
 i = np.argsort(tot)[-5:]
-print("slowest 5: total", tot[i] / 1e6, "bwd", cb[i] / 1e6, "fwd", cf[i] / 1e6, "rounds", nr[i], "bwd sweeps", nb[i])
+print("slowest 5: total", tot[i] / 1e6, "bwd", cb[i] / 1e6, "fwd", cf[i] / 1e6, "rounds", nr[i], "fetched", nf[i])
 print("corr(total, rounds)", np.corrcoef(tot, nr)[0, 1])

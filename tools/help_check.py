@@ -8,7 +8,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kind = sys.argv[2] if len(sys.argv) > 2 else "free"
 b = problems.make_batch(kind, B, 100, seed=1000)
 res = {}
-for mode in ("0", "1"):
+MODES = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "1"]
+for mode in MODES:
     os.environ["DIRECT_DDP_HELP"] = mode
     s = solver.DdpSolver(B, 100, b.p_max, np.float32)
     g0 = s.solve(abi.phase0_params(), b)
@@ -25,7 +26,7 @@ for mode in ("0", "1"):
     del s
 bad = 0
 for i, nm in enumerate(("phase0", "fixed20", "natural")):
-    a, c = res["0"][i], res["1"][i]
+    a, c = res[MODES[0]][i], res[MODES[-1]][i]
     for f in ("rtn", "iter_used", "fwd_passes", "cost", "costq", "T", "poly", "bez", "opterr", "mu"):
         x, y = getattr(a, f), getattr(c, f)
         if x is None: continue
