@@ -133,7 +133,12 @@ typedef struct {
 
 /* Launch k_iterate as one workgroup per trajectory instead of the default ticket scheduler (persistent
  * waves drawing (trajectory, iteration) tickets: no tail when batch > resident waves).  Results are
- * identical; the environment variable DIRECT_DDP_SCHED=static|dynamic overrides the flag. */
+ * identical; the environment variable DIRECT_DDP_SCHED=static|dynamic overrides the flag.
+ * Two more scheduling choices are made per launch from the batch size and never change a result bit (both have a
+ * bitwise-equality test): two line-search steps per forward sweep (batches up to 2 x the resident waves;
+ * DIRECT_DDP_PAIR=0|1 forces) and the shared line search, in which waves waiting for a trajectory evaluate later
+ * steps of its line search (batches up to 1.5 x the resident waves, handles of at most 2 x; DIRECT_DDP_HELP=0|1
+ * forces, read at create time: such a handle keeps 11 iterate buffers instead of 3). */
 #define DIRECT_FLAG_STATIC_SCHEDULE 1
 
 typedef struct direct_ddp_handle_s* direct_ddp_handle_t;
