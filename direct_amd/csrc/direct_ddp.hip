@@ -560,11 +560,17 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   // forced) for batches up to twice the resident waves: larger handles keep the three-buffer layout.
   const bool can_help = h->dynamic && h->sched_slots > 0 && h->help_mode != 0 &&
                         (h->help_mode > 0 || cfg->max_batch <= 2 * h->sched_slots);
-  h->nbuf = can_help ? kMaxBuf : 3;
+  bool fits = true;
+  if (can_help && h->help_mode < 0) {  // the extra trial buffers must stay a small part of the device's memory
+    size_t free_b = 0, total_b = 0;
+    const size_t extra = (size_t)(kMaxBuf - 3) * (B * (nm + 1) * kXS * r + 2 * B * nm * h->ncs * r);
+    fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && extra <= free_b / 8;
+  }
+  h->nbuf = (can_help && fits) ? kMaxBuf : 3;
   for (int i = 0; i < h->nbuf; i++) {
     A(&h->X[i], B * (nm + 1) * kXS * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
   }
-  if (can_help) A(&h->help, B * sizeof(HelpSlot));
+  if (h->nbuf == kMaxBuf) A(&h->help, B * sizeof(HelpSlot));
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
   A(&h->st, B * sizeof(TrajState));
   A(&h->o.rtn, B * 4); A(&h->o.iter_used, B * 4); A(&h->o.fwd_passes, B * 4);
