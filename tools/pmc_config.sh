@@ -1,0 +1,17 @@
+#!/bin/bash
+# HBM traffic and SQ busy counters of ONE other configuration (separate --pmc passes over tools/prof_one.py):
+# usage (through gpurun): bash tools/pmc_config.sh <tag> <kind> <f32|f64> <batch> <nseg> <iters>   -> gpurun_out/<tag>_*.json
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && export PYTHONPATH=$ROOT
+rm -rf /tmp/pmc_cfg
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAVES SQ_BUSY_CYCLES"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_cfg/p$i -o pmc -- python $ROOT/tools/prof_one.py "$@" > $OUT/${TAG}_pmc_run$i.log 2>&1
+done
+cp $ROOT/profiles/r02_hbm_calib.json $OUT/${TAG}_hbm_calib.json 2>/dev/null
+python $ROOT/tools/pmc_collect.py /tmp/pmc_cfg $OUT/${TAG} "$@"
