@@ -306,41 +306,61 @@ def main():
     bc, bidx, owner, blk = distributed.gather_best(lc, first + li if li >= 0 else -1, block)
     torch.cuda.synchronize()
     gather = {"torch_ms": (time.perf_counter() - tg) * 1e3, "best_cost": bc, "best_index": bidx, "owner": owner}
-    # RCCL writes a version banner to the C stdout when a communicator is created: keep this process's stdout
-    # for the ONE JSON line by pointing fd 1 at stderr while the library talks to RCCL
-    sys.stdout.flush()
-    saved_fd = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        uid = [s.rccl_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
-        comm = s.rccl_comm_create(uid[0], world, rank)
-        wb = torch.zeros(N, 18, dtype=outs["bez"].dtype, device=dev)
-        wT = torch.zeros(N, dtype=outs["T"].dtype, device=dev)
-        for rep in range(2):  # the second call is the timed one (the first builds RCCL's channels)
-            tg = time.perf_counter()
-            ci, cc, cown = s.gather_best(comm, world, rank, outs["cost"].data_ptr(), outs["rtn"].data_ptr(),
-                                         outs["bez"].data_ptr(), outs["T"].data_ptr(), first, mem=abi.MEM_DEVICE, batch=B,
-                                         out_bez=wb.data_ptr(), out_T=wT.data_ptr())
-            c_ms = (time.perf_counter() - tg) * 1e3
-        s.rccl_comm_destroy(comm)
-        same = (ci == bidx and cc == bc and cown == owner
-                and bool(torch.equal(torch.cat([wb.reshape(-1), wT.reshape(-1)]), blk.to(dev))))
-        gather.update({"c_abi_rccl_ms": c_ms, "c_abi_matches_torch": bool(same), "rccl_ranks": world})
-    except Exception as e:  # noqa: BLE001 - the bench line must survive a gather failure; it is reported, not hidden
-        gather.update({"c_abi_error": repr(e)})
-    finally:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        os.dup2(saved_fd, 1)
-        os.close(saved_fd)
     devices = [local]
-    if world > 1:
+    if world > 1:  # every torch.distributed exchange the line needs happens BEFORE the library's own communicator is tried
         got = [None] * world
         dist.all_gather_object(got, (rank, local, torch.cuda.get_device_name(local)))
         devices = got
         gather["dist_world_size"] = dist.get_world_size()
+    uid = [None]
+    try:
+        uid = [s.rccl_unique_id() if rank == 0 else None]
+    except Exception as e:  # noqa: BLE001
+        gather.update({"c_abi_error": repr(e)})
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)  # None: rank 0 could not talk to RCCL, nobody tries
+
+    def c_abi_gather(res):
+        """(b): the library's C entry point on its own RCCL communicator.  Runs in a thread with a deadline: a
+        communicator that cannot be built must cost the run this block, never the bench line."""
+        try:
+            comm = s.rccl_comm_create(uid[0], world, rank)
+            wb = torch.zeros(N, 18, dtype=outs["bez"].dtype, device=dev)
+            wT = torch.zeros(N, dtype=outs["T"].dtype, device=dev)
+            for rep in range(2):  # the second call is the timed one (the first builds RCCL's channels)
+                tg = time.perf_counter()
+                ci, cc, cown = s.gather_best(comm, world, rank, outs["cost"].data_ptr(), outs["rtn"].data_ptr(),
+                                             outs["bez"].data_ptr(), outs["T"].data_ptr(), first, mem=abi.MEM_DEVICE, batch=B,
+                                             out_bez=wb.data_ptr(), out_T=wT.data_ptr())
+                c_ms = (time.perf_counter() - tg) * 1e3
+            s.rccl_comm_destroy(comm)
+            same = (ci == bidx and cc == bc and cown == owner
+                    and bool(torch.equal(torch.cat([wb.reshape(-1), wT.reshape(-1)]), blk.to(dev))))
+            res.update({"c_abi_rccl_ms": c_ms, "c_abi_matches_torch": bool(same), "rccl_ranks": world})
+        except Exception as e:  # noqa: BLE001 - reported, not hidden
+            res.update({"c_abi_error": repr(e)})
+
+    # RCCL writes a version banner to the C stdout when a communicator is created: keep this process's stdout
+    # for the ONE JSON line by pointing fd 1 at stderr while the library talks to RCCL
+    rccl_hung = False
+    if uid[0] is not None:
+        import ctypes
+        import threading
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        res = {}
+        th = threading.Thread(target=c_abi_gather, args=(res,), daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        rccl_hung = th.is_alive()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+        gather.update(res if not rccl_hung else
+                      {"c_abi_error": "no answer from the library's RCCL communicator within 120 s; secondaries skipped"})
+    if rccl_hung:  # the handle's stream may be blocked behind a collective that never completes: nothing more runs on it
+        args.no_secondary = True
 
     # secondary: the same step sustained for 100 more launches (~4 s of uninterrupted GPU work: clocks settle, and an
     # outside sampler such as the driver's SMI poll gets to see the device busy; the headline value is NOT taken here)
@@ -421,6 +441,9 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
+    if rccl_hung:  # a thread is stuck inside RCCL: an orderly shutdown would wait for it
+        sys.stderr.flush()
+        os._exit(0)
     s.close()
     if world > 1:
         dist.barrier()
