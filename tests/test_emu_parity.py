@@ -183,3 +183,26 @@ def test_backward_pass_stuck_exit_matches_oracle():
     assert (e.rtn == r.rtn).all() and (e.iter_used == r.iter_used).all() and (e.fwd_passes == r.fwd_passes).all()
     ok = np.isfinite(r.cost)
     assert np.abs(e.cost[ok] / r.cost[ok] - 1).max() < 1e-8
+
+
+@pytest.mark.parametrize("name", ["corridor_n8", "free_n5"] if "free_n5" in helpers.CASES else list(helpers.CASES)[:2])
+def test_line_search_round_layouts_are_bitwise_equal(name, monkeypatch):
+    """How the step sizes of a line search are grouped into sweeps is scheduling only (ddp_wave.h, fwd_pass): one step
+    per sweep, or {0} {1,2} {3,4} ... {9,10}.  Each trial's arithmetic and the order in which the trials are judged stay
+    those of the sequential search, so every output of both phases must be bit-identical."""
+    g, batch = helpers.load_case(name)
+    p0, p1 = helpers.case_params(name)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIRECT_EMU_PAIR", mode)
+        e0 = emuapi.solve_batch(p0, batch)
+        e1 = emuapi.solve_batch(p1, helpers.phase1_batch(g, batch))
+        outs.append((e0, e1))
+    steps = 0
+    for ph in range(2):
+        for f in ("rtn", "iter_used", "fwd_passes", "cost", "costq", "T", "poly", "bez", "opterr", "mu"):
+            a = np.asarray(getattr(outs[0][ph], f))
+            for o in outs[1:]:
+                assert np.array_equal(a.view(np.uint8), np.asarray(getattr(o[ph], f)).view(np.uint8)), (ph, f)
+        steps += int((outs[0][ph].fwd_passes > 1).sum())
+    assert steps > 0
