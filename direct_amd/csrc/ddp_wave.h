@@ -1141,8 +1141,11 @@ struct Wave {
     WSYNC();
     // opterr = max(|Qu|, |r|, |c + y|) over the sweep (DDP:641): one running maximum per lane is enough
     PLV(Real, e_mu);
-    LANES { LV(e_mu) = 0; }
-    Acc qu_err = 0;
+    PLV(Acc, e_qu);  // running max |Hu[j]| of lane j < 10 over the knots (DDP:633, quirk Q10: Qu after the condensation correction)
+    LANES {
+      LV(e_mu) = 0;
+      LV(e_qu) = 0;
+    }
 
     // plane counts run two knots ahead of the sweep (the prefetch of knot k-1 needs P(k-1) for its
     // addresses: loading it on the spot would expose one HBM round trip per knot)
@@ -1496,7 +1499,6 @@ struct Wave {
       // with v_readlane (SGPR operands of the FMAs): the LDS pipe is the busiest unit of the sweep and a
       // round trip per elimination step would also sit on the serial dependency chain.
       PLA(Acc, m, 10);
-      PLV(Acc, colmax);
       LANES {
         // column `lane` of [Huu + lam I | Hu | Hux]; lanes >= 20 redo column 19 (their results are never read)
         const int l19 = lane < 20 ? lane : 19;
@@ -1504,17 +1506,14 @@ struct Wave {
         const int stride = l19 < 10 ? 10 : 1;
 #pragma unroll
         for (int a = 0; a < 10; a++) LV(m)[a] = src[a * stride];
+        const Acc hu = L.Hz[9 + (lane < 10 ? lane : 9)];  // Hu = Hz[9..18], one entry per lane: max |Qu| for the optimality error
         DDP_LOADS_ISSUED();
-        Acc cmax = 0;  // lane 10 holds Hu = Hz[9..18]: max |Qu| for the optimality error (DDP:633, quirk Q10)
-#pragma unroll
-        for (int a = 0; a < 10; a++) cmax = fmax(cmax, fabs(LV(m)[a]));
-        LV(colmax) = cmax;
+        LV(e_qu) = fmax(LV(e_qu), fabs(hu));
         if (regi > 0) {  // lam = base^reg - 1 is exactly 0 at reg = 0 (the common case)
 #pragma unroll
           for (int a = 0; a < 10; a++) LV(m)[a] += ((a == lane) ? lam : (Acc)0);
         }
       }
-      const Acc qu_knot = RDLANE_V(colmax, 10);
       // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
       // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]): the
       // multiplier of row i is lane i's scaled entry.  The scaled rows are also written to LDS, where
@@ -1601,7 +1600,6 @@ struct Wave {
         }
       }
       WSYNC();
-      qu_err = fmax(qu_err, qu_knot);  // DDP:633 (quirk Q10): Qu after the condensation correction
       DDP_MARK("B_R2");
       // ---- R2: slack / dual gains per row; V recursion; gains to HBM
       LANES {
@@ -1684,6 +1682,7 @@ struct Wave {
     }
     DDP_MARK("B_END");
     const double mu_err = WAVE_MAX_D(e_mu);
+    const double qu_err = WAVE_MAX_D(e_qu);
     st.bp_failed = 0;
     st.opterr = fmax((double)qu_err, mu_err);  // DDP:641
     return 1;
