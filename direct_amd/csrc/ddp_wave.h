@@ -2087,7 +2087,8 @@ struct Wave {
                 const Real y = LV(ry)[i];
                 const Real ynew = (Real)(St)(y + alpha[t] * LV(rky)[i] - az);
                 snew = (Real)(St)(s + alpha[t] * LV(rks)[i] + (s * frcp(y)) * az);
-                LV(bad)[t] |= (in && (ynew < omt * y || snew < omt * s)) ? 1 : 0;
+                // bitwise, not short-circuit: the latter compiles to nested exec-masked branches per row
+                LV(bad)[t] |= (int)(in & ((ynew < omt * y) | (snew < omt * s)));
                 LV(plog)[t].mul(in ? ynew : (Real)1);
                 LV(serr)[t] += in ? fabs(cn + ynew) : (Real)0;
                 if (in) {
@@ -2099,11 +2100,11 @@ struct Wave {
                 // once (phase R1) instead of every trial re-deriving them from the old control values
                 const Real co = LV(rky)[i];
                 snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - LV(ry)[i] * az);
-                LV(bad)[t] |= (in && (cn > omt * co || snew < omt * s)) ? 1 : 0;
+                LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
                 LV(plog)[t].mul(in ? -cn : (Real)1);
                 if (in) sn[r] = (St)snew;
               }
-              LV(nviol)[t] += (in && cn >= (Real)2.0e-4) ? 1 : 0;
+              LV(nviol)[t] += (int)(in & (cn >= (Real)2.0e-4));
             }
           }
         }
