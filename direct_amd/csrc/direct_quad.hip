@@ -20,8 +20,33 @@ namespace {
 
 constexpr int NX = DIRECT_QUAD_NX, NU = DIRECT_QUAD_NU;
 
+// Phase boundary inside a one-wave workgroup: LDS operations of one wave execute in order, so all that is needed is
+// that the compiler keeps them in order (same reasoning as WSYNC in ddp_wave.h).  __syncthreads() would add an
+// s_barrier and s_waitcnt vmcnt(0), i.e. wait for every outstanding HBM access at every phase.
+#define QSYNC()                      \
+  do {                               \
+    asm volatile("" ::: "memory");   \
+    __builtin_amdgcn_wave_barrier(); \
+  } while (0)
+
+// 1 / sqrt(x) and 1 / x: hardware seed + two Newton steps (full double accuracy), a dozen instructions
+// instead of the ~40 of an IEEE division or square root
+__device__ __forceinline__ double q_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ double q_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 struct QConst {
   double m, g, J[3], dt, q[NX], r[NU], qf[NX], reg_base, tol;
+  double inv_m, inv_J[3], kJ[3];  // 1 / m, 1 / J, (J2-J1)/J0, (J0-J2)/J1, (J1-J0)/J2
   int iter_max, fixed_iters;
 };
 
@@ -44,10 +69,10 @@ struct QBatch {
 };
 
 struct QLds {
-  double V[144], Vn[144], A[144], VA[144], Qxx[144];
-  double Bm[48], VB[48], Qux[48], Kk[48], QuuK[48];
+  double V[144], Vn[144], VA[144], Qxx[144];
+  double VB[48], Qux[48], Kk[48], QuuK[48];
   double Quu[16], Vx[12], Qx[12], xk[12], xn[12], dx[12], xnext[12];
-  double Qu[4], kk[4], Quuk[4], uk[4], un[4], trig[8], S[40], part[16];
+  double Qu[4], kk[4], Quuk[4], uk[4], un[4], trig[8], S[60], part[16];
   QState st;
 };
 
@@ -60,8 +85,9 @@ __device__ __forceinline__ double wsum(double v) {
 // S[0..8] d vdot / d euler, S[9..17] d eulerdot / d euler, S[18..26] W, S[27..35] d omegadot / d omega, S[36..38] R e3 / m
 __device__ __forceinline__ double special_entry(const QConst& c, const double* x, const double* u, const double* t, int e) {
   const double sph = t[0], cph = t[1], sth = t[2], cth = t[3], sps = t[4], cps = t[5];
-  const double a = u[0] / c.m, tth = sth / cth, sec2 = 1.0 / (cth * cth);
-  const double k0 = (c.J[2] - c.J[1]) / c.J[0], k1 = (c.J[0] - c.J[2]) / c.J[1], k2 = (c.J[1] - c.J[0]) / c.J[2];
+  const double icth = t[6];  // 1 / cos(theta), once per knot (trig_lanes)
+  const double a = u[0] * c.inv_m, tth = sth * icth, sec2 = icth * icth;
+  const double k0 = c.kJ[0], k1 = c.kJ[1], k2 = c.kJ[2];
   switch (e) {
     case 0: return a * (-sph * sth * cps + cph * sps);
     case 1: return a * (cph * cth * cps);
@@ -78,7 +104,7 @@ __device__ __forceinline__ double special_entry(const QConst& c, const double* x
     case 12: return -sph * x[10] - cph * x[11];
     case 13: return 0.0;
     case 14: return 0.0;
-    case 15: return (cph * x[10] - sph * x[11]) / cth;
+    case 15: return (cph * x[10] - sph * x[11]) * icth;
     case 16: return (sph * x[10] + cph * x[11]) * sth * sec2;
     case 17: return 0.0;
     case 18: return 1.0;
@@ -88,8 +114,8 @@ __device__ __forceinline__ double special_entry(const QConst& c, const double* x
     case 22: return cph;
     case 23: return -sph;
     case 24: return 0.0;
-    case 25: return sph / cth;
-    case 26: return cph / cth;
+    case 25: return sph * icth;
+    case 26: return cph * icth;
     case 27: return 0.0;
     case 28: return -k0 * x[11];
     case 29: return -k0 * x[10];
@@ -99,16 +125,17 @@ __device__ __forceinline__ double special_entry(const QConst& c, const double* x
     case 33: return -k2 * x[10];
     case 34: return -k2 * x[9];
     case 35: return 0.0;
-    case 36: return (cph * sth * cps + sph * sps) / c.m;
-    case 37: return (cph * sth * sps - sph * cps) / c.m;
-    default: return (cph * cth) / c.m;
+    case 36: return (cph * sth * cps + sph * sps) * c.inv_m;
+    case 37: return (cph * sth * sps - sph * cps) * c.inv_m;
+    default: return (cph * cth) * c.inv_m;
   }
 }
 
 // component l of f(x, u) from trig[]
 __device__ __forceinline__ double dyn_entry(const QConst& c, const double* x, const double* u, const double* t, int l) {
   const double sph = t[0], cph = t[1], sth = t[2], cth = t[3], sps = t[4], cps = t[5];
-  const double a = u[0] / c.m, tth = sth / cth;
+  const double icth = t[6];
+  const double a = u[0] * c.inv_m, tth = sth * icth;
   switch (l) {
     case 0: return x[3];
     case 1: return x[4];
@@ -118,10 +145,10 @@ __device__ __forceinline__ double dyn_entry(const QConst& c, const double* x, co
     case 5: return a * (cph * cth) - c.g;
     case 6: return x[9] + sph * tth * x[10] + cph * tth * x[11];
     case 7: return cph * x[10] - sph * x[11];
-    case 8: return (sph * x[10] + cph * x[11]) / cth;
-    case 9: return (u[1] - (c.J[2] - c.J[1]) * x[10] * x[11]) / c.J[0];
-    case 10: return (u[2] - (c.J[0] - c.J[2]) * x[9] * x[11]) / c.J[1];
-    default: return (u[3] - (c.J[1] - c.J[0]) * x[9] * x[10]) / c.J[2];
+    case 8: return (sph * x[10] + cph * x[11]) * icth;
+    case 9: return (u[1] - (c.J[2] - c.J[1]) * x[10] * x[11]) * c.inv_J[0];
+    case 10: return (u[2] - (c.J[0] - c.J[2]) * x[9] * x[11]) * c.inv_J[1];
+    default: return (u[3] - (c.J[1] - c.J[0]) * x[9] * x[10]) * c.inv_J[2];
   }
 }
 
@@ -152,6 +179,7 @@ __device__ __forceinline__ void trig_lanes(const double* x, double* trig, int la
     sincos_fast(x[6 + lane], &s, &c);
     trig[2 * lane] = s;
     trig[2 * lane + 1] = c;
+    if (lane == 1) trig[6] = q_rcp(c);  // 1 / cos(theta)
   }
 }
 
@@ -179,21 +207,21 @@ __device__ void q_begin(const QBatch<St>& Q, QLds& L, int b, int lane) {
     L.xn[lane] = (double)Q.x0[(size_t)b * NX + lane];
   }
   if (lane < NU) L.un[lane] = lane == 0 ? Q.c.m * Q.c.g : 0.0;  // the hover input
-  __syncthreads();
+  QSYNC();
   double cost = 0.0;
   St* X = Q.X[0] + (size_t)b * (N + 1) * NX;
   St* U = Q.U[0] + (size_t)b * N * NU;
   for (int k = 0; k < N; k++) {
     if (lane < NX) L.xn[lane] = (double)(St)L.xn[lane];  // the stored iterate is the iterate
-    __syncthreads();
+    QSYNC();
     trig_lanes(L.xn, L.trig, lane);
-    __syncthreads();
+    QSYNC();
     cost += roll_knot(Q.c, L, xg, lane);
     if (lane < NX) X[(size_t)k * NX + lane] = (St)L.xn[lane];
     if (lane < NU) U[(size_t)k * NU + lane] = (St)L.un[lane];
-    __syncthreads();
+    QSYNC();
     if (lane < NX) L.xn[lane] = L.xnext[lane];
-    __syncthreads();
+    QSYNC();
   }
   double part = 0.0;
   if (lane < NX) {
@@ -221,92 +249,93 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
     else if (L.st.step > 3) reg += 1;
     L.st.reg = reg < 0 ? 0 : (reg > 24 ? 24 : reg);
   }
-  __syncthreads();
+  QSYNC();
   double lam = 1.0;
   for (int q = 0; q < L.st.reg; q++) lam *= c.reg_base;
   lam -= 1.0;
   const St* X = Q.X[cur] + (size_t)b * (N + 1) * NX;
   const St* U = Q.U[cur] + (size_t)b * N * NU;
   for (int e = lane; e < 144; e += 64) L.V[e] = (e / 12 == e % 12) ? c.qf[e / 12] : 0.0;
+  if (lane < 18) L.S[40 + lane] = (lane >= 9 && (lane - 9) / 3 == (lane - 9) % 3) ? 1.0 : 0.0;  // zero block, identity block
   if (lane < NX) L.Vx[lane] = c.qf[lane] * ((double)X[(size_t)N * NX + lane] - xg[lane]);
-  __syncthreads();
+  QSYNC();
+  // x_k / u_k are loaded one knot ahead into a register: with QSYNC nothing waits for HBM but the use of the value
+  const int lxu = lane < NX + NU ? lane : NX + NU - 1;
+  const St* src = lxu < NX ? X + lxu : U + (lxu - NX);
+  const int stride = lxu < NX ? NX : NU;
+  St pre = src[(size_t)(N - 1) * stride];
   for (int k = N - 1; k >= 0; k--) {
-    if (lane < NX) L.xk[lane] = (double)X[(size_t)k * NX + lane];
-    else if (lane < NX + NU) L.uk[lane - NX] = (double)U[(size_t)k * NU + lane - NX];
-    __syncthreads();
+    if (lane < NX) L.xk[lane] = (double)pre;
+    else if (lane < NX + NU) L.uk[lane - NX] = (double)pre;
+    pre = src[(size_t)(k > 0 ? k - 1 : 0) * stride];
+    QSYNC();
     trig_lanes(L.xk, L.trig, lane);
-    __syncthreads();
+    QSYNC();
     if (lane < 39) L.S[lane] = special_entry(c, L.xk, L.uk, L.trig, lane);
-    __syncthreads();
-    // A = I + dt f_x, B = dt f_u
-    for (int e = lane; e < 144; e += 64) {
-      const int r = e / 12, cc = e % 12;
-      double v = r == cc ? 1.0 : 0.0;
-      if (r < 3) v += (cc == r + 3) ? c.dt : 0.0;
-      else if (r < 6) v += (cc >= 6 && cc < 9) ? c.dt * L.S[(r - 3) * 3 + cc - 6] : 0.0;
-      else if (r < 9) v += (cc >= 6 && cc < 9) ? c.dt * L.S[9 + (r - 6) * 3 + cc - 6] : ((cc >= 9) ? c.dt * L.S[18 + (r - 6) * 3 + cc - 9] : 0.0);
-      else v += (cc >= 9) ? c.dt * L.S[27 + (r - 9) * 3 + cc - 9] : 0.0;
-      L.A[e] = v;
-    }
-    if (lane < 48) {
-      const int r = lane / 4, cc = lane % 4;
-      double v = 0.0;
-      if (cc == 0 && r >= 3 && r < 6) v = c.dt * L.S[36 + r - 3];
-      if (r >= 9 && cc == r - 8) v = c.dt / c.J[r - 9];
-      L.Bm[lane] = v;
-    }
-    __syncthreads();
-    for (int e = lane; e < 144; e += 64) {  // VA = V A
-      const int r = e / 12, cc = e % 12;
+    QSYNC();
+    // A = I + dt F and B = dt G are never formed.  F = f_x has four 3x3 blocks of non-constant entries (S[0..35]) and an
+    // identity block (rows 0..2, columns 3..5); G = f_u has the column S[36..38] (rows 3..5) and 1 / J (rows 9..11).
+    // With S[40..48] = 0 and S[49..57] = I3 every product against F is "two 3x3 blocks per column group":
+    //   (V F)[r][3g + c]  = sum_j V[r][la(g) + j] S[sa(g) + 3j + c] + sum_j V[r][lb(g) + j] S[sb(g) + 3j + c]
+    //   (F' M)[3g + c][q] = sum_j S[sa(g) + 3j + c] M[la(g) + j][q] + sum_j S[sb(g) + 3j + c] M[lb(g) + j][q]
+    // six terms instead of twelve, and no 144-entry matrix to build per knot.
+    for (int e = lane; e < 144; e += 64) {  // VA = V A = V + dt V F
+      const int r = e / 12, cc = e % 12, g = cc / 3, c3 = cc % 3;
+      const int la = g == 2 ? 3 : (g == 3 ? 6 : 0), lb = g == 2 ? 6 : (g == 3 ? 9 : 0);
+      const int sa = g == 0 ? 40 : (g == 1 ? 49 : (g == 2 ? 0 : 18)), sb = g == 2 ? 9 : (g == 3 ? 27 : 40);
       double acc = 0.0;
 #pragma unroll
-      for (int l = 0; l < 12; l++) acc += L.V[r * 12 + l] * L.A[l * 12 + cc];
-      L.VA[e] = acc;
+      for (int j = 0; j < 3; j++) acc += L.V[r * 12 + la + j] * L.S[sa + 3 * j + c3] + L.V[r * 12 + lb + j] * L.S[sb + 3 * j + c3];
+      L.VA[e] = L.V[e] + c.dt * acc;
     }
     if (lane < 48) {  // VB = V B
       const int r = lane / 4, cc = lane % 4;
-      double acc = 0.0;
-#pragma unroll
-      for (int l = 0; l < 12; l++) acc += L.V[r * 12 + l] * L.Bm[l * 4 + cc];
-      L.VB[lane] = acc;
+      double acc;
+      if (cc == 0) acc = L.V[r * 12 + 3] * L.S[36] + L.V[r * 12 + 4] * L.S[37] + L.V[r * 12 + 5] * L.S[38];
+      else acc = L.V[r * 12 + 8 + cc] * c.inv_J[cc - 1];
+      L.VB[lane] = c.dt * acc;
     }
-    __syncthreads();
-    for (int e = lane; e < 144; e += 64) {  // Qxx = lxx + A' VA
-      const int r = e / 12, cc = e % 12;
+    QSYNC();
+    for (int e = lane; e < 144; e += 64) {  // Qxx = lxx + A' VA = lxx + VA + dt F' VA
+      const int r = e / 12, cc = e % 12, g = r / 3, r3 = r % 3;
+      const int la = g == 2 ? 3 : (g == 3 ? 6 : 0), lb = g == 2 ? 6 : (g == 3 ? 9 : 0);
+      const int sa = g == 0 ? 40 : (g == 1 ? 49 : (g == 2 ? 0 : 18)), sb = g == 2 ? 9 : (g == 3 ? 27 : 40);
       double acc = 0.0;
 #pragma unroll
-      for (int l = 0; l < 12; l++) acc += L.A[l * 12 + r] * L.VA[l * 12 + cc];
-      L.Qxx[e] = acc + (r == cc ? c.dt * c.q[r] : 0.0);
+      for (int j = 0; j < 3; j++) acc += L.S[sa + 3 * j + r3] * L.VA[(la + j) * 12 + cc] + L.S[sb + 3 * j + r3] * L.VA[(lb + j) * 12 + cc];
+      L.Qxx[e] = L.VA[e] + c.dt * acc + (r == cc ? c.dt * c.q[r] : 0.0);
     }
     if (lane < 48) {  // Qux = B' VA
       const int i = lane / 12, j = lane % 12;
-      double acc = 0.0;
-#pragma unroll
-      for (int l = 0; l < 12; l++) acc += L.Bm[l * 4 + i] * L.VA[l * 12 + j];
-      L.Qux[lane] = acc;
+      double acc;
+      if (i == 0) acc = L.S[36] * L.VA[3 * 12 + j] + L.S[37] * L.VA[4 * 12 + j] + L.S[38] * L.VA[5 * 12 + j];
+      else acc = c.inv_J[i - 1] * L.VA[(8 + i) * 12 + j];
+      L.Qux[lane] = c.dt * acc;
     } else {  // Quu = luu + B' VB
       const int e = lane - 48, i = e / 4, j = e % 4;
-      double acc = 0.0;
-#pragma unroll
-      for (int l = 0; l < 12; l++) acc += L.Bm[l * 4 + i] * L.VB[l * 4 + j];
-      L.Quu[e] = acc + (i == j ? c.dt * c.r[i] : 0.0);
+      double acc;
+      if (i == 0) acc = L.S[36] * L.VB[3 * 4 + j] + L.S[37] * L.VB[4 * 4 + j] + L.S[38] * L.VB[5 * 4 + j];
+      else acc = c.inv_J[i - 1] * L.VB[(8 + i) * 4 + j];
+      L.Quu[e] = c.dt * acc + (i == j ? c.dt * c.r[i] : 0.0);
     }
-    __syncthreads();
-    if (lane < NX) {  // Qx = lx + A' Vx
+    if (lane < NX) {  // Qx = lx + A' Vx = lx + Vx + dt F' Vx
+      const int g = lane / 3, r3 = lane % 3;
+      const int la = g == 2 ? 3 : (g == 3 ? 6 : 0), lb = g == 2 ? 6 : (g == 3 ? 9 : 0);
+      const int sa = g == 0 ? 40 : (g == 1 ? 49 : (g == 2 ? 0 : 18)), sb = g == 2 ? 9 : (g == 3 ? 27 : 40);
       double acc = 0.0;
 #pragma unroll
-      for (int l = 0; l < 12; l++) acc += L.A[l * 12 + lane] * L.Vx[l];
-      L.Qx[lane] = c.dt * c.q[lane] * (L.xk[lane] - xg[lane]) + acc;
+      for (int j = 0; j < 3; j++) acc += L.S[sa + 3 * j + r3] * L.Vx[la + j] + L.S[sb + 3 * j + r3] * L.Vx[lb + j];
+      L.Qx[lane] = c.dt * c.q[lane] * (L.xk[lane] - xg[lane]) + L.Vx[lane] + c.dt * acc;
     } else if (lane < NX + NU) {  // Qu = lu + B' Vx
       const int i = lane - NX;
-      double acc = 0.0;
-#pragma unroll
-      for (int l = 0; l < 12; l++) acc += L.Bm[l * 4 + i] * L.Vx[l];
-      L.Qu[i] = c.dt * c.r[i] * (L.uk[i] - (i == 0 ? c.m * c.g : 0.0)) + acc;
+      double acc;
+      if (i == 0) acc = L.S[36] * L.Vx[3] + L.S[37] * L.Vx[4] + L.S[38] * L.Vx[5];
+      else acc = c.inv_J[i - 1] * L.Vx[8 + i];
+      L.Qu[i] = c.dt * c.r[i] * (L.uk[i] - (i == 0 ? c.m * c.g : 0.0)) + c.dt * acc;
     }
-    __syncthreads();
+    QSYNC();
     // LLT of Quu + lam I: computed by every lane (wave-uniform), then one right-hand side per lane
-    double Lm[NU][NU];
+    double Lm[NU][NU], ri[NU];  // ri = 1 / L_jj: the factor and both solves multiply instead of dividing
     int ok = 1;
 #pragma unroll
     for (int j = 0; j < NU; j++) {
@@ -314,19 +343,18 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
 #pragma unroll
       for (int l = 0; l < j; l++) d -= Lm[j][l] * Lm[j][l];
       if (d <= 0.0) ok = 0;
-      const double dj = sqrt(d);
-      Lm[j][j] = dj;
+      ri[j] = q_rsq(d);
 #pragma unroll
       for (int i = j + 1; i < NU; i++) {
         double v = L.Quu[i * NU + j];
 #pragma unroll
         for (int l = 0; l < j; l++) v -= Lm[i][l] * Lm[j][l];
-        Lm[i][j] = v / dj;
+        Lm[i][j] = v * ri[j];
       }
     }
     if (!ok) {
       if (lane == 0) L.st.bp_failed = 1;
-      __syncthreads();
+      QSYNC();
       return 0;
     }
     if (lane <= NX) {  // column 0: Qu -> k, columns 1..12: Qux[:, c-1] -> K[:, c-1]
@@ -336,14 +364,14 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
         double v = lane == 0 ? L.Qu[i] : L.Qux[i * NX + lane - 1];
 #pragma unroll
         for (int l = 0; l < i; l++) v -= Lm[i][l] * y[l];
-        y[i] = v / Lm[i][i];
+        y[i] = v * ri[i];
       }
 #pragma unroll
       for (int i = NU - 1; i >= 0; i--) {
         double v = y[i];
 #pragma unroll
         for (int l = i + 1; l < NU; l++) v -= Lm[l][i] * z[l];
-        z[i] = v / Lm[i][i];
+        z[i] = v * ri[i];
       }
 #pragma unroll
       for (int i = 0; i < NU; i++) {
@@ -351,7 +379,7 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
         else L.Kk[i * NX + lane - 1] = -z[i];
       }
     }
-    __syncthreads();
+    QSYNC();
     if (lane < 48) {  // gains to HBM; Quu K
       Q.K[((size_t)b * N + k) * 48 + lane] = (St)L.Kk[lane];
       const int i = lane / 12, j = lane % 12;
@@ -367,7 +395,7 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
       for (int l = 0; l < NU; l++) acc += L.Quu[i * NU + l] * L.kk[l];
       L.Quuk[i] = acc;
     }
-    __syncthreads();
+    QSYNC();
     for (int e = lane; e < 144; e += 64) {  // value update with the UNREGULARISED Quu (reference :626-628)
       const int i = e / 12, j = e % 12;
       double acc = L.Qxx[e];
@@ -382,13 +410,13 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
       for (int l = 0; l < NU; l++) acc += L.Kk[l * NX + lane] * L.Quuk[l] + L.Kk[l * NX + lane] * L.Qu[l] + L.Qux[l * NX + lane] * L.kk[l];
       L.dx[lane] = acc;  // Vx for the next knot, parked until V has been read by everyone
     }
-    __syncthreads();
+    QSYNC();
     for (int e = lane; e < 144; e += 64) L.V[e] = 0.5 * (L.Vn[e] + L.Vn[(e % 12) * 12 + e / 12]);
     if (lane < NX) L.Vx[lane] = L.dx[lane];
-    __syncthreads();
+    QSYNC();
   }
   if (lane == 0) L.st.bp_failed = 0;
-  __syncthreads();
+  QSYNC();
   return 1;
 }
 
@@ -405,17 +433,28 @@ __device__ void q_forward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
     double alpha = 1.0;
     for (int q = 0; q < step; q++) alpha *= 0.5;
     if (lane < NX) L.xn[lane] = (double)X[lane];
-    __syncthreads();
+    QSYNC();
     double cost = 0.0;
+    // the old iterate and the gains of knot k + 1 are loaded while knot k is evaluated (clamped indices: no branches)
+    const int l12 = lane < NX ? lane : NX - 1, l52 = lane < 52 ? lane : 51, l4 = lane >= 48 && lane < 52 ? lane - 48 : 0;
+    const St* gsrc = l52 < 48 ? Q.K + (size_t)b * N * 48 + l52 : Q.kf + (size_t)b * N * NU + (l52 - 48);
+    const int gstride = l52 < 48 ? 48 : NU;
+    St px = X[l12], pg = gsrc[0], pu = U[l4];
     for (int k = 0; k < N; k++) {
-      if (lane < NX) L.dx[lane] = L.xn[lane] - (double)X[(size_t)k * NX + lane];
-      if (lane < 48) L.Kk[lane] = (double)Q.K[((size_t)b * N + k) * 48 + lane];
+      if (lane < NX) L.dx[lane] = L.xn[lane] - (double)px;
+      if (lane < 48) L.Kk[lane] = (double)pg;
       else if (lane < 52) {
-        L.kk[lane - 48] = (double)Q.kf[((size_t)b * N + k) * NU + lane - 48];
-        L.uk[lane - 48] = (double)U[(size_t)k * NU + lane - 48];
+        L.kk[lane - 48] = (double)pg;
+        L.uk[lane - 48] = (double)pu;
+      }
+      {
+        const size_t kn = (size_t)(k + 1 < N ? k + 1 : k);
+        px = X[kn * NX + l12];
+        pg = gsrc[kn * gstride];
+        pu = U[kn * NU + l4];
       }
       trig_lanes(L.xn, L.trig, lane);
-      __syncthreads();
+      QSYNC();
       if (lane < NU) {
         double acc = 0.0;
 #pragma unroll
@@ -423,13 +462,13 @@ __device__ void q_forward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
         // rounded to the storage type before use: the recorded cost belongs to the iterate that is stored
         L.un[lane] = (double)(St)(L.uk[lane] + alpha * L.kk[lane] + acc);
       }
-      __syncthreads();
+      QSYNC();
       cost += roll_knot(c, L, xg, lane);
       if (lane < NX) Xt[(size_t)k * NX + lane] = (St)L.xn[lane];
       if (lane < NU) Ut[(size_t)k * NU + lane] = (St)L.un[lane];
-      __syncthreads();
+      QSYNC();
       if (lane < NX) L.xn[lane] = (double)(St)L.xnext[lane];
-      __syncthreads();
+      QSYNC();
     }
     double part = 0.0;
     if (lane < NX) {
@@ -441,13 +480,13 @@ __device__ void q_forward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
       if (lane == 0) {
         L.st.cost = cost; L.st.step = step; L.st.fp_failed = 0; L.st.cur = nxt;
       }
-      __syncthreads();
+      QSYNC();
       return;
     }
-    __syncthreads();
+    QSYNC();
   }
   if (lane == 0) L.st.fp_failed = 1;
-  __syncthreads();
+  QSYNC();
 }
 
 template <typename St>
@@ -481,7 +520,7 @@ __global__ __launch_bounds__(64, 4) void k_quad_iterate(QBatch<St> Q, int n_iter
       if (!Q.c.fixed_iters && !L.st.fp_failed && prev - L.st.cost <= Q.c.tol * prev) L.st.done = 1;
       if (L.st.iter >= Q.c.iter_max) L.st.done = 1;
     }
-    __syncthreads();
+    __syncthreads();  // a real barrier: the next backward sweep reads U on other lanes than the forward pass wrote it
   }
   __syncthreads();
   if (lane == 0) Q.st[b] = L.st;
@@ -548,10 +587,13 @@ direct_status_t set_params(direct_quad_handle_t h, const direct_quad_params_t* p
   c.iter_max = p->iter_max; c.fixed_iters = p->fixed_iters;
   for (int i = 0; i < 3; i++) {
     c.J[i] = p->inertia[i];
+    c.inv_J[i] = 1.0 / p->inertia[i];
     c.q[i] = p->q_pos; c.q[3 + i] = p->q_vel; c.q[6 + i] = p->q_ang; c.q[9 + i] = p->q_rate;
     c.qf[i] = p->qf_pos; c.qf[3 + i] = p->qf_vel; c.qf[6 + i] = p->qf_ang; c.qf[9 + i] = p->qf_rate;
   }
   c.r[0] = p->r_thrust; c.r[1] = c.r[2] = c.r[3] = p->r_torque;
+  c.inv_m = 1.0 / c.m;
+  c.kJ[0] = (c.J[2] - c.J[1]) / c.J[0]; c.kJ[1] = (c.J[0] - c.J[2]) / c.J[1]; c.kJ[2] = (c.J[1] - c.J[0]) / c.J[2];
   return DIRECT_OK;
 }
 }  // namespace
