@@ -69,7 +69,7 @@ struct QBatch {
 };
 
 struct QLds {
-  double V[144], Vn[144], VA[144], Qxx[144];
+  double V[144], VA[144], Qxx[144];
   double VB[48], Qux[48], Kk[48], QuuK[48];
   double Quu[16], Vx[12], Qx[12], xk[12], xn[12], dx[12], xnext[12];
   double Qu[4], kk[4], Quuk[4], uk[4], un[4], trig[8], S[60], part[16];
@@ -380,39 +380,39 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
       }
     }
     QSYNC();
-    if (lane < 48) {  // gains to HBM; Quu K
+    if (lane < 48) {  // gains to HBM; W = Quu K + 2 Qux
       Q.K[((size_t)b * N + k) * 48 + lane] = (St)L.Kk[lane];
       const int i = lane / 12, j = lane % 12;
-      double acc = 0.0;
+      double acc = 2.0 * L.Qux[lane];
 #pragma unroll
       for (int l = 0; l < NU; l++) acc += L.Quu[i * NU + l] * L.Kk[l * NX + j];
       L.QuuK[lane] = acc;
-    } else if (lane < 52) {
+    } else if (lane < 52) {  // w = Quu k + Qu
       const int i = lane - 48;
       Q.kf[((size_t)b * N + k) * NU + i] = (St)L.kk[i];
-      double acc = 0.0;
+      double acc = L.Qu[i];
 #pragma unroll
       for (int l = 0; l < NU; l++) acc += L.Quu[i * NU + l] * L.kk[l];
       L.Quuk[i] = acc;
     }
     QSYNC();
-    for (int e = lane; e < 144; e += 64) {  // value update with the UNREGULARISED Quu (reference :626-628)
+    // Value update with the UNREGULARISED Quu (reference :626-628), symmetrised:
+    //   Vn = Qxx + K' Quu K + K' Qux + Qux' K,  V = (Vn + Vn') / 2 = (Qxx + Qxx') / 2 + (K' W + W' K) / 2,  W = Quu K + 2 Qux
+    // (Quu is symmetric up to rounding) - eight products per entry, written straight into V: nothing reads V between
+    // the V A product at the top of the knot and here.
+    for (int e = lane; e < 144; e += 64) {
       const int i = e / 12, j = e % 12;
-      double acc = L.Qxx[e];
+      double acc = L.Qxx[e] + L.Qxx[j * 12 + i];
 #pragma unroll
-      for (int l = 0; l < NU; l++)
-        acc += L.Kk[l * NX + i] * L.QuuK[l * NX + j] + L.Kk[l * NX + i] * L.Qux[l * NX + j] + L.Qux[l * NX + i] * L.Kk[l * NX + j];
-      L.Vn[e] = acc;
+      for (int l = 0; l < NU; l++) acc += L.Kk[l * NX + i] * L.QuuK[l * NX + j] + L.Kk[l * NX + j] * L.QuuK[l * NX + i];
+      L.V[e] = 0.5 * acc;
     }
-    if (lane < NX) {
+    if (lane < NX) {  // Vx = Qx + K' (Quu k + Qu) + Qux' k; Vx was last read for Qx / Qu above
       double acc = L.Qx[lane];
 #pragma unroll
-      for (int l = 0; l < NU; l++) acc += L.Kk[l * NX + lane] * L.Quuk[l] + L.Kk[l * NX + lane] * L.Qu[l] + L.Qux[l * NX + lane] * L.kk[l];
-      L.dx[lane] = acc;  // Vx for the next knot, parked until V has been read by everyone
+      for (int l = 0; l < NU; l++) acc += L.Kk[l * NX + lane] * L.Quuk[l] + L.Qux[l * NX + lane] * L.kk[l];
+      L.Vx[lane] = acc;
     }
-    QSYNC();
-    for (int e = lane; e < 144; e += 64) L.V[e] = 0.5 * (L.Vn[e] + L.Vn[(e % 12) * 12 + e / 12]);
-    if (lane < NX) L.Vx[lane] = L.dx[lane];
     QSYNC();
   }
   if (lane == 0) L.st.bp_failed = 0;
