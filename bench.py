@@ -422,7 +422,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "iters_per_step_rank0": iters_step, "gather": gather,
         }
-        if sq is not None:
+        if sq is not None and "f64_flops_per_ddp_iteration" in sq["derived"] and "f64_arith_frac_of_valu" in sq["derived"]:
             fl = sq["derived"]["f64_flops_per_ddp_iteration"]
             tf = fl * (iters_step / (avg_ms * 1e-3)) / 1e12
             line["roofline_compute"] = {"bound": "fp64 vector", "achieved_tflops_f64": tf, "peak": F64_VECTOR_PEAK_TF,
