@@ -241,6 +241,25 @@ def test_shared_line_search_is_bitwise_equal_to_the_owner_only_search(built, cor
     assert int(fixed["1"][0].fwd_passes.sum()) == B * 20
 
 
+@pytest.mark.parametrize("dt,nb,nseg,chunk", [(np.float64, 3300, 40, "1"), (np.float32, 3500, 60, "3")])
+def test_shared_line_search_other_storage_types_and_chunk_sizes(built, dt, nb, nseg, chunk, monkeypatch):
+    """The same bitwise equality for double storage, an awkward batch size, shorter trajectories and tickets of three
+    outer-loop trips (a helper then holds the ticket of a chunk while the chunk before it runs three line searches)."""
+    batch = problems.make_batch("corridor", nb, nseg, seed=77)
+    monkeypatch.setenv("DIRECT_DDP_CHUNK", chunk)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIRECT_DDP_HELP", mode)
+        s = solver.DdpSolver(nb, nseg, batch.p_max, dt)
+        res[mode] = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=30), batch.astype(dt))
+        assert s.sched_error() == 0
+        s.close()
+    for a, b in zip(res["0"], res["1"]):
+        for f in ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert res["1"][1].iter_used.max() > 5
+
+
 def test_output_sampling_of_the_full_batch(built, free_batch):
     """direct_traj_sample_batch on 4096 solved trajectories: size-independent properties of the samples
     (the oracle is checked on a random subset)."""

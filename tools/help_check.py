@@ -1,17 +1,19 @@
 """Shared line search on/off: bitwise comparison of every output and kernel time (DIRECT_DDP_HELP is read at create).
-usage: help_check.py [B] [kind]"""
+usage: help_check.py [B] [kind] [modes, e.g. 0,1] [f32|f64] [N]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, ".")
 from direct_amd import abi, problems, solver
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kind = sys.argv[2] if len(sys.argv) > 2 else "free"
-b = problems.make_batch(kind, B, 100, seed=1000)
+DT = np.float64 if (len(sys.argv) > 4 and sys.argv[4] == "f64") else np.float32
+N = int(sys.argv[5]) if len(sys.argv) > 5 else 100
+b = problems.make_batch(kind, B, N, seed=1000)
 res = {}
 MODES = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "1"]
 for mode in MODES:
     os.environ["DIRECT_DDP_HELP"] = mode
-    s = solver.DdpSolver(B, 100, b.p_max, np.float32)
+    s = solver.DdpSolver(B, N, b.p_max, DT)
     g0 = s.solve(abi.phase0_params(), b)
     b1 = b.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, b.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
     pf = abi.phase1_params(iter_max=20, fixed_iters=1)
