@@ -285,12 +285,14 @@ struct TrialRes {
 // that are waiting for this very trajectory (k_iterate_dyn) claim rounds of it instead of sleeping.
 struct HelpSlot {
   int gen;         // 0: closed; else the tag of the open line search (release-published by the owner)
-  int next_round;  // next unclaimed round, 1..5 = steps (1,2) .. (9,10); owner and helpers draw from it
+  int next_round;  // next unclaimed round, 1..last_round; owner and helpers draw from it
   int active;      // helpers inside the protocol; the owner closes with gen = 0 and waits for 0
   int cancel;      // an earlier step was accepted: running rounds stop at the next knot
-  int cur, seq;    // the nominal iterate's buffer; the owner's tag counter
+  int cur;         // the nominal iterate's buffer
+  int last_round;  // 5: rounds are the step pairs (1,2) .. (9,10); 10: rounds are the single steps 1 .. 10
   double mu;
-  int done[8];     // done[r] == gen: res[2r-1], res[2r] hold round r's results (release-published by its runner)
+  int done[12];    // done[r] == gen: round r's results are in res[], one record per step (release-published by its runner)
+  int pad[4];
   TrialRes res[12];
 };
 constexpr int kMaxBuf = 11;  // iterate buffers: `cur` + one per concurrently evaluated step (3 without helpers)
@@ -1758,9 +1760,10 @@ struct Wave {
   DDP_DEV void proto_error() const { a_store(B.sched_err, 1); }
   // owner: open the line search around buffer `cur` to helpers.  Everything a helper reads (gains, the nominal
   // iterate, the row cache) was written by this wave before the release fence.
-  DDP_DEV void share_open(HelpSlot* hs, int cur, double mu, int tag) {
+  DDP_DEV void share_open(HelpSlot* hs, int cur, double mu, int tag, int last_round) {
     if (threadIdx.x == 0) {
       hs->cur = cur;
+      hs->last_round = last_round;
       hs->mu = mu;
       __hip_atomic_store(&hs->next_round, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&hs->cancel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1787,7 +1790,7 @@ struct Wave {
   DDP_DEV int share_claim(HelpSlot* hs) { return a_add(&hs->next_round, 1); }
   DDP_DEV int share_cancelled(HelpSlot* hs) { return a_load(&hs->cancel); }
   // helper: join the open line search of trajectory `b`, if there is one
-  DDP_DEV int help_enter(HelpSlot* hs, int& cur, double& mu, int& tag) {
+  DDP_DEV int help_enter(HelpSlot* hs, int& cur, double& mu, int& tag, int& last_round) {
     const int g = a_load(&hs->gen);
     if (!g) return 0;
     a_add(&hs->active, 1);
@@ -1798,13 +1801,15 @@ struct Wave {
       return 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    int cv = 0, ml = 0, mh = 0;
+    int cv = 0, ml = 0, mh = 0, lv = 0;
     if (threadIdx.x == 0) {
       cv = hs->cur;
+      lv = hs->last_round;
       ml = __double2loint(hs->mu);
       mh = __double2hiint(hs->mu);
     }
     cur = __builtin_amdgcn_readfirstlane(cv);
+    last_round = __builtin_amdgcn_readfirstlane(lv);
     mu = __hiloint2double(__builtin_amdgcn_readfirstlane(mh), __builtin_amdgcn_readfirstlane(ml));
     tag = g;
     return 1;
@@ -1813,12 +1818,13 @@ struct Wave {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the trial buffers this wave wrote
     a_add(&hs->active, -1);
   }
-  // runner of round r (steps 2r-1, 2r): hand the results to the owner
-  DDP_DEV void post_results(HelpSlot* hs, int r, const TrialRes* res, int tag) {
+  // runner of round r (steps step0 .. step0 + nt - 1): hand the results to the owner
+  DDP_DEV void post_results(HelpSlot* hs, int r, int step0, int nt, const TrialRes* res, int tag) {
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int t = 0; t < 2; t++) {  // field by field: the records stay in registers
-        TrialRes* d = &hs->res[2 * r - 1 + t];
+        if (t >= nt) break;
+        TrialRes* d = &hs->res[step0 + t];
         d->alive = res[t].alive; d->step = res[t].step; d->neg = res[t].neg; d->viol = res[t].viol;
         d->stepsize = res[t].stepsize; d->qsum = res[t].qsum; d->cost = res[t].cost;
         d->sumlog = res[t].sumlog; d->errsum = res[t].errsum;
@@ -1828,7 +1834,7 @@ struct Wave {
     a_store(&hs->done[r], tag);
   }
   // owner: wait for round r (claimed by a helper, which always completes it unless the search is cancelled)
-  DDP_DEV int fetch_results(HelpSlot* hs, int r, int tag, TrialRes* out) {
+  DDP_DEV int fetch_results(HelpSlot* hs, int r, int step0, int nt, int tag, TrialRes* out) {
     int spins = 0;
     while (a_load(&hs->done[r]) != tag) {
       __builtin_amdgcn_s_sleep(4);
@@ -1838,7 +1844,7 @@ struct Wave {
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const int* src = (const int*)&hs->res[2 * r - 1];  // two records = 32 words, one per lane
+    const int* src = (const int*)&hs->res[step0];  // two records = 32 words, one per lane
     const int v = src[threadIdx.x & 31];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -1853,18 +1859,19 @@ struct Wave {
       out[t].sumlog = __hiloint2double(__builtin_amdgcn_readlane(v, o + 11), __builtin_amdgcn_readlane(v, o + 10));
       out[t].errsum = __hiloint2double(__builtin_amdgcn_readlane(v, o + 13), __builtin_amdgcn_readlane(v, o + 12));
     }
+    if (nt < 2) out[1].alive = 0;  // a one-step round: the second record belongs to the next round
     return 1;
   }
   DDP_DEV HelpSlot* help_slot() const { return B.help ? &B.help[b] : nullptr; }
 #else  // the emulator runs one wave: nothing to share
-  DDP_DEV void share_open(HelpSlot*, int, double, int) {}
+  DDP_DEV void share_open(HelpSlot*, int, double, int, int) {}
   DDP_DEV void share_close(HelpSlot*) {}
   DDP_DEV int share_claim(HelpSlot*) { return 0; }
   DDP_DEV int share_cancelled(HelpSlot*) { return 0; }
-  DDP_DEV int help_enter(HelpSlot*, int&, double&, int&) { return 0; }
+  DDP_DEV int help_enter(HelpSlot*, int&, double&, int&, int&) { return 0; }
   DDP_DEV void help_leave(HelpSlot*) {}
-  DDP_DEV void post_results(HelpSlot*, int, const TrialRes*, int) {}
-  DDP_DEV int fetch_results(HelpSlot*, int, int, TrialRes*) { return 0; }
+  DDP_DEV void post_results(HelpSlot*, int, int, int, const TrialRes*, int) {}
+  DDP_DEV int fetch_results(HelpSlot*, int, int, int, int, TrialRes*) { return 0; }
   DDP_DEV HelpSlot* help_slot() const { return nullptr; }
 #endif
 
@@ -2186,10 +2193,10 @@ struct Wave {
     DDP_LAUNDER_S(b);
     DDP_LAUNDER_S(N);
     HelpSlot* hs = help_slot();
-    int cur = 0, infeas = 0, tag = 0;
+    int cur = 0, infeas = 0, tag = 0, last_round = 10;
     double mu_d = 0.0;
     if (helper) {
-      if (!help_enter(hs, cur, mu_d, tag)) return;
+      if (!help_enter(hs, cur, mu_d, tag, last_round)) return;
     } else {
       cur = DDP_UNIFORM_I(st.cur);
       infeas = DDP_UNIFORM_I(st.infeas);
@@ -2200,9 +2207,11 @@ struct Wave {
     const Real omt = DDP_UNIFORM_R((Real)(1.0 - tau_d));
     const int nfilter = helper ? 0 : DDP_UNIFORM_I(st.nfilter);
     double* filt = B.filt + (size_t)b * B.fcap * 2;
-    const int pair = (helper || (B.k.pair_trials && !infeas)) ? 1 : 0;
-    const int share = (!helper && pair && hs != nullptr) ? 1 : 0;
-    const int last_round = pair ? 5 : 10;  // rounds: {0}, then pairs (2r-1, 2r) or single steps r
+    // rounds: {0}, then the pairs (2r-1, 2r), r = 1..5, or the single steps r = 1..10 (few trajectories on many waves:
+    // every step then finds a wave of its own)
+    const int pair = helper ? (last_round == 5 ? 1 : 0) : ((B.k.pair_trials && !infeas) ? 1 : 0);
+    const int share = (!helper && !infeas && hs != nullptr) ? 1 : 0;
+    if (!helper) last_round = pair ? 5 : 10;
     Accept A;
     A.accepted = 0; A.nkeep = 0; A.step = 0; A.neg = 0; A.buf = cur; A.viol = 0;
     A.stepsize = 0.0; A.cost = 0.0; A.costq = 0.0; A.logcost = 0.0; A.err = 0.0; A.sumlog = 0.0; A.errsum = 0.0;
@@ -2216,12 +2225,13 @@ struct Wave {
       TrialRes res[2];
       res[0].alive = 0;
       res[1].alive = 0;
+      const int nt = (pair && mine > 0) ? 2 : 1, step0 = (pair && mine > 0) ? 2 * mine - 1 : mine;
       if (mine >= 0) {
-        if (pair && mine > 0) run_round<2>(2 * mine - 1, cur, infeas, omt, res, helper, hs);
-        else run_round<1>(mine, cur, infeas, omt, res, 0, hs);
+        if (nt == 2) run_round<2>(step0, cur, infeas, omt, res, helper, hs);
+        else run_round<1>(step0, cur, infeas, omt, res, helper, hs);
       }
       if (helper) {
-        post_results(hs, mine, res, tag);
+        post_results(hs, mine, step0, nt, res, tag);
         continue;
       }
       const int upto = mine >= 0 ? mine : last_round;
@@ -2233,7 +2243,7 @@ struct Wave {
           consider(res[1], cur, infeas, mu_d, nfilter, filt, A);
         } else {  // a helper's round
           TrialRes o[2];
-          if (!fetch_results(hs, r_eval, tag, o)) {
+          if (!fetch_results(hs, r_eval, pair ? 2 * r_eval - 1 : r_eval, pair ? 2 : 1, tag, o)) {
             broken = 1;
             break;
           }
@@ -2243,7 +2253,7 @@ struct Wave {
       }
       if (A.accepted || broken || mine < 0 || r_eval > last_round) break;
       if (share && !opened) {
-        share_open(hs, cur, mu_d, tag);
+        share_open(hs, cur, mu_d, tag, last_round);
         opened = 1;
       }
     }

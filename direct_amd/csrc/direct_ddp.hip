@@ -95,17 +95,18 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, uns
   int ready = (e == 0) ? 1 : 0, have = 0, wanted = 0;
   int spins = 0;
   for (; !ready && !wanted && spins < (1 << 22); spins++) {
-    int hv = 0, g = 0, r = 0;
+    int hv = 0, g = 0, r = 0, lr = 0;
     if (threadIdx.x == 0) {
       hv = __hip_atomic_load(&S.done_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (slots) {
         g = __hip_atomic_load(&slots[b].gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         r = __hip_atomic_load(&slots[b].next_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lr = __hip_atomic_load(&slots[b].last_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     have = __builtin_amdgcn_readfirstlane(hv);
     ready = (have >= e) ? 1 : 0;
-    wanted = (!ready && __builtin_amdgcn_readfirstlane((g != 0 && r <= 5) ? 1 : 0)) ? 1 : 0;
+    wanted = (!ready && __builtin_amdgcn_readfirstlane((g != 0 && r <= lr) ? 1 : 0)) ? 1 : 0;
     if (!ready && !wanted) __builtin_amdgcn_s_sleep(32);
   }
   if (spins > 1 || wanted) *waited = 1;
@@ -287,6 +288,7 @@ struct direct_ddp_handle_s {
   void *X[direct::kMaxBuf] = {}, *S[direct::kMaxBuf] = {}, *Y[direct::kMaxBuf] = {};
   int nbuf = 3;              // iterate buffers allocated: 3, or kMaxBuf when the line search can be shared
   HelpSlot* help = nullptr;  // [max_batch], with nbuf == kMaxBuf
+  int single_ratio = 8;      // shared line search in single steps when batch * ratio <= resident waves (DIRECT_DDP_SINGLE)
   int help_mode = -1;        // shared line search: -1 auto (batches up to 1.5 x the resident waves), DIRECT_DDP_HELP=0|1 forces
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
   double* filt = nullptr;
@@ -362,6 +364,9 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   // two trials per sweep pay off where the launch is bound by its slowest chain (batch up to twice the resident
   // waves: +4 % at B = 4096) and cost ~1 % where it is throughput-bound; results are identical either way
   k.pair_trials = h->pair_trials >= 0 ? h->pair_trials : ((h->sched_slots > 0 && in.batch <= 2 * h->sched_slots) ? 1 : 0);
+  // few trajectories on many waves and a shared line search: single steps, one wave each, beat pairs
+  if (h->pair_trials < 0 && h->help && h->help_mode != 0 && h->dynamic && h->nmax >= 80 && in.batch * h->single_ratio <= h->sched_slots)
+    k.pair_trials = 0;
   return B;
 }
 
@@ -390,8 +395,16 @@ template <typename Real>
 static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
   auto Bt = make_batch<Real>(h, h->cur_in, h->params);
   if (mode == 0) {
-    // the static launch is already tail-free when every trajectory is resident at once
-    if (h->dynamic && h->sched_slots > 0 && h->B > h->sched_slots) {
+    // shared line search: where the launch is bound by its slowest chain and a round is long enough to pay for the
+    // protocol's fences (agent-scope release = L2 write-back).  Measured at N = 100: +5 .. +13 % for batches up to 4/3 of
+    // the resident waves, -1.4 % at twice the resident waves, +15 .. +20 % below them; at N = 60: -1 .. -5 %; at
+    // N = 30: up to -35 %.  Unless forced either way.
+    const bool help = h->help && (h->help_mode >= 0 ? h->help_mode != 0 : (2 * h->B <= 3 * h->sched_slots && h->nmax >= 80));
+    // The static launch is tail-free when every trajectory is resident at once - but then the waves that are left
+    // over have nothing to do, while the ticket scheduler turns them into helpers: with help it is used for small
+    // batches too (DIRECT_DDP_SMALL=0: not below the resident waves).
+    static const bool small_dyn = getenv("DIRECT_DDP_SMALL") ? atoi(getenv("DIRECT_DDP_SMALL")) != 0 : true;
+    if (h->dynamic && h->sched_slots > 0 && (h->B > h->sched_slots || (help && small_dyn))) {
       Sched S;
       S.ticket = (unsigned*)h->sched;
       S.err = h->sched + 1;
@@ -400,9 +413,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.prio = h->sched_prio;
       (void)hipMemsetAsync(h->sched, 0, sizeof(int), h->stream);  // the error flag [1] is sticky: cleared in stage_inputs
       (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);
-      // shared line search: where the launch is bound by its slowest chain (measured: +5 .. +13 % for batches up to
-      // 4/3 of the resident waves, -1.4 % at twice the resident waves), unless forced either way
-      if (h->help && (h->help_mode >= 0 ? h->help_mode : (2 * h->B <= 3 * h->sched_slots)) && Bt.k.pair_trials) {
+      if (help) {
         (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
         Bt.help = h->help;
       }
@@ -556,10 +567,11 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
                                             : resident_slots<float>(h, prop.multiProcessorCount);
   if (const char* ev = getenv("DIRECT_DDP_HELP")) h->help_mode = atoi(ev);
+  if (const char* ev = getenv("DIRECT_DDP_SINGLE")) h->single_ratio = atoi(ev) > 0 ? atoi(ev) : (1 << 30);
   // The shared line search needs a trial buffer per step.  It only ever runs where trials are paired, i.e. (unless
   // forced) for batches up to twice the resident waves: larger handles keep the three-buffer layout.
   const bool can_help = h->dynamic && h->sched_slots > 0 && h->help_mode != 0 &&
-                        (h->help_mode > 0 || cfg->max_batch <= 2 * h->sched_slots);
+                        (h->help_mode > 0 || (cfg->max_batch <= 2 * h->sched_slots && cfg->n_seg_max >= 80));
   bool fits = true;
   if (can_help && h->help_mode < 0) {  // the extra trial buffers must stay a small part of the device's memory
     size_t free_b = 0, total_b = 0;

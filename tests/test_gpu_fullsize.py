@@ -260,6 +260,24 @@ def test_shared_line_search_other_storage_types_and_chunk_sizes(built, dt, nb, n
     assert res["1"][1].iter_used.max() > 5
 
 
+@pytest.mark.parametrize("nb,kind,dt", [(1, "corridor", np.float32), (7, "free", np.float64), (300, "corridor", np.float32)])
+def test_small_batches_on_the_ticket_scheduler_match_the_static_launch(built, nb, kind, dt, monkeypatch):
+    """Below the resident waves the launch used to be one workgroup per trajectory; with the shared line search the
+    ticket scheduler serves these batches too and the waves left over help (single steps, one wave each, when the batch
+    is small).  Same bits as the static launch, natural exits, both phases."""
+    batch = problems.make_batch(kind, nb, N, seed=300 + nb)
+    res = {}
+    for mode in ("static", "dynamic"):
+        monkeypatch.setenv("DIRECT_DDP_SCHED", mode)
+        s = solver.DdpSolver(nb, N, batch.p_max, dt)
+        res[mode] = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=40), batch.astype(dt))
+        assert s.sched_error() == 0
+        s.close()
+    for a, b in zip(res["static"], res["dynamic"]):
+        for f in ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
 def test_output_sampling_of_the_full_batch(built, free_batch):
     """direct_traj_sample_batch on 4096 solved trajectories: size-independent properties of the samples
     (the oracle is checked on a random subset)."""
