@@ -295,13 +295,14 @@ struct HelpSlot {
   int pad[4];
   TrialRes res[12];
 };
-constexpr int kMaxBuf = 11;  // iterate buffers: `cur` + one per concurrently evaluated step (3 without helpers)
+constexpr int kMaxBuf = 12;  // iterate buffers: `cur` + one per concurrently evaluated step, 0 .. 10 (3 without helpers)
 
 // ---- device-resident batch (all pointers are device memory) -----------------------------------
 template <typename Real>
 struct Batch {
   int B, nmax, pmax, ncs;  // ncs = row stride of S/Y/KS/KY (>= 6*pmax+55)
-  int fcap, nbuf, pad1, pad2;  // nbuf: iterate buffers in use (3, or kMaxBuf with the shared line search)
+  int fcap, nbuf, help_early, pad2;  // nbuf: iterate buffers in use (3, or kMaxBuf with the shared line search);
+                                     // help_early: single-step searches are open to helpers from step 0 on
   const int32_t* n_seg;
   const Real* x0;
   const Real* xd;
@@ -1760,12 +1761,12 @@ struct Wave {
   DDP_DEV void proto_error() const { a_store(B.sched_err, 1); }
   // owner: open the line search around buffer `cur` to helpers.  Everything a helper reads (gains, the nominal
   // iterate, the row cache) was written by this wave before the release fence.
-  DDP_DEV void share_open(HelpSlot* hs, int cur, double mu, int tag, int last_round) {
+  DDP_DEV void share_open(HelpSlot* hs, int cur, double mu, int tag, int last_round, int first_round) {
     if (threadIdx.x == 0) {
       hs->cur = cur;
       hs->last_round = last_round;
       hs->mu = mu;
-      __hip_atomic_store(&hs->next_round, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hs->next_round, first_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&hs->cancel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1864,7 +1865,7 @@ struct Wave {
   }
   DDP_DEV HelpSlot* help_slot() const { return B.help ? &B.help[b] : nullptr; }
 #else  // the emulator runs one wave: nothing to share
-  DDP_DEV void share_open(HelpSlot*, int, double, int, int) {}
+  DDP_DEV void share_open(HelpSlot*, int, double, int, int, int) {}
   DDP_DEV void share_close(HelpSlot*) {}
   DDP_DEV int share_claim(HelpSlot*) { return 0; }
   DDP_DEV int share_cancelled(HelpSlot*) { return 0; }
@@ -2217,6 +2218,12 @@ struct Wave {
     A.stepsize = 0.0; A.cost = 0.0; A.costq = 0.0; A.logcost = 0.0; A.err = 0.0; A.sumlog = 0.0; A.errsum = 0.0;
     int r_eval = 0;  // owner: the first round whose results have not been judged yet
     int opened = 0;
+    if (share && !pair && B.k.pair_trials == 0 && B.help_early) {
+      // few trajectories on many waves: the search is open from step 0 on - the waves that would evaluate the later
+      // steps have nothing else to do, and when step 0 is rejected the answer of steps 1 .. 10 is already there
+      share_open(hs, cur, mu_d, tag, last_round, 0);
+      opened = 1;
+    }
 #pragma unroll 1
     while (true) {
       int mine = (helper || opened) ? share_claim(hs) : r_eval;
@@ -2253,7 +2260,7 @@ struct Wave {
       }
       if (A.accepted || broken || mine < 0 || r_eval > last_round) break;
       if (share && !opened) {
-        share_open(hs, cur, mu_d, tag, last_round);
+        share_open(hs, cur, mu_d, tag, last_round, r_eval);
         opened = 1;
       }
     }

@@ -416,6 +416,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       if (help) {
         (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
         Bt.help = h->help;
+        Bt.help_early = getenv("DIRECT_DDP_EARLY") ? atoi(getenv("DIRECT_DDP_EARLY")) : 1;
       }
       RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
     } else {

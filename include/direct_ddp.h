@@ -139,7 +139,7 @@ typedef struct {
  * DIRECT_DDP_PAIR=0|1 forces) and the shared line search, in which waves waiting for a trajectory evaluate later
  * steps of its line search (batches up to 1.5 x the resident waves and n_seg_max >= 80 - shorter trajectories do not
  * pay for the hand-over -, handles of at most 2 x; DIRECT_DDP_HELP=0|1 forces, read at create time: such a handle keeps
- * 11 iterate buffers instead of 3).  With the shared line search the ticket scheduler also serves batches below the
+ * 12 iterate buffers instead of 3).  With the shared line search the ticket scheduler also serves batches below the
  * resident waves, where the waves left over become helpers (single-trajectory latency: -20 %). */
 #define DIRECT_FLAG_STATIC_SCHEDULE 1
 
