@@ -288,6 +288,8 @@ struct direct_ddp_handle_s {
   void *X[direct::kMaxBuf] = {}, *S[direct::kMaxBuf] = {}, *Y[direct::kMaxBuf] = {};
   int nbuf = 3;              // iterate buffers allocated: 3, or kMaxBuf when the line search can be shared
   HelpSlot* help = nullptr;  // [max_batch], with nbuf == kMaxBuf
+  bool small_dyn = true;     // with helpers the ticket scheduler also serves batches below the resident waves (DIRECT_DDP_SMALL=0: static launch there)
+  int help_early = 1;        // single-step shared searches are open from step 0 on (DIRECT_DDP_EARLY=0: after step 0 failed)
   int single_ratio = 8;      // shared line search in single steps when batch * ratio <= resident waves (DIRECT_DDP_SINGLE)
   int help_mode = -1;        // shared line search: -1 auto (batches up to 1.5 x the resident waves), DIRECT_DDP_HELP=0|1 forces
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
@@ -403,8 +405,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     // The static launch is tail-free when every trajectory is resident at once - but then the waves that are left
     // over have nothing to do, while the ticket scheduler turns them into helpers: with help it is used for small
     // batches too (DIRECT_DDP_SMALL=0: not below the resident waves).
-    static const bool small_dyn = getenv("DIRECT_DDP_SMALL") ? atoi(getenv("DIRECT_DDP_SMALL")) != 0 : true;
-    if (h->dynamic && h->sched_slots > 0 && (h->B > h->sched_slots || (help && small_dyn))) {
+    if (h->dynamic && h->sched_slots > 0 && (h->B > h->sched_slots || (help && h->small_dyn))) {
       Sched S;
       S.ticket = (unsigned*)h->sched;
       S.err = h->sched + 1;
@@ -416,7 +417,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       if (help) {
         (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
         Bt.help = h->help;
-        Bt.help_early = getenv("DIRECT_DDP_EARLY") ? atoi(getenv("DIRECT_DDP_EARLY")) : 1;
+        Bt.help_early = h->help_early;
       }
       RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
     } else {
@@ -569,6 +570,8 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
                                             : resident_slots<float>(h, prop.multiProcessorCount);
   if (const char* ev = getenv("DIRECT_DDP_HELP")) h->help_mode = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_SINGLE")) h->single_ratio = atoi(ev) > 0 ? atoi(ev) : (1 << 30);
+  if (const char* ev = getenv("DIRECT_DDP_SMALL")) h->small_dyn = atoi(ev) != 0;
+  if (const char* ev = getenv("DIRECT_DDP_EARLY")) h->help_early = atoi(ev);
   // The shared line search needs a trial buffer per step.  It only ever runs where trials are paired, i.e. (unless
   // forced) for batches up to twice the resident waves: larger handles keep the three-buffer layout.
   const bool can_help = h->dynamic && h->sched_slots > 0 && h->help_mode != 0 &&
