@@ -64,6 +64,7 @@ struct QBatch {
   St* U[2];      // [B][N][4]
   St* K;         // [B][N][4][12]
   St* kf;        // [B][N][4]
+  double* Tg[2]; // [B][N][8]: sin / cos of the Euler angles and 1 / cos(theta) of X[.][k], written by whoever rolled the knot
   QState* st;
   QConst c;
 };
@@ -216,6 +217,7 @@ __device__ void q_begin(const QBatch<St>& Q, QLds& L, int b, int lane) {
     QSYNC();
     trig_lanes(L.xn, L.trig, lane);
     QSYNC();
+    if (lane < 7) Q.Tg[0][((size_t)b * N + k) * 8 + lane] = L.trig[lane];
     cost += roll_knot(Q.c, L, xg, lane);
     if (lane < NX) X[(size_t)k * NX + lane] = (St)L.xn[lane];
     if (lane < NU) U[(size_t)k * NU + lane] = (St)L.un[lane];
@@ -264,12 +266,15 @@ __device__ int q_backward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
   const St* src = lxu < NX ? X + lxu : U + (lxu - NX);
   const int stride = lxu < NX ? NX : NU;
   St pre = src[(size_t)(N - 1) * stride];
+  // sin / cos of x_k's Euler angles were computed when the knot was rolled (same stored x_k, same function: same bits)
+  const double* tsrc = Q.Tg[cur] + (size_t)b * N * 8 + (lane < 7 ? lane : 6);
+  double tpre = tsrc[(size_t)(N - 1) * 8];
   for (int k = N - 1; k >= 0; k--) {
     if (lane < NX) L.xk[lane] = (double)pre;
     else if (lane < NX + NU) L.uk[lane - NX] = (double)pre;
+    if (lane < 7) L.trig[lane] = tpre;
     pre = src[(size_t)(k > 0 ? k - 1 : 0) * stride];
-    QSYNC();
-    trig_lanes(L.xk, L.trig, lane);
+    tpre = tsrc[(size_t)(k > 0 ? k - 1 : 0) * 8];
     QSYNC();
     if (lane < 39) L.S[lane] = special_entry(c, L.xk, L.uk, L.trig, lane);
     QSYNC();
@@ -464,6 +469,7 @@ __device__ void q_forward(const QBatch<St>& Q, QLds& L, int b, int lane, const d
       }
       QSYNC();
       cost += roll_knot(c, L, xg, lane);
+      if (lane < 7) Q.Tg[nxt][((size_t)b * N + k) * 8 + lane] = L.trig[lane];
       if (lane < NX) Xt[(size_t)k * NX + lane] = (St)L.xn[lane];
       if (lane < NU) Ut[(size_t)k * NU + lane] = (St)L.un[lane];
       QSYNC();
@@ -558,7 +564,7 @@ struct direct_quad_handle_s {
   int dtype = 0, device = 0, max_batch = 0, N = 0, B = 0;
   size_t rsz = 4;
   bool begun = false, timed = false;
-  void *x0 = nullptr, *xg = nullptr, *X[2] = {nullptr, nullptr}, *U[2] = {nullptr, nullptr}, *K = nullptr, *kf = nullptr;
+  void *x0 = nullptr, *xg = nullptr, *X[2] = {nullptr, nullptr}, *U[2] = {nullptr, nullptr}, *K = nullptr, *kf = nullptr, *Tg[2] = {nullptr, nullptr};
   void *o_cost = nullptr, *o_x = nullptr, *o_u = nullptr;
   int32_t* o_iters = nullptr;
   QState* st = nullptr;
@@ -573,7 +579,7 @@ template <typename St>
 QBatch<St> make_q(direct_quad_handle_t h) {
   QBatch<St> Q;
   Q.B = h->B; Q.N = h->N; Q.x0 = (const St*)h->x0; Q.xg = (const St*)h->xg;
-  for (int i = 0; i < 2; i++) { Q.X[i] = (St*)h->X[i]; Q.U[i] = (St*)h->U[i]; }
+  for (int i = 0; i < 2; i++) { Q.X[i] = (St*)h->X[i]; Q.U[i] = (St*)h->U[i]; Q.Tg[i] = (double*)h->Tg[i]; }
   Q.K = (St*)h->K; Q.kf = (St*)h->kf; Q.st = h->st; Q.c = h->c;
   return Q;
 }
@@ -635,7 +641,7 @@ direct_status_t direct_quad_create(int32_t dtype, int32_t device, int32_t max_ba
     h->allocs.push_back(*pp);
   };
   A(&h->x0, B * NX * r); A(&h->xg, B * NX * r);
-  for (int i = 0; i < 2; i++) { A(&h->X[i], B * (N + 1) * NX * r); A(&h->U[i], B * N * NU * r); }
+  for (int i = 0; i < 2; i++) { A(&h->X[i], B * (N + 1) * NX * r); A(&h->U[i], B * N * NU * r); A(&h->Tg[i], B * N * 8 * sizeof(double)); }
   A(&h->K, B * N * 48 * r); A(&h->kf, B * N * NU * r); A((void**)&h->st, B * sizeof(QState));
   A(&h->o_cost, B * r); A((void**)&h->o_iters, B * 4); A(&h->o_x, B * (N + 1) * NX * r); A(&h->o_u, B * N * NU * r);
   if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
