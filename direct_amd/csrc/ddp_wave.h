@@ -1764,7 +1764,7 @@ struct Wave {
   DDP_DEV void share_open(HelpSlot* hs, int cur, double mu, int tag, int last_round, int first_round) {
     if (threadIdx.x == 0) {
       hs->cur = cur;
-      hs->last_round = last_round;
+      __hip_atomic_store(&hs->last_round, last_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // polled by next_work
       hs->mu = mu;
       __hip_atomic_store(&hs->next_round, first_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&hs->cancel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
