@@ -195,7 +195,7 @@ def test_ticket_scheduler_is_bitwise_equal_to_one_workgroup_per_trajectory(built
 
 
 def test_paired_line_search_trials_are_bitwise_equal_to_the_sequential_search(built, corridor_batch, monkeypatch):
-    """From the second attempt on two step sizes share a forward sweep (fwd_round<2>): each trial's arithmetic and the
+    """From the second attempt on two step sizes share a forward sweep (run_round<2>): each trial's arithmetic and the
     order of acceptance are those of the sequential search, so every output must be bit-identical - natural exits,
     both phases, 4096 polyhedron corridors (mean 2.4 trials per iteration, up to 11)."""
     res = {}
