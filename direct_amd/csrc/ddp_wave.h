@@ -597,6 +597,12 @@ struct Wave {
   // Nothing here may WAIT on a load it has just issued (no arithmetic on the loaded words, no
   // load-dependent branch): every access is an unconditional load from a clamped, always valid index
   // and the words stay raw until commit().
+  // Feasible mode: the backward sweep hands c and s / c of the iterate to the forward trials through the idle y / ky
+  // arrays (phase R1 writes them, every trial reads them instead of re-deriving them from the old control values).
+  // That trades HBM traffic (two words per row and direction) for VALU work: right for float storage, where the kernel
+  // is issue-bound; with double storage the large configurations are HBM-bound and the trials
+  // recompute, as the reference's forward pass does (DDP:696).
+  static constexpr bool kRowCache = sizeof(St) < sizeof(double);
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
     St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
@@ -620,10 +626,10 @@ struct Wave {
       const int r = (pkv[i] & 255) - 1;
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0; their results are masked
       p.s[i] = sk[rc];
-      if (infeas || fwd) p.y[i] = yk[rc];  // feasible forward pass: q = s / c of the old iterate (written by phase R1)
+      if (infeas || (fwd && kRowCache)) p.y[i] = yk[rc];  // feasible forward pass: q = s / c of the old iterate (written by phase R1)
       if (fwd) {
         p.ks[i] = ksk[rc];
-        p.ky[i] = kyk[rc];                 // feasible mode: c of the old iterate (written by phase R1)
+        if (infeas || kRowCache) p.ky[i] = kyk[rc];  // feasible mode: c of the old iterate (written by phase R1)
       }
     }
     if (fwd) {
@@ -911,6 +917,7 @@ struct Wave {
   // knots the last sweep never reached are then rebuilt here, from the iterate, as the reference's forward pass
   // recomputes them (DDP:696).  Off the hot path: it runs only on the way to rtn = -4.
   DDP_DEV void refresh_row_cache() {
+    if (!kRowCache) return;
     const int buf = st.cur;
     for (int k = 0; k < N; k++) {
       const int P = np_(k);
@@ -1271,8 +1278,10 @@ struct Wave {
             g = -mu * cinv;  // s - r/c
             LV(e_mu) = fmax(LV(e_mu), in ? fabs(rv) : (Real)0);
             if (in) {  // for the forward trials of this iteration (the y / ky arrays are free in feasible mode)
-              SpU(sp.Y[0], k)[r] = (St)D;
-              SpU(sp.KY, k)[r] = (St)c;
+              if (kRowCache) {
+                SpU(sp.Y[0], k)[r] = (St)D;
+                SpU(sp.KY, k)[r] = (St)c;
+              }
             }
           }
           // for phase R2: infeasible mode needs c and rhat; feasible mode only the two quotients r / c and s / c, so
@@ -2025,7 +2034,7 @@ struct Wave {
               const int l62 = lane < 63 ? lane : 62;
               const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
               const int crd = cr < 15 ? cr : 14;  // the d/dT table has no rows for the dynamics / cost (unused there)
-              Real dvo = 0, vn = 0, gf = 0;
+              Real dvo = 0, vn = 0, gf = 0, vo = 0;
               // Summed over the exponent j = i - o instead of the coefficient index i (same terms, same
               // order: the i < o terms have zero weight): the power T^j is then the same for every lane and
               // comes from a uniform register instead of three LDS table reads per term.
@@ -2049,6 +2058,7 @@ struct Wave {
                 for (int jj = 0; jj < 3; jj++) {
                   const int j = 3 * half + jj;
                   const Real w = wb6[jj] * pwo[j];
+                  if (!kRowCache) vo += w * zo6[jj];  // the old control values (every alive trial writes the same ones)
                   gf += w * dz6[jj];
                   dvo += wd6[jj] * pwo[j < 1 ? 0 : j - 1] * zo6[jj];
                   vn += wb6[jj] * pwn[t][j] * zn6[jj];
@@ -2056,12 +2066,14 @@ struct Wave {
               }
               const Real un = F.zn[9 + (lane < 54 ? 0 : l62 - 54)], dT = F.dz[18];
               if (lane < 45) F.G[lane] = gf + dvo * dT;
+              if (!kRowCache && lane < 45) L.val[lane] = vo;
               Real* dst = lane < 45 ? &F.valn[l62] : (lane < 54 ? &F.xnx[l62 - 45] : &F.qp[l62 - 54]);
               *dst = lane < 54 ? vn : vn * un;  // u_a[d] * (R u)_a[d]: the nine of them sum to u'Ru (DDP:1294-1305)
             }
             if (lane == 63) {
               F.valn[45] = F.zn[18];
               F.G[45] = F.dz[18];
+              if (!kRowCache) L.val[45] = L.z[18];
             }
           }
         }
@@ -2106,8 +2118,9 @@ struct Wave {
               } else {  // DDP:694-703
                 // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
                 // once (phase R1) instead of every trial re-deriving them from the old control values
-                const Real co = LV(rky)[i];
-                snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - LV(ry)[i] * az);
+                const Real co = kRowCache ? LV(rky)[i] : row_c(L.val, rk);
+                const Real q = kRowCache ? LV(ry)[i] : s * frcp(co);
+                snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - q * az);
                 LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
                 LV(plog)[t].mul(in ? -cn : (Real)1);
                 if (in) sn[r] = (St)snew;
