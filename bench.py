@@ -289,6 +289,8 @@ def main():
     if s.sched_error():
         raise SystemExit("the ticket scheduler reported an error: results are invalid")
     iters_step = int(outs["fwd_passes"].sum().item())
+    # the mode every trajectory's timed iterations ran in (taken now: the secondary solves reuse the output arrays)
+    infeas_mask = outs["infeas_out"].cpu().numpy().astype(bool)
     total = torch.tensor([float(iters_step)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
@@ -392,7 +394,9 @@ def main():
         label = label_model_line(torch, dev, B, not args.no_cpu_baseline and world == 1)
 
     if rank == 0:
-        words = problems.algorithmic_words(batch1.n_planes, batch1.n_seg, infeasible=False)
+        # a trajectory that is still infeasible after the fixed iterations has moved y / ky as well: 10 nc instead of
+        # 5 nc words per knot
+        words = problems.algorithmic_words(batch1.n_planes, batch1.n_seg, infeasible=infeas_mask)
         bytes_per_launch = words * np.dtype(np_dt).itemsize * FIXED_ITERS  # one launch = FIXED_ITERS iterations of B corridors
         avg_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -419,7 +423,8 @@ def main():
                          "traffic_source": None if traffic is None else traffic["_file"],
                          "peak_measured_copy": hbm_copy, "frac_of_measured_copy": None if not hbm_copy else achieved / hbm_copy,
                          "kernel": "k_iterate_dyn (ticket-scheduled k_iterate)", "kernel_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "infeasible_mode_frac": float(infeas_mask.mean())},
             "iters_per_step_rank0": iters_step, "gather": gather,
         }
         if sq is not None and "f64_flops_per_ddp_iteration" in sq["derived"] and "f64_arith_frac_of_valu" in sq["derived"]:

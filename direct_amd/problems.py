@@ -155,11 +155,13 @@ def make_config1(seed=1, n_seg=50, dtype=np.float64):
 
 def algorithmic_words(n_planes, n_seg, infeasible=False):
     """Algorithmic words moved per DDP iteration of a batch:
-    per knot 257 + 5 nc + 8 P (feasible) or 257 + 10 nc + 8 P (infeasible), nc = 6 P + 55."""
+    per knot 257 + 5 nc + 8 P (feasible) or 257 + 10 nc + 8 P (infeasible), nc = 6 P + 55.
+    `infeasible`: one flag for the batch or one per trajectory (the mode its iterations run in)."""
     n_planes = np.asarray(n_planes)
     k = np.arange(n_planes.shape[1])[None, :] < np.asarray(n_seg)[:, None]
     nc = 6 * n_planes + 55
-    w = 257 + (10 if infeasible else 5) * nc + 8 * n_planes
+    per_row = np.where(np.broadcast_to(np.asarray(infeasible, bool).reshape(-1, 1), n_planes.shape), 10, 5)
+    w = 257 + per_row * nc + 8 * n_planes
     return int(np.where(k, w, 0).sum())
 
 
