@@ -133,6 +133,7 @@ def label_model_line(torch, dev, B, with_cpu):
     x0, xg = quad.label_problems(B, seed=1000)
     p = quad.default_params(iter_max=iters, fixed_iters=1)
     q = quad.QuadSolver(B, N, np.float32, device=dev.index or 0)
+    q.set_stream(torch.cuda.current_stream().cuda_stream)
     tx0, txg = torch.from_numpy(x0.astype(np.float32)).to(dev), torch.from_numpy(xg.astype(np.float32)).to(dev)
     cost, it = torch.zeros(B, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
     ms = []

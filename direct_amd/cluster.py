@@ -16,7 +16,8 @@ class Config(C.Structure):
 
 
 EXPORTS = ("direct_cluster_create", "direct_cluster_destroy", "direct_cluster_last_error", "direct_cluster_set_map",
-           "direct_cluster_polygon_generation_batch", "direct_cluster_convex_test", "direct_cluster_last_ms")
+           "direct_cluster_polygon_generation_batch", "direct_cluster_convex_test", "direct_cluster_last_ms",
+           "direct_cluster_set_stream")
 CLUSTER_OK, CLUSTER_OVERFLOW, CLUSTER_BAD_SEED = 0, 1, 2
 _BOUND = False
 
@@ -34,6 +35,7 @@ def _lib():
         L.direct_cluster_convex_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
         L.direct_cluster_last_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_cluster_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         _BOUND = True
     return L
 
@@ -91,6 +93,9 @@ class ClusterGenerator:
         _check(_lib().direct_cluster_convex_test(self.h, inside.ctypes.data, n, cand.ctypes.data, cluster.shape[0],
                                                  cluster.ctypes.data, clu.ctypes.data, cc.ctypes.data, acc.ctypes.data))
         return clu, cc[:n * (n - 1) // 2], acc
+
+    def set_stream(self, hip_stream):
+        _check(_lib().direct_cluster_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def last_ms(self):
         ms = C.c_float()

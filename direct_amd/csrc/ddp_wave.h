@@ -55,6 +55,14 @@ inline T emu_uniform(T x, int line) {
 #define RDLANE(arr, idx, src) (arr[src][idx])
 #define RDLANE_M(var, member, src) (var[src].member)
 #define RDLANE_V(var, src) (var[src])
+// value of per-lane array entry arr[idx] on lane `src` of the CALLER'S ROW of 16 lanes / acc -= that value * mul
+#define ROW_BCAST(arr, idx, src) (arr[(lane & 48) + (src)][idx])
+#define ROW_FNMA(acc, arr, idx, src, mul) ((acc) -= arr[(lane & 48) + (src)][idx] * (mul))
+#define ROW_HAZARD(x) ((void)0)
+// a predicate accumulated over several LANES blocks of which only lane 0's value is wanted
+#define DDP_PRED_DECL(name) int name[64] = {0}
+#define DDP_PRED_OR(name, cond) (name[lane] |= (cond) ? 1 : 0)
+#define DDP_PRED_LANE0(name) (name[0])
 #define DDP_UNIFORM_I(x) direct::emu_uniform((x), __COUNTER__)
 #define DDP_UNIFORM_R(x) direct::emu_uniform((x), __COUNTER__)
 #define DDP_LAUNDER_S(x) ((void)0)
@@ -92,6 +100,19 @@ inline T emu_uniform(T x, int line) {
 #define RDLANE(arr, idx, src) direct::readlane_real(arr[idx], src)
 #define RDLANE_M(var, member, src) direct::readlane_real(var.member, src)
 #define RDLANE_V(var, src) direct::readlane_real(var, src)
+// Row broadcasts on the DP-ALU's DPP path (gfx90a+: 64-bit DPP supports row_newbcast only): lane `src` (a compile-time
+// constant, 0..15) of every row of 16 lanes is the operand of all 16 lanes of that row.  ROW_FNMA is ONE instruction,
+// v_fmac_f64_dpp: acc -= bcast(arr[idx]) * mul - against two v_readlane plus the FMA of the SGPR-broadcast form.
+// The hazard recognizer does not look into inline asm: a VGPR written by the VALU needs two wait states before a DPP
+// read (ROW_HAZARD pins the producer before the s_nop; the ROW_BCAST form carries its own).
+#define ROW_BCAST(arr, idx, src) direct::row_bcast<src>(arr[idx])
+#define ROW_FNMA(acc, arr, idx, src, mul) direct::row_fnma<src>(acc, arr[idx], mul)
+#define ROW_HAZARD(x) asm volatile("s_nop 1" : "+v"(x))
+// a predicate accumulated over several LANES blocks of which only lane 0's value is wanted: the compare's own lane
+// mask, OR-ed on the scalar unit (a per-lane flag costs a v_cndmask per update, or is merged into an fmin / fmax chain)
+#define DDP_PRED_DECL(name) unsigned long long name = 0ull
+#define DDP_PRED_OR(name, cond) (name |= __ballot(cond))
+#define DDP_PRED_LANE0(name) ((int)(name & 1ull))
 #define DDP_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
 // a wave-uniform real computed by the VALU (or read from LDS) moved to SGPRs: frees its VGPRs
 #define DDP_UNIFORM_R(x) direct::uniform_real(x)
@@ -125,6 +146,27 @@ inline T emu_uniform(T x, int line) {
 #endif
 
 namespace direct {
+
+// compile-time loop: f(IC<B>{}), f(IC<B+1>{}), ... - the DPP lane selectors must be constant expressions
+template <int I>
+struct IC {
+  static constexpr int v = I;
+  constexpr operator int() const { return I; }
+};
+template <int B, int E, typename F>
+DDP_DEV void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+template <int B, int E, typename F>
+DDP_DEV void static_for_down(F&& f) {  // B, B-1, ..., E
+  if constexpr (B >= E) {
+    f(IC<B>{});
+    static_for_down<B - 1, E>(f);
+  }
+}
 
 constexpr int kPLim = 32;  // DIRECT_P_LIMIT
 
@@ -170,6 +212,16 @@ __device__ __forceinline__ double readlane_real(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(SRC));
+  return r;
+}
+template <int SRC>
+__device__ __forceinline__ void row_fnma(double& acc, double a, double b) {
+  asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(SRC));
 }
 __device__ __forceinline__ float uniform_real(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -314,7 +366,7 @@ struct Batch {
   const Real* seeds;     // [B][nmax][3] Polytope.seed_coord (line-init only)
   const uint8_t* infeas_in;
   // Iterate buffers: `cur` and the trial buffers (step t of a line search writes buffer trial_buf(cur, t))
-  Real* X[kMaxBuf];   // [B][nmax+1][kXS]: x_k (9), u_k (10), position low words (3), pad
+  Real* X[kMaxBuf];   // [B][nmax+1][x_stride<Real>()]: x_k (9), u_k (10) (+ with float storage their 19 low words), pad
   Real* S[kMaxBuf];   // [B][nmax][ncs]
   Real* Y[kMaxBuf];   // [B][nmax][ncs]
   Real* KU;     // [B][nmax][100]: ku (10), Ku (10x9 row-major)
@@ -324,10 +376,18 @@ struct Batch {
   TrajState* st;
   HelpSlot* help;  // [B], or null: every line search stays with its owner
   int* sched_err;  // the launch's sticky error flag (spin limits of the shared line search)
+  unsigned long long* visits;  // [2] knots executed by backward sweeps / by forward trials (observability; may be null)
   SolveConst k;
 };
 
-constexpr int kXS = 24;  // knot record stride of X: x (9), u (10), low parts of the position (3), pad (2)
+constexpr int kXS = 24;  // LDS knot record: x (9), u (10), pad
+// Knot record stride of X in HBM.  With float storage EVERY entry of the iterate (x, u) is an unevaluated hi + lo float
+// pair (words a and 19 + a): the filter line search demands a STRICT decrease of a log-cost of ~2e6 that moves by 1e-10
+// per iteration near a stall, and on a single-float lattice (6e-8 relative) small steps are rounded away - float
+// storage then left the fp64 iterates at the stagnation exits of 11 % of BASELINE config 2's problems
+// (profiles/r03_n100_parity.json).  Gains, slacks and duals stay single floats: they shape the step, not the iterate.
+template <typename St>
+constexpr int x_stride() { return sizeof(St) < sizeof(double) ? 40 : 24; }
 typedef double Acc;      // accumulator type of the condensed system (see WaveLds)
 
 // state of one line-search trial of the forward pass (LDS)
@@ -522,7 +582,7 @@ struct Wave {
   DDP_DEV Wave(const Batch<St>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
 
   // Knot (b, k) of the [B][nmax(+1)] arrays; k may differ between lanes.
-  DDP_DEV St* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * kXS; }
+  DDP_DEV St* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * x_stride<St>(); }
   DDP_DEV St* Sp_(St* base, int k) const { return base + ((size_t)b * B.nmax + k) * B.ncs; }
   DDP_DEV const St* planes_(int k) const { return B.planes + ((size_t)b * B.nmax + k) * B.pmax * 4; }
   DDP_DEV int np_(int k) const { return B.n_planes[(size_t)b * B.nmax + k]; }
@@ -571,25 +631,29 @@ struct Wave {
   }
   DDP_DEV size_t rowU(int k) const { return (size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k); }
   // sel: 0 = the current iterate buffer, 1 / 2 = the trial buffers
-  DDP_DEV GSt* XpU(int sel, int k) const { return sp.X[sel] + (size_t)(unsigned)DDP_UNIFORM_I(b * (B.nmax + 1) + k) * kXS; }
+  DDP_DEV GSt* XpU(int sel, int k) const { return sp.X[sel] + (size_t)(unsigned)DDP_UNIFORM_I(b * (B.nmax + 1) + k) * x_stride<St>(); }
   DDP_DEV GSt* SpU(GSt* base, int k) const { return base + rowU(k) * B.ncs; }
   DDP_DEV GCSt* planesU(int k) const { return sp.planes + rowU(k) * (B.pmax * 4); }
   DDP_DEV int npU(int k) const { return sp.n_planes[rowU(k)]; }
   DDP_DEV GSt* KUpU(int k) const { return sp.KU + rowU(k) * 100; }
-  // Knot-record access.  Positions reach hundreds of metres while a barrier step must resolve
-  // ~1e-7 of the log-cost, so with float storage the three position words are kept as an unevaluated
-  // hi + lo pair (words a and 19 + a); every other entry is O(1) and a single word suffices.
+  // Knot-record access.  With float storage every entry is an unevaluated hi + lo pair (words a and 19 + a), see
+  // x_stride().  pair_round() is the value such a pair holds: what "rounded to the storage type" means for the iterate.
   template <typename Ptr>
   DDP_DEV Real ldx(Ptr rec, int a) const {
     Real v = (Real)rec[a];
-    if (sizeof(St) < sizeof(double) && a < 3) v += (Real)rec[19 + a];
+    if (sizeof(St) < sizeof(double)) v += (Real)rec[19 + a];
     return v;
   }
   template <typename Ptr>
   DDP_DEV void stx(Ptr rec, int a, Real v) const {
     const St hi = (St)v;
     rec[a] = hi;
-    if (sizeof(St) < sizeof(double) && a < 3) rec[19 + a] = (St)(v - (Real)hi);
+    if (sizeof(St) < sizeof(double)) rec[19 + a] = (St)(v - (Real)hi);
+  }
+  DDP_DEV Real pair_round(Real v) const {
+    if (sizeof(St) >= sizeof(double)) return v;
+    const St hi = (St)v;
+    return (Real)hi + (Real)(St)(v - (Real)hi);
   }
 
   // Software prefetch of the next knot's HBM data into registers: the serial knot recursion would
@@ -610,7 +674,7 @@ struct Wave {
     (void)buf;
     GCSt* rec = XpU(0, k);
     p.zh = rec[lane < 19 ? lane : 18];
-    p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 3 ? lane : 2)] : (St)0;  // see ldx()
+    p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 19 ? lane : 18)] : (St)0;  // see ldx()
     GCSt* pk = planesU(k);
     const int pend = 4 * P - 1;
     p.pl[0] = pk[lane < pend ? lane : pend];
@@ -640,7 +704,7 @@ struct Wave {
   }
   DDP_DEV void commit(const Pre& p, int lane, int P, bool fwd) {
     Real z = (Real)p.zh;
-    if (sizeof(St) < sizeof(double) && lane < 3) z += (Real)p.zl;
+    if (sizeof(St) < sizeof(double)) z += (Real)p.zl;
     if (lane < 19) L.z[lane] = z;
     if (lane < 4 * P) L.pl[lane] = (Real)p.pl[0];
     if (lane + 64 < 4 * P) L.pl[lane + 64] = (Real)p.pl[1];
@@ -841,6 +905,16 @@ struct Wave {
     return (double)acc;
   }
 
+  // observability (direct_ddp_last_launch_info): knots executed by a backward sweep (which = 0) / by the trials of a
+  // forward round (which = 1); one atomic per sweep
+  DDP_DEV void count_visits(int which, int n) const {
+#if !defined(DIRECT_EMULATE)
+    if (B.visits != nullptr && threadIdx.x == 0) atomicAdd(&B.visits[which], (unsigned long long)n);
+#else
+    (void)which; (void)n;
+#endif
+  }
+
   // ---- evaluation sweep over one iterate buffer: costs, log / error sums, violation count.
   // With do_roll it also propagates x (initialroll, DDP:1608-1620).
   DDP_DEV void eval_sweep(int buf, bool do_roll) {
@@ -1019,8 +1093,8 @@ struct Wave {
       }
       // the coefficients of the last trial stay, the duration is the (possibly doubled once more) Tk
       LANES {
-        if (lane >= 9 && lane < 18) Xp(0, l)[lane] = (St)L.z[lane];
-        if (lane == 18) Xp(0, l)[18] = (St)Tk;
+        if (lane >= 9 && lane < 18) stx(Xp(0, l), lane, L.z[lane]);
+        if (lane == 18) stx(Xp(0, l), 18, Tk);
       }
       WSYNC();
     }
@@ -1066,23 +1140,23 @@ struct Wave {
       if (lane < 9) stx(Xp(0, 0), lane, (Real)B.x0[(size_t)b * 9 + lane]);
       // u: zero init (DDP:126-127) or the tail of the Bezier->poly row (DDP:167-193)
       for (int k = lane; k < N; k += 64) {
-        St* u = Xp(0, k) + 9;
+        St* rec = Xp(0, k);
         Real T = T0[k];
         if (B.k.zero_init || (B.init_bez == nullptr && B.init_poly == nullptr)) {
-          for (int a = 0; a < 9; a++) u[a] = (St)0;
+          for (int a = 0; a < 9; a++) stx(rec, 9 + a, (Real)0);
         } else if (B.init_poly != nullptr) {  // extension: monomial warm start, u = [c3; c4; c5]
           const St* row = B.init_poly + ((size_t)b * B.nmax + k) * 18;
-          for (int a = 0; a < 9; a++) u[a] = row[9 + a];
+          for (int a = 0; a < 9; a++) stx(rec, 9 + a, (Real)row[9 + a]);
         } else {
           const St* row = B.init_bez + ((size_t)b * B.nmax + k) * 18;  // [x0..x5,y0..y5,z0..z5]
           for (int i = 3; i < 6; i++)
             for (int d = 0; d < 3; d++) {
               Real acc = 0;
               for (int l = 0; l < 6; l++) acc += (Real)kBez2Mono[l][i] * (T * (Real)row[d * 6 + l]);
-              u[(i - 3) * 3 + d] = (St)(acc / powi(T, i));
+              stx(rec, 9 + (i - 3) * 3 + d, acc / powi(T, i));
             }
         }
-        u[9] = (St)T;
+        stx(rec, 18, T);
       }
     }
     if (!B.k.zero_init && B.k.line_init) line_init();
@@ -1187,9 +1261,9 @@ struct Wave {
           LV(pkc)[i] = LV(pkn)[i];
         }
       }
-      // the segment time straight from lane 18's prefetch register (z[18], a single word: see ldx()):
+      // the segment time straight from lane 18's prefetch registers (hi + lo with float storage, see ldx()):
       // the T-dependent tables then need no LDS round trip and share this phase
-      const Real T = (Real)RDLANE_M(pre, zh, 18);
+      const Real T = (sizeof(St) < sizeof(double)) ? (Real)RDLANE_M(pre, zh, 18) + (Real)RDLANE_M(pre, zl, 18) : (Real)RDLANE_M(pre, zh, 18);
       if (k > 0) {
         Pn = DDP_UNIFORM_I(Pnn);
         Pnn = npU(k > 1 ? k - 2 : 0);
@@ -1506,16 +1580,23 @@ struct Wave {
       }
       WSYNC();
       DDP_MARK("B_C");
-      // ---- C: LLT of Huu + lam I and the 10 right-hand sides [Hu | Hux].  One column per lane in
-      // registers (lanes 0..9 the matrix, 10..19 the right-hand sides).  Every multiplier is broadcast
-      // with v_readlane (SGPR operands of the FMAs): the LDS pipe is the busiest unit of the sweep and a
-      // round trip per elimination step would also sit on the serial dependency chain.
+      // ---- C: LLT of Huu + lam I and the 10 right-hand sides [Hu | Hux], one column per lane in registers.
+      // Columns live in ROWS OF 16 LANES so that every multiplier is a DP-ALU DPP row broadcast folded into the FMA
+      // (ROW_FNMA: one v_fmac_f64_dpp instead of two v_readlane + FMA; no LDS round trip and no SGPR hop on the
+      // serial chain): row 0 = matrix columns 0..9 + right-hand sides 10..15, row 1 = a second copy of the matrix
+      // columns + right-hand sides 16..19; rows 2 and 3 repeat rows 0 and 1 (their results are never read).
       PLA(Acc, m, 10);
+      PLA(Acc, ls, 10);  // scaled entries: ls[k] of matrix lane j is L[j][k]; of a right-hand-side lane (L^-1 [Hu | Hux])[k][.]
+      PLA(Acc, xs, 10);  // back-substituted columns (right-hand-side lanes)
+      PLA(Acc, rd, 10);  // 1 / L_kk
+      PLV(int, colv);
+      DDP_PRED_DECL(bad);
       LANES {
-        // column `lane` of [Huu + lam I | Hu | Hux]; lanes >= 20 redo column 19 (their results are never read)
-        const int l19 = lane < 20 ? lane : 19;
-        const Acc* src = l19 < 10 ? &L.Huu[l19] : (l19 == 10 ? &L.Hz[9] : &L.Hxu[(l19 - 11) * 10]);
-        const int stride = l19 < 10 ? 10 : 1;
+        const int l5 = lane & 31;
+        const int col = l5 < 16 ? l5 : (l5 < 26 ? l5 - 16 : (l5 < 30 ? l5 - 10 : 19));
+        LV(colv) = col;
+        const Acc* src = col < 10 ? &L.Huu[col] : (col == 10 ? &L.Hz[9] : &L.Hxu[(col - 11) * 10]);
+        const int stride = col < 10 ? 10 : 1;
 #pragma unroll
         for (int a = 0; a < 10; a++) LV(m)[a] = src[a * stride];
         const Acc hu = L.Hz[9 + (lane < 10 ? lane : 9)];  // Hu = Hz[9..18], one entry per lane: max |Qu| for the optimality error
@@ -1523,77 +1604,56 @@ struct Wave {
         LV(e_qu) = fmax(LV(e_qu), fabs(hu));
         if (regi > 0) {  // lam = base^reg - 1 is exactly 0 at reg = 0 (the common case)
 #pragma unroll
-          for (int a = 0; a < 10; a++) LV(m)[a] += ((a == lane) ? lam : (Acc)0);
+          for (int a = 0; a < 10; a++) LV(m)[a] += ((a == col) ? lam : (Acc)0);
         }
       }
       // Elimination.  After row kk of a column has been scaled by 1/L_kk it IS the multiplier of that
       // column's index (Huu + lam I and its Schur complements are symmetric: M[i][kk] = M[kk][i]): the
       // multiplier of row i is lane i's scaled entry.  The scaled rows are also written to LDS, where
       // phase R2 reads [y | Y] = L^-1 [Hu | Hux] (columns 10..19).
-      int ok = 1;
-      Acc rdiag[10];
-#pragma unroll
-      for (int kk = 0; kk < 10; kk++) {
-        const Acc piv = RDLANE(m, kk, kk);
-        ok = (piv <= (Acc)0) ? 0 : ok;  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
-        const Acc rinv = frsq(piv);
-        rdiag[kk] = rinv;
+      static_for<0, 10>([&](auto KK) {
+        constexpr int kk = KK;
         LANES {
-          const Acc t = LV(m)[kk] * rinv;
-          LV(m)[kk] = t;
-          L.UY[kk * 20 + lane] = t;  // lanes >= 20 land in the padding / the next rows' not-yet-written slots
+          const Acc piv = ROW_BCAST(m, kk, kk);
+          DDP_PRED_OR(bad, piv <= (Acc)0);  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
+          const Acc rinv = frsq(piv);
+          LV(rd)[kk] = rinv;
+          LV(ls)[kk] = LV(m)[kk] * rinv;
+          ROW_HAZARD(LV(ls)[kk]);
+          L.UY[kk * 20 + LV(colv)] = LV(ls)[kk];
+          static_for<kk + 1, 10>([&](auto I) {
+            constexpr int i = I;
+            ROW_FNMA(LV(m)[i], ls, kk, i, LV(ls)[kk]);
+          });
         }
-        if (kk < 9) {
-          Acc lrow[10];
-#pragma unroll
-          for (int i = kk + 1; i < 10; i++) lrow[i] = RDLANE(m, kk, i);
-          LANES {
-            const Acc t = LV(m)[kk];
-#pragma unroll
-            for (int i = kk + 1; i < 10; i++) LV(m)[i] -= lrow[i] * t;
-          }
-        }
-      }
-      ok = DDP_UNIFORM_I(ok);
+      });
+      const int ok = DDP_PRED_LANE0(bad) ? 0 : 1;  // every row of lanes has seen the same ten pivots
       if (!ok) {  // DDP:546-551, 595-600
         st.bp_failed = 1;
         st.opterr = INFINITY;
+        count_visits(0, N - k);
         return 0;
       }
-      // back substitution L^T X = [y | Y] in the right-hand-side lanes.  The multipliers L[j][i] (j > i) are final
-      // once the elimination is done and sit in LDS as row i of UY: uniform-address (broadcast) reads that no
-      // step of the substitution has to wait for, instead of 90 v_readlane on the VALU.  Three batches of rows
-      // keep the operand registers bounded (6 + 15 + 24 multipliers).
-      {
-        static constexpr int kLo[3] = {6, 3, 0}, kHi[3] = {9, 5, 2};
-#pragma unroll
-        for (int bt = 0; bt < 3; bt++) {
-          Acc u[3][10];
-#pragma unroll
-          for (int i = kHi[bt]; i >= kLo[bt]; i--)
-#pragma unroll
-            for (int j = i + 1; j < 10; j++) u[i - kLo[bt]][j] = L.UY[i * 20 + j];
-          DDP_LOADS_ISSUED();
-#pragma unroll
-          for (int i = kHi[bt]; i >= kLo[bt]; i--) {
-            const Acc dinv = rdiag[i];
-            LANES {
-              Acc acc = LV(m)[i];
-#pragma unroll
-              for (int j = i + 1; j < 10; j++) acc -= u[i - kLo[bt]][j] * LV(m)[j];
-              LV(m)[i] = acc * dinv;
-              DDP_PIN(LV(m)[i]);
-            }
-          }
+      // back substitution L^T X = [y | Y] in the right-hand-side lanes: L[j][i] (j > i) is entry i of matrix lane j,
+      // again a row broadcast folded into the FMA; same order of operations as the sequential form
+      static_for_down<9, 0>([&](auto II) {
+        constexpr int i = II;
+        LANES {
+          Acc acc = LV(ls)[i];
+          static_for<i + 1, 10>([&](auto J) {
+            constexpr int j = J;
+            ROW_FNMA(acc, ls, i, j, LV(xs)[j]);
+          });
+          LV(xs)[i] = acc * LV(rd)[i];
         }
-      }
+      });
       LANES {
-        if (lane >= 10 && lane < 20) {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
-          const int col = lane - 10;
+        if (LV(colv) >= 10) {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
+          const int c = LV(colv) - 10;
 #pragma unroll
           for (int a = 0; a < 10; a++) {
-            const int idx = (col == 0) ? a : 10 + a * 9 + (col - 1);
-            L.KU[idx] = -LV(m)[a];
+            const int idx = (c == 0) ? a : 10 + a * 9 + (c - 1);
+            L.KU[idx] = -LV(xs)[a];
           }
         }
       }
@@ -1693,6 +1753,7 @@ struct Wave {
       WSYNC();
     }
     DDP_MARK("B_END");
+    count_visits(0, N);
     const double mu_err = WAVE_MAX_D(e_mu);
     const double qu_err = WAVE_MAX_D(e_qu);
     st.bp_failed = 0;
@@ -1924,6 +1985,7 @@ struct Wave {
     WSYNC();
     int Pn = DDP_UNIFORM_I(npU(0));
     int Pnn = npU(N > 1 ? 1 : 0);
+    int n_visits = 0;  // trial-knots this round executes (observability)
     PLV(Pre, pre);
     PLA(int, pkn, RPL);
     PLA(int, pkc, RPL);
@@ -1944,6 +2006,8 @@ struct Wave {
         cancel_v = __hip_atomic_load(&hs->cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #endif
+#pragma unroll
+      for (int t = 0; t < NT; t++) n_visits += tr[t].alive;
       PLA(Real, rs, RPL);
       PLA(Real, ry, RPL);
       PLA(Real, rks, RPL);
@@ -1959,7 +2023,7 @@ struct Wave {
         }
       }
       // the old T straight from lane 18's prefetch register (no LDS round trip)
-      const Real To = (Real)RDLANE_M(pre, zh, 18);
+      const Real To = (sizeof(St) < sizeof(double)) ? (Real)RDLANE_M(pre, zh, 18) + (Real)RDLANE_M(pre, zl, 18) : (Real)RDLANE_M(pre, zh, 18);
       if (k + 1 < N) {
         Pn = DDP_UNIFORM_I(Pnn);
         Pnn = npU(k + 2 < N ? k + 2 : k + 1);
@@ -2009,7 +2073,7 @@ struct Wave {
               F.dz[lane] = acc;
               // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
               // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
-              const Real un = (Real)(St)(zl + alpha[t] * kf + acc);
+              const Real un = pair_round(zl + alpha[t] * kf + acc);
               F.zn[lane] = un;
               LV(unew) = un;
             }
@@ -2150,6 +2214,7 @@ struct Wave {
       if (!any_alive) break;
     }
     DDP_MARK("F_END");
+    count_visits(1, n_visits);
     // totals of the trials that survived every knot (DDP:716-732)
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -2501,7 +2566,7 @@ DDP_DEV void get_field_wave(Wave<Real, St, RPL>& W, int field, St* dst) {
     const int P = W.np_(k), nc = 6 * P + 55;
     size_t rowbase = ((size_t)b * B.nmax + k) * ncm;
     if (field == 1) {
-      LANES { if (lane < 10) dst[((size_t)b * B.nmax + k) * 10 + lane] = W.Xp(buf, k)[9 + lane]; }
+      LANES { if (lane < 10) dst[((size_t)b * B.nmax + k) * 10 + lane] = (St)W.ldx(W.Xp(buf, k), 9 + lane); }
     } else if (field == 5) {
       LANES { if (lane < 10) dst[((size_t)b * B.nmax + k) * 10 + lane] = W.KUp(k)[lane]; }
     } else if (field == 6) {
@@ -2549,7 +2614,7 @@ DDP_DEV void set_field_wave(Wave<Real, St, RPL>& W, int field, const St* src) {
     const int nc = 6 * W.np_(k) + 55;
     size_t rowbase = ((size_t)b * B.nmax + k) * ncm;
     if (field == 1) {
-      LANES { if (lane < 10) W.Xp(buf, k)[9 + lane] = src[((size_t)b * B.nmax + k) * 10 + lane]; }
+      LANES { if (lane < 10) W.stx(W.Xp(buf, k), 9 + lane, (Real)src[((size_t)b * B.nmax + k) * 10 + lane]); }
     } else if (field == 2 || field == 3) {
       St* d = (field == 2) ? W.Sp_(B.S[buf], k) : W.Sp_(B.Y[buf], k);
       LANES { for (int r = lane; r < nc; r += 64) d[r] = src[rowbase + r]; }

@@ -617,6 +617,12 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
   return DIRECT_OK;
 }
 
+direct_status_t direct_cluster_set_stream(direct_cluster_handle_t h, void* hip_stream) {
+  if (!h) return DIRECT_ERR_INVALID;
+  h->stream = (hipStream_t)hip_stream;  // every copy, launch and event of the handle is enqueued on it from now on
+  return DIRECT_OK;
+}
+
 direct_status_t direct_cluster_last_ms(direct_cluster_handle_t h, float* ms) {
   if (!h || !ms) return cfail(DIRECT_ERR_INVALID, "null argument");
   if (!h->timed) return cfail(DIRECT_ERR_INVALID, "nothing has been timed yet");

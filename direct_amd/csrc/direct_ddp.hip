@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
     if (t == -1) break;
     if (t == -2) continue;
     if (t <= -3) {  // timed out: retire the trajectory so that its later tickets are skipped at once
-      if (threadIdx.x == 0) __hip_atomic_store(&S.done_epoch[-3 - t], kDoneBit | (int)n_epochs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_fetch_max(&S.done_epoch[-3 - t], kDoneBit | (int)n_epochs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
     const int e = __builtin_amdgcn_readfirstlane((int)((unsigned)t / nb));
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
       if (run) W.store_state();
       const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (threadIdx.x == 0) __hip_atomic_store(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // max, not store: done_epoch only ever grows, and a trajectory that a timed-out waiter has retired
+      // (kDoneBit | n_epochs, below) stays retired when its straggling chunk completes afterwards
+      if (threadIdx.x == 0) __hip_atomic_fetch_max(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -186,8 +188,16 @@ __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
   W.load_state();
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
-  if (mode == 1) W.bwd_sweep();
-  else W.fwd_pass();
+  if (mode == 1) {
+    W.bwd_sweep();
+  } else {
+    // The trials read c and s / c of the nominal iterate from the row cache, which only a COMPLETED backward sweep
+    // fills (ddp_wave.h, refresh_row_cache): after a backward pass that gave up part-way the rows of the knots it
+    // never reached are rebuilt from the iterate, as iterate_once() does and as the reference's forwardpass
+    // recomputes them (ddp_optimizer.cpp:696).  direct_ddp_set_field refreshes the cache itself.
+    if (__builtin_amdgcn_readfirstlane(lds.st.bp_failed) && !__builtin_amdgcn_readfirstlane(lds.st.infeas)) W.refresh_row_cache();
+    W.fwd_pass();
+  }
   W.store_state();
 }
 
@@ -208,8 +218,17 @@ __global__ __launch_bounds__(64) void k_field(Batch<St> B, int field, St* buf, i
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
   W.init_tables();
-  if (set) set_field_wave(W, field, (const St*)buf);
-  else get_field_wave(W, field, buf);
+  if (set) {
+    set_field_wave(W, field, (const St*)buf);
+    // an overwritten iterate invalidates the row cache of the feasible-mode forward trials (c, s / c of the iterate)
+    if (field <= 2 && !__builtin_amdgcn_readfirstlane(lds.st.infeas)) {
+      __threadfence();  // the refresh reads the new iterate on other lanes than the ones that stored it
+      __syncthreads();
+      W.refresh_row_cache();
+    }
+  } else {
+    get_field_wave(W, field, buf);
+  }
 }
 
 // UpdateTime + warm start between the two phases (teach_repeat_planner.cpp:911-918), on device
@@ -310,6 +329,8 @@ struct direct_ddp_handle_s {
   int g_ranks = 0;
   // dynamic scheduling of k_iterate_dyn: [0] ticket, [1] error flag, [2..] done_epoch[max_batch]
   int* sched = nullptr;
+  unsigned long long* visits = nullptr;  // [2] sweep-work counters of the last hot-kernel launch (direct_ddp_last_launch_info)
+  direct_ddp_launch_info_t last_info = {};
   int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device
   int sched_chunk = 1;   // outer-loop trips per ticket (DIRECT_DDP_CHUNK at create time; experiments)
   int pair_trials = -1;  // two line-search steps per forward sweep from the second attempt on: -1 auto, DIRECT_DDP_PAIR=0|1 forces
@@ -354,6 +375,7 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   B.nbuf = h->nbuf;
   B.help = nullptr;  // set by the dynamic launch only
   B.sched_err = h->sched + 1;
+  B.visits = nullptr;  // set by launch_iterate_t (the hot-kernel launch only)
   B.KU = (Real*)h->KU; B.KS = (Real*)h->KS; B.KY = (Real*)h->KY; B.filt = h->filt; B.st = h->st;
   SolveConst& k = B.k;
   k.max_vel = p.max_vel; k.max_acc = p.max_acc; k.w_snap = p.w_snap; k.w_term = p.w_terminal;
@@ -367,7 +389,7 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   // waves: +4 % at B = 4096) and cost ~1 % where it is throughput-bound; results are identical either way
   k.pair_trials = h->pair_trials >= 0 ? h->pair_trials : ((h->sched_slots > 0 && in.batch <= 2 * h->sched_slots) ? 1 : 0);
   // few trajectories on many waves and a shared line search: single steps, one wave each, beat pairs
-  if (h->pair_trials < 0 && h->help && h->help_mode != 0 && h->dynamic && h->nmax >= 80 && in.batch * h->single_ratio <= h->sched_slots)
+  if (h->pair_trials < 0 && h->help && h->help_mode != 0 && h->dynamic && h->nmax >= 80 && (long long)in.batch * h->single_ratio <= (long long)h->sched_slots)
     k.pair_trials = 0;
   return B;
 }
@@ -396,6 +418,11 @@ static int resident_slots(direct_ddp_handle_t h, int n_cu) {
 template <typename Real>
 static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
   auto Bt = make_batch<Real>(h, h->cur_in, h->params);
+  Bt.visits = h->visits;
+  (void)hipMemsetAsync(h->visits, 0, 2 * sizeof(unsigned long long), h->stream);
+  direct_ddp_launch_info_t& li = h->last_info;
+  li = direct_ddp_launch_info_t{};
+  li.pair_trials = Bt.k.pair_trials; li.n_buffers = h->nbuf; li.batch = h->B;
   if (mode == 0) {
     // shared line search: where the launch is bound by its slowest chain and a round is long enough to pay for the
     // protocol's fences (agent-scope release = L2 write-back).  Measured at N = 100: +5 .. +13 % for batches up to 4/3 of
@@ -418,9 +445,14 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
         (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
         Bt.help = h->help;
         Bt.help_early = h->help_early;
+        li.shared_search = 1;
+        li.single_steps = Bt.k.pair_trials ? 0 : 1;
       }
+      li.dynamic = 1;
+      li.resident_waves = h->sched_slots;
       RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
     } else {
+      li.resident_waves = h->sched_slots;
       RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n);
     }
   } else {
@@ -558,6 +590,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   h->rpl = (ncm + 63) / 64;
   h->fcap = 0;
   const size_t B = cfg->max_batch, nm = cfg->n_seg_max, r = h->rsz;
+  const size_t xs = cfg->dtype == DIRECT_F64 ? x_stride<double>() : x_stride<float>();  // knot record of the iterate
   direct_status_t st = DIRECT_OK;
   auto A = [&](auto pp, size_t bytes) { if (st == DIRECT_OK) st = dalloc(h, pp, bytes); };
   A(&h->x0, B * 9 * r); A(&h->xd, B * 9 * r); A(&h->T0, B * nm * r); A(&h->T_next, B * nm * r);
@@ -579,12 +612,12 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   bool fits = true;
   if (can_help && h->help_mode < 0) {  // the extra trial buffers must stay a small part of the device's memory
     size_t free_b = 0, total_b = 0;
-    const size_t extra = (size_t)(kMaxBuf - 3) * (B * (nm + 1) * kXS * r + 2 * B * nm * h->ncs * r);
+    const size_t extra = (size_t)(kMaxBuf - 3) * (B * (nm + 1) * xs * r + 2 * B * nm * h->ncs * r);
     fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && extra <= free_b / 8;
   }
   h->nbuf = (can_help && fits) ? kMaxBuf : 3;
   for (int i = 0; i < h->nbuf; i++) {
-    A(&h->X[i], B * (nm + 1) * kXS * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
+    A(&h->X[i], B * (nm + 1) * xs * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
   }
   if (h->nbuf == kMaxBuf) A(&h->help, B * sizeof(HelpSlot));
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
@@ -596,6 +629,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
   A(&h->best_idx, 16); A(&h->best_cost, 16);
   A(&h->sched, (B + 2) * sizeof(int));
+  A(&h->visits, 2 * sizeof(unsigned long long));
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
   if (const char* ev = getenv("DIRECT_DDP_PRIO")) h->sched_prio = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_PAIR")) h->pair_trials = atoi(ev);
@@ -891,6 +925,19 @@ direct_status_t direct_ddp_last_kernel_ms(direct_ddp_handle_t h, double* ms, int
   HIP_TRY(hipEventElapsedTime(&t, h->ev0, h->ev1));
   *ms = (double)t;
   if (n_launches) *n_launches = h->n_launches;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_ddp_last_launch_info(direct_ddp_handle_t h, direct_ddp_launch_info_t* info) {
+  if (!h || !info) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->timed) return fail(DIRECT_ERR_INVALID, "no hot-kernel launch yet");
+  HIP_TRY(hipSetDevice(h->device));
+  unsigned long long v[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(v, h->visits, sizeof v, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *info = h->last_info;
+  info->bwd_knot_visits = v[0];
+  info->fwd_knot_visits = v[1];
   return DIRECT_OK;
 }
 

@@ -747,6 +747,12 @@ direct_status_t direct_quad_get(direct_quad_handle_t h, void* x, void* u, void* 
   return DIRECT_OK;
 }
 
+direct_status_t direct_quad_set_stream(direct_quad_handle_t h, void* hip_stream) {
+  if (!h) return DIRECT_ERR_INVALID;
+  h->stream = (hipStream_t)hip_stream;  // every copy, launch and event of the handle is enqueued on it from now on
+  return DIRECT_OK;
+}
+
 direct_status_t direct_quad_last_kernel_ms(direct_quad_handle_t h, double* ms) {
   if (!h || !ms) return qfail(DIRECT_ERR_INVALID, "null argument");
   if (!h->timed) return qfail(DIRECT_ERR_INVALID, "nothing has been timed yet");

@@ -7,7 +7,8 @@ import numpy as np
 from . import abi, solver
 
 EXPORTS = ("direct_quad_default_params", "direct_quad_create", "direct_quad_destroy", "direct_quad_last_error",
-           "direct_quad_solve_batch", "direct_quad_begin", "direct_quad_iterate", "direct_quad_get", "direct_quad_last_kernel_ms")
+           "direct_quad_solve_batch", "direct_quad_begin", "direct_quad_iterate", "direct_quad_get", "direct_quad_last_kernel_ms",
+           "direct_quad_set_stream")
 SCALARS = ("cost", "reg", "step", "fp_failed", "bp_failed", "iter", "done", "fwd_passes")
 ALGORITHMIC_WORDS_PER_KNOT_ITER = 3 * 12 + 5 * 4 + 2 * 4 * 12   # 152
 
@@ -37,6 +38,7 @@ def _lib():
         L.direct_quad_iterate.argtypes = [C.c_void_p, C.c_int32]
         L.direct_quad_get.argtypes = [C.c_void_p] * 6
         L.direct_quad_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_quad_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         _BOUND = True
     return L
 
@@ -108,6 +110,9 @@ class QuadSolver:
         x0, xg = np.ascontiguousarray(x0, self.np_dtype), np.ascontiguousarray(xg, self.np_dtype)
         self.B = x0.shape[0]
         _check(_lib().direct_quad_begin(self.h, C.addressof(params), self.B, abi.MEM_HOST, x0.ctypes.data, xg.ctypes.data))
+
+    def set_stream(self, hip_stream):
+        _check(_lib().direct_quad_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def iterate(self, n=1):
         _check(_lib().direct_quad_iterate(self.h, int(n)))

@@ -26,6 +26,7 @@ EXPORTS = (
     "direct_ddp_best_cost", "direct_ddp_sched_error", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
     "direct_rccl_unique_id", "direct_rccl_comm_create", "direct_rccl_comm_destroy", "direct_ddp_gather_best",
     "direct_corridor_wire_size", "direct_corridor_pack", "direct_corridor_unpack", "direct_corridor_replay_batch",
+    "direct_ddp_last_launch_info",
 )
 
 
@@ -62,6 +63,7 @@ def lib():
         L.direct_ddp_best_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p]
         L.direct_ddp_sched_error.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_ddp_last_launch_info.argtypes = [C.c_void_p, C.c_void_p]
         L.direct_rccl_unique_id.argtypes = [C.c_void_p]
         L.direct_rccl_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.direct_rccl_comm_destroy.argtypes = [C.c_void_p]
@@ -278,6 +280,12 @@ class DdpSolver:
                                             C.c_void_p(bez), C.c_void_p(T), int(batch), int(first_index), C.addressof(idx),
                                             C.addressof(val), C.addressof(owner), C.c_void_p(out_bez), C.c_void_p(out_T)))
         return idx.value, val.value, owner.value
+
+    def launch_info(self):
+        """direct_ddp_last_launch_info as a dict: how the last hot-kernel launch was scheduled + knot visits executed."""
+        li = abi.LaunchInfo()
+        _check(lib().direct_ddp_last_launch_info(self.h, C.addressof(li)))
+        return {n: int(getattr(li, n)) for n, _ in abi.LaunchInfo._fields_ if n != "reserved"}
 
     def sched_error(self):
         """Synchronise and read the sticky scheduler-error flag (include/direct_ddp.h)."""

@@ -78,6 +78,9 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
                                            uint8_t* can_clu, uint8_t* can_can, uint8_t* accept);
 
 /* HIP-event time [ms] of the kernels of the last polygon_generation_batch / convex_test call */
+/* The HIP stream (hipStream_t) the handle enqueues its copies, kernels and timing events on; NULL (the default) is
+ * the legacy default stream.  Mirrors direct_ddp_set_stream. */
+direct_status_t direct_cluster_set_stream(direct_cluster_handle_t h, void* hip_stream);
 direct_status_t direct_cluster_last_ms(direct_cluster_handle_t h, float* ms);
 
 #ifdef __cplusplus

@@ -295,6 +295,23 @@ direct_status_t direct_ddp_set_field(direct_ddp_handle_t h, int32_t field, const
  * stream (milliseconds); *n_launches receives how many kernel launches that covered. */
 direct_status_t direct_ddp_last_kernel_ms(direct_ddp_handle_t h, double* ms, int32_t* n_launches);
 
+/* How the last direct_ddp_iterate / solve / plan launch of the hot kernel was scheduled, and how much sweep work it
+ * executed (observability only - no reference counterpart; results never depend on any of it).  Blocks until the
+ * launch has finished. */
+typedef struct {
+  int32_t dynamic;        /* 1: ticket-scheduled persistent waves (k_iterate_dyn); 0: one workgroup per trajectory */
+  int32_t shared_search;  /* 1: waiting waves evaluate later step sizes of the trajectory they wait for */
+  int32_t pair_trials;    /* 1: two line-search steps per forward sweep from the second attempt on */
+  int32_t single_steps;   /* 1: shared searches hand out single steps (few trajectories on many waves) */
+  int32_t n_buffers;      /* iterate buffers allocated per array (3, or 12 with the shared line search) */
+  int32_t resident_waves; /* persistent waves launched / one-wave workgroups resident at once on this device */
+  int32_t batch, reserved;
+  uint64_t bwd_knot_visits; /* backward-sweep knots executed by the launch (all trajectories, retries included) */
+  uint64_t fwd_knot_visits; /* forward trial-knots executed (every trial of every line search, helpers' included;
+                               a trial cut short by the fraction-to-boundary rule counts the knots it reached) */
+} direct_ddp_launch_info_t;
+direct_status_t direct_ddp_last_launch_info(direct_ddp_handle_t h, direct_ddp_launch_info_t* info);
+
 /* Config-5 reduction: index and value of the smallest cost among problems with rtn >= 0.
  * cost/rtn are device or host arrays per `mem`; the result is written to host. */
 direct_status_t direct_ddp_best_cost(direct_ddp_handle_t h, int32_t mem, const void* cost,

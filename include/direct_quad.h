@@ -67,6 +67,9 @@ direct_status_t direct_quad_begin(direct_quad_handle_t h, const direct_quad_para
                                   const void* x0, const void* xg);
 direct_status_t direct_quad_iterate(direct_quad_handle_t h, int32_t n_iters);
 direct_status_t direct_quad_get(direct_quad_handle_t h, void* x, void* u, void* K, void* kf, double* scalars);
+/* The HIP stream (hipStream_t) the handle enqueues its copies, kernels and timing events on; NULL (the default) is
+ * the legacy default stream.  Mirrors direct_ddp_set_stream: device-memory arguments are ordered on this stream. */
+direct_status_t direct_quad_set_stream(direct_quad_handle_t h, void* hip_stream);
 direct_status_t direct_quad_last_kernel_ms(direct_quad_handle_t h, double* ms);
 
 #ifdef __cplusplus

@@ -70,7 +70,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   if (in->seeds) cp(E->seeds, in->seeds, (size_t)B * nm * 3);
   E->infeas_in.assign(B, (uint8_t)p->infeas);
   if (in->infeas_in) E->infeas_in.assign(in->infeas_in, in->infeas_in + B);
-  size_t nx = (size_t)B * (nm + 1) * kXS, ns = (size_t)B * nm * ncm;
+  size_t nx = (size_t)B * (nm + 1) * x_stride<Real>(), ns = (size_t)B * nm * ncm;
   E->X0.assign(nx, 0); E->X1.assign(nx, 0); E->X2.assign(nx, 0);
   E->S0.assign(ns, 0); E->S1.assign(ns, 0); E->S2.assign(ns, 0);
   E->Y0.assign(ns, 0); E->Y1.assign(ns, 0); E->Y2.assign(ns, 0);
@@ -87,7 +87,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data(); Bt.S[2] = E->S2.data();
   Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.Y[2] = E->Y2.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
   Bt.KY = E->KY.data(); Bt.filt = E->filt.data(); Bt.st = E->st.data();
-  Bt.nbuf = 3; Bt.help = nullptr; Bt.sched_err = nullptr;
+  Bt.nbuf = 3; Bt.help = nullptr; Bt.sched_err = nullptr; Bt.visits = nullptr;
   SolveConst& k = Bt.k;
   k.max_vel = p->max_vel; k.max_acc = p->max_acc; k.w_snap = p->w_snap; k.w_term = p->w_terminal;
   k.w_time = p->w_time; k.reg_base = p->zero_init ? 1.6 : 4.0; k.shift = p->minvo ? 0.0 : 2.0e-4;

@@ -45,7 +45,7 @@ def perturb_ulp(batch, seed):
         return np.where(s > 0, np.nextafter(a, np.inf), np.where(s < 0, np.nextafter(a, -np.inf), a))
     return abi.HostBatch(batch.n_seg, p(batch.x0), p(batch.xd), p(batch.T0), batch.n_planes, p(batch.planes),
                          seeds=batch.seeds, init_bez=None if batch.init_bez is None else p(batch.init_bez),
-                         infeas_in=batch.infeas_in)
+                         infeas_in=batch.infeas_in, init_poly=None if batch.init_poly is None else p(batch.init_poly))
 
 
 class OracleStepper:

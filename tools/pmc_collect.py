@@ -1,9 +1,13 @@
 """Aggregates rocprofv3 --pmc passes (csv output) of ONE workload into the JSON files bench.py reads.
 
 usage: pmc_collect.py <passes_dir> <out_prefix> <kind> <dtype> <batch> <nseg> <fixed_iters>
-<passes_dir>/<pass>/ holds one rocprofv3 run each (counter_collection.csv + kernel_trace.csv).  For every
-counter the k_iterate dispatches of the timed workload (the largest ones: the phase-0 launch is much
-smaller) are averaged.  Writes <out_prefix>_sq_counters.json and, when FETCH_SIZE / WRITE_SIZE passes are
+<passes_dir>/<pass>/ holds one rocprofv3 run each (counter_collection.csv + kernel_trace.csv).  The timed launch is
+selected BY POSITION: tools/prof_one.py runs phase 0 first and the fixed-iteration phase-1 solve last, so the timed
+launch is the LAST k_iterate* dispatch of the process (r02 selected "the largest dispatches", which picked the
+50-iteration phase-0 launch wherever phase 0 never reaches feasibility: config 4).  The selection is then CHECKED:
+the kernel-trace duration of the selected dispatch must agree within 10 % with the "kernel ms" line the same process
+printed from its HIP events (<out_prefix>_pmc_run<i>.log), and - when <out_prefix>_plain.log exists - with the
+un-profiled run; otherwise the script exits non-zero and writes nothing.  Writes <out_prefix>_sq_counters.json and, when FETCH_SIZE / WRITE_SIZE passes are
 present, <out_prefix>_hbm_traffic.json (units and corrections: MI355X_MICROARCH.md, HBM section; the
 calibration factors for THIS access width come from <out_prefix>_hbm_calib.json when it exists)."""
 import csv
@@ -23,19 +27,43 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
         by.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
         by[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for name, disp in by.items():
-        vals = list(disp.values())
-        big = [v for v in vals if v > 0.5 * max(vals)] if max(vals) > 0 else vals
-        counters[name] = sum(big) / len(big)
+        last = max(disp, key=int)  # the last k_iterate* dispatch of the process = the timed launch
+        counters[name] = disp[last]
 for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
     rows = [r for r in csv.DictReader(open(f)) if "k_iterate" in r["Kernel_Name"]]
-    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-    if durs:
-        kernel_ms.append(max(durs))
+    if rows:
+        r = max(rows, key=lambda q: int(q["Dispatch_Id"]))
+        kernel_ms.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+
+
+def printed_ms(path):
+    """the `kernel ms <x>` line of tools/prof_one.py (HIP events around the timed launch, same process)"""
+    try:
+        for l in open(path):
+            if l.startswith("kernel ms"):
+                return float(l.split()[2])
+    except OSError:
+        pass
+    return None
+
+
+event_ms = [m for m in (printed_ms(f) for f in sorted(glob.glob(prefix + "_pmc_run*.log"))) if m is not None]
+plain_ms = printed_ms(prefix + "_plain.log")
+if not kernel_ms or not event_ms:
+    sys.exit("pmc_collect: no k_iterate dispatch / no 'kernel ms' line found - nothing written")
+worst = max(abs(t / e - 1.0) for t, e in zip(kernel_ms, event_ms))
+if worst > 0.10:
+    sys.exit("pmc_collect: selected dispatch %s ms vs HIP-event time %s ms of the same runs: wrong launch selected"
+             % (kernel_ms, event_ms))
+if plain_ms is not None and max(abs(t / plain_ms - 1.0) for t in kernel_ms) > 0.10:
+    sys.exit("pmc_collect: kernel ms under PMC %s vs un-profiled %.2f ms differ by more than 10 %%" % (kernel_ms, plain_ms))
 c = counters
 out = {"command": "rocprofv3 --pmc <counters of one pass> --kernel-trace --output-format csv -- python tools/prof_one.py "
                   "%s %s %d %d %d (separate passes; the fixed-iteration phase-1 launch of bench.py's workload)"
                   % (kind, dtype, batch, nseg, iters),
-       "workload": workload, "counters": c, "kernel_ms_under_pmc": kernel_ms}
+       "workload": workload, "counters": c, "kernel_ms_under_pmc": kernel_ms, "kernel_ms_hip_events_same_runs": event_ms,
+       "kernel_ms_unprofiled": plain_ms,
+       "dispatch_selection": "last k_iterate* dispatch of tools/prof_one.py; checked against the HIP-event time (10 %)"}
 ddp_iters = float(batch * iters)
 der = {}
 if "SQ_INSTS_VALU" in c:

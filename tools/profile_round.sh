@@ -22,6 +22,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/cal_f -o f
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/cal_w -o w -- $ROOT/tools/hbm_calib > /dev/null 2>&1
 python $ROOT/tools/hbm_calib_collect.py /tmp/cal_f /tmp/cal_w $OUT/${R}_hbm_calib_plain.log $OUT/${R}
 # PMC passes over the workload (no torch in the process: a pass is ~10 s)
+python $ROOT/tools/prof_one.py free f32 4096 100 20 > $OUT/${R}_plain.log 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \

@@ -20,3 +20,6 @@ for r in csv.DictReader(open(f)):
 for n, d in sorted(by.items()):
     print(n, "per DDP iteration: %.0f" % (max(d.values()) / 81920.0))
 PY
+rm -rf /tmp/qp2
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/qp2 -o q -- python $ROOT/tools/pass_counts.py > /dev/null 2>&1
+python $ROOT/tools/pass_counts.py report /tmp/qp2
