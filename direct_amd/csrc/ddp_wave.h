@@ -48,6 +48,9 @@ inline T emu_uniform(T x, int line) {
 #define DDP_DEV inline
 #define DDP_DEV_NOINLINE inline
 #define LANES for (int lane = (direct::emu_lane() = 0); lane < 64; direct::emu_lane() = ++lane)
+// LANES_AGAIN(l): a further per-lane block of a phase whose lane index l was declared with DDP_LANE_DECL
+#define LANES_AGAIN(l) LANES
+#define DDP_LANE_DECL(l) const int l = 0; (void)l
 #define PLV(T, name) T name[64]
 #define PLA(T, name, n) T name[64][n]
 #define LV(name) name[lane]
@@ -58,6 +61,7 @@ inline T emu_uniform(T x, int line) {
 // value of per-lane array entry arr[idx] on lane `src` of the CALLER'S ROW of 16 lanes / acc -= that value * mul
 #define ROW_BCAST(arr, idx, src) (arr[(lane & 48) + (src)][idx])
 #define ROW_FNMA(acc, arr, idx, src, mul) ((acc) -= arr[(lane & 48) + (src)][idx] * (mul))
+#define ROW_FMA(acc, arr, idx, src, mul) ((acc) += arr[(lane & 48) + (src)][idx] * (mul))
 #define ROW_HAZARD(x) ((void)0)
 // a predicate accumulated over several LANES blocks of which only lane 0's value is wanted
 #define DDP_PRED_DECL(name) int name[64] = {0}
@@ -65,6 +69,8 @@ inline T emu_uniform(T x, int line) {
 #define DDP_PRED_LANE0(name) (name[0])
 #define DDP_UNIFORM_I(x) direct::emu_uniform((x), __COUNTER__)
 #define DDP_UNIFORM_R(x) direct::emu_uniform((x), __COUNTER__)
+#define DDP_UNIFORM_PW(x) direct::emu_uniform((x), __COUNTER__)
+#define ROW_FMA_V(acc, var, src, mul) ((acc) += var[(lane & 48) + (src)] * (mul))
 #define DDP_LAUNDER_S(x) ((void)0)
 #define DDP_LOADS_ISSUED() ((void)0)
 #define DDP_PIN(x) ((void)0)
@@ -84,6 +90,10 @@ inline T emu_uniform(T x, int line) {
 // indices and loop-invariant LDS table reads of every phase out of the knot loop (that costs >128
 // VGPRs and with them the occupancy); re-deriving them per phase is a handful of integer ops.
 #define LANES for (int lane = direct::opaque_lane(), lanes_once_ = 1; lanes_once_; lanes_once_ = 0)
+// Several per-lane blocks of ONE phase that share one laundered lane index (each LANES block launders its own: a
+// v_mov and the re-derivation of everything computed from it)
+#define LANES_AGAIN(l) for (int lane = l, lanes_once_ = 1; lanes_once_; lanes_once_ = 0)
+#define DDP_LANE_DECL(l) const int l = direct::opaque_lane()
 #define PLV(T, name) T name
 #define PLA(T, name, n) T name[n]
 #define LV(name) name
@@ -107,6 +117,7 @@ inline T emu_uniform(T x, int line) {
 // read (ROW_HAZARD pins the producer before the s_nop; the ROW_BCAST form carries its own).
 #define ROW_BCAST(arr, idx, src) direct::row_bcast<src>(arr[idx])
 #define ROW_FNMA(acc, arr, idx, src, mul) direct::row_fnma<src>(acc, arr[idx], mul)
+#define ROW_FMA(acc, arr, idx, src, mul) direct::row_fma<src>(acc, arr[idx], mul)
 #define ROW_HAZARD(x) asm volatile("s_nop 1" : "+v"(x))
 // a predicate accumulated over several LANES blocks of which only lane 0's value is wanted: the compare's own lane
 // mask, OR-ed on the scalar unit (a per-lane flag costs a v_cndmask per update, or is merged into an fmin / fmax chain)
@@ -116,6 +127,11 @@ inline T emu_uniform(T x, int line) {
 #define DDP_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
 // a wave-uniform real computed by the VALU (or read from LDS) moved to SGPRs: frees its VGPRs
 #define DDP_UNIFORM_R(x) direct::uniform_real(x)
+// The powers of T: wave-uniform values that every lane computes for itself and keeps in VGPRs.  Moving a double to
+// SGPRs costs two v_readfirstlane on top of the multiply that produced it (there is no scalar f64 multiply): three
+// VALU instructions per power instead of one.
+#define DDP_UNIFORM_PW(x) (x)
+#define ROW_FMA_V(acc, var, src, mul) direct::row_fma<src>(acc, var, mul)
 // re-materialise a wave-uniform value: stops LICM from hoisting everything derived from it (slab
 // pointers, strides) out of the outer iteration loop, where it would stay live across both sweeps
 #define DDP_LAUNDER_S(x) asm volatile("" : "+s"(x))
@@ -218,6 +234,10 @@ __device__ __forceinline__ double row_bcast(double v) {
   double r;
   asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(SRC));
   return r;
+}
+template <int SRC>
+__device__ __forceinline__ void row_fma(double& acc, double a, double b) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(SRC));
 }
 template <int SRC>
 __device__ __forceinline__ void row_fnma(double& acc, double a, double b) {
@@ -397,7 +417,8 @@ struct FwdTrial {
 };
 
 // ---- LDS (one per wave) ------------------------------------------------------------------------
-// RowT: type of the per-row D / g staging arrays (the storage type: float halves them in DIRECT_F32).
+// RowT (the storage type) is kept for the template's signature; the per-row D / g staging arrays are double for both
+// storage types (float staging cost a conversion per row and plane in phase S and two per row in phase R1).
 template <typename Real, typename RowT, int RPL>
 struct WaveLds {
   typedef FwdTrial<Real> FwdT;
@@ -411,7 +432,8 @@ struct WaveLds {
   // launch).  They depend on the lane alone, but `lane` is laundered per phase (see LANES) so that the indices are
   // not hoisted into a hundred live registers - which made every knot re-derive them with ~40 integer
   // instructions per phase.  One ds_read_b32 and a few bit-field extracts replace that.
-  int lt[5][64];
+  int lt[6][64];
+  Real ones[5];           // 1.0: the neutral second factor of phase S's g rows (addressed like a plane component)
   // per knot, both sweeps
   Real tp[8];             // powers of T
   Real z[kXS];
@@ -441,7 +463,7 @@ struct WaveLds {
           };
         };
         struct {
-          RowT drow[64 * RPL], grow[64 * RPL];
+          Acc drow[64 * RPL], grow[64 * RPL];
         };
       };
       Acc Hz[20];
@@ -805,6 +827,16 @@ struct Wave {
           a++;
         }
         L.lt[4][lane] = a | ((a + rem) << 4);
+        {  // lt[5]: phase S roles (lanes >= 54 redo lane 53)
+          const int l54 = lane < 54 ? lane : 53;
+          const bool isS = l54 < 36;
+          const int e = l54 % 6, j = isS ? l54 / 6 : (l54 - 36) / 3;
+          const int d0 = isS ? ((e < 3) ? 0 : (e < 5 ? 1 : 2)) : (l54 - 36) % 3;
+          const int d1 = isS ? ((e < 3) ? e : (e < 5 ? e - 2 : 2)) : 0;
+          const int dst = isS ? l54 : (int)(&L.hh[0] - &L.Sp[0]) + (l54 - 36);  // Sp, dl, Sd, hh are consecutive members
+          L.lt[5][lane] = d0 | (d1 << 2) | ((isS ? 1 : 0) << 4) | (j << 5) | (dst << 8);
+        }
+        if (lane < 5) L.ones[lane] = (Real)1;
       }
       if (lane < 5) {  // pseudo-planes (n, o) of the non-plane rows: +/-v - vmax, +/-a - amax, -T + 0.3 (DDP:1237-1279)
         Real* q = &L.pl[4 * Lds::kPMax + 4 * lane];
@@ -1363,8 +1395,8 @@ struct Wave {
           LV(rc)[i] = infeas ? c : D;
           LV(rr)[i] = infeas ? rv : rv * frcp_reuse;
           if (in) {
-            L.drow[r] = (St)D;
-            L.grow[r] = (St)g;
+            L.drow[r] = (Acc)D;
+            L.grow[r] = (Acc)g;
           }
         }
 #pragma unroll
@@ -1406,32 +1438,27 @@ struct Wave {
       // lanes recompute (and re-store) a neighbour's value, which costs no extra instruction in SIMT and
       // removes the exec-mask bookkeeping of role branches.
       LANES {
-        {
-          const int l54 = lane < 54 ? lane : 53;
-          const bool isS = l54 < 36;
-          const int e = l54 % 6, j = isS ? l54 / 6 : (l54 - 36) / 3;
-          const int d0 = isS ? ((e < 3) ? 0 : (e < 5 ? 1 : 2)) : (l54 - 36) % 3;
-          const int d1 = isS ? ((e < 3) ? e : (e < 5 ? e - 2 : 2)) : 0;
-          const St* w = isS ? L.drow : L.grow;
+        {  // lanes 0..35: S_j[d0][d1] = sum_q D_(jP+q) n_q[d0] n_q[d1]; lanes 36..53: h_j[d0] = sum_q g_(jP+q) n_q[d0] * 1
+          const int ws = L.lt[5][lane];  // d0 | d1 << 2 | isS << 4 | j << 5 | destination (doubles from Sp[0]) << 8
+          const bool isS = (ws >> 4) & 1;
+          const Acc* w = (isS ? L.drow : L.grow) + ((ws >> 5) & 7) * P;
+          const Real* n0 = &L.pl[ws & 3];
+          const Real* nf = isS ? &L.pl[(ws >> 2) & 3] : &L.ones[0];
+          const int fstep = isS ? 4 : 0;
           Acc acc = 0;
 #pragma unroll 2
-          for (int q = 0; q < P; q++) {
-            const Real* n = &L.pl[4 * q];
-            const Real f = isS ? n[d1] : (Real)1;
-            acc += (Real)w[j * P + q] * n[d0] * f;
-          }
-          Acc* dst = isS ? &L.Sp[l54] : &L.hh[l54 - 36];
-          *dst = acc;
+          for (int q = 0; q < P; q++) acc += w[q] * n0[4 * q] * nf[fstep * q];
+          (&L.Sp[0])[(ws >> 8) & 255] = acc;
         }
         {  // velocity / acceleration rows: +/- pairs
           const int l27 = lane < 27 ? lane : 26;
           const int rp = 6 * P + (l27 < 15 ? l27 : 15 + l27);  // 6P + l | 6P + 30 + (l - 15)
           const int rm = rp + (l27 < 15 ? 15 : 12);
-          L.dl[l27] = (Acc)L.drow[rp] + (Acc)L.drow[rm];
-          L.hh[18 + l27] = (Acc)L.grow[rp] - (Acc)L.grow[rm];
+          L.dl[l27] = L.drow[rp] + L.drow[rm];
+          L.hh[18 + l27] = L.grow[rp] - L.grow[rm];
         }
-        L.last[0] = (Acc)L.drow[nc - 1];
-        L.last[1] = (Acc)L.grow[nc - 1];
+        L.last[0] = L.drow[nc - 1];
+        L.last[1] = L.grow[nc - 1];
       }
       WSYNC();
       DDP_MARK("B_S2");
@@ -1587,11 +1614,12 @@ struct Wave {
       // columns + right-hand sides 16..19; rows 2 and 3 repeat rows 0 and 1 (their results are never read).
       PLA(Acc, m, 10);
       PLA(Acc, ls, 10);  // scaled entries: ls[k] of matrix lane j is L[j][k]; of a right-hand-side lane (L^-1 [Hu | Hux])[k][.]
-      PLA(Acc, xs, 10);  // back-substituted columns (right-hand-side lanes)
+      PLA(Acc, xs, 10);  // MINUS the back-substituted columns (right-hand-side lanes): the gains themselves
       PLA(Acc, rd, 10);  // 1 / L_kk
       PLV(int, colv);
       DDP_PRED_DECL(bad);
-      LANES {
+      DDP_LANE_DECL(lane_c);
+      LANES_AGAIN(lane_c) {
         const int l5 = lane & 31;
         const int col = l5 < 16 ? l5 : (l5 < 26 ? l5 - 16 : (l5 < 30 ? l5 - 10 : 19));
         LV(colv) = col;
@@ -1613,7 +1641,7 @@ struct Wave {
       // phase R2 reads [y | Y] = L^-1 [Hu | Hux] (columns 10..19).
       static_for<0, 10>([&](auto KK) {
         constexpr int kk = KK;
-        LANES {
+        LANES_AGAIN(lane_c) {
           const Acc piv = ROW_BCAST(m, kk, kk);
           DDP_PRED_OR(bad, piv <= (Acc)0);  // Eigen LLT: NumericalIssue iff pivot <= 0 (NaN passes)
           const Acc rinv = frsq(piv);
@@ -1634,26 +1662,28 @@ struct Wave {
         count_visits(0, N - k);
         return 0;
       }
-      // back substitution L^T X = [y | Y] in the right-hand-side lanes: L[j][i] (j > i) is entry i of matrix lane j,
-      // again a row broadcast folded into the FMA; same order of operations as the sequential form
+      // Back substitution L^T X = [y | Y] in the right-hand-side lanes: L[j][i] (j > i) is entry i of matrix lane j,
+      // again a row broadcast folded into the FMA.  The lanes carry Z = -X, the gains themselves ([ku | Ku] = -X,
+      // DDP:561-564, 607-609):  x_i = (y_i - sum L_ji x_j) / L_ii  <=>  z_i = (y_i + sum L_ji z_j) * (-1 / L_ii) - the
+      // same products and sums in the same order, every intermediate the exact negative or the same value.
       static_for_down<9, 0>([&](auto II) {
         constexpr int i = II;
-        LANES {
+        LANES_AGAIN(lane_c) {
           Acc acc = LV(ls)[i];
           static_for<i + 1, 10>([&](auto J) {
             constexpr int j = J;
-            ROW_FNMA(acc, ls, i, j, LV(xs)[j]);
+            ROW_FMA(acc, ls, i, j, LV(xs)[j]);
           });
-          LV(xs)[i] = acc * LV(rd)[i];
+          LV(xs)[i] = acc * (-LV(rd)[i]);
         }
       });
-      LANES {
-        if (LV(colv) >= 10) {  // [ku | Ku] = -X   (DDP:561-564, 607-609)
+      LANES_AGAIN(lane_c) {
+        if (LV(colv) >= 10) {
           const int c = LV(colv) - 10;
 #pragma unroll
           for (int a = 0; a < 10; a++) {
             const int idx = (c == 0) ? a : 10 + a * 9 + (c - 1);
-            L.KU[idx] = -LV(xs)[a];
+            L.KU[idx] = LV(xs)[a];
           }
         }
       }
@@ -2046,43 +2076,45 @@ struct Wave {
           typename Lds::FwdT& F = L.ft[t];
           PLV(Real, unew);
           PLV(Real, dxl);
+          // x lanes: 0..8, and a second copy in lanes 16..24 of the ROW OF 16 that holds the ten u lanes (16..25): every
+          // dx[c] then reaches the u lanes as a DPP row broadcast folded into the FMA, not through two v_readlane
           LANES {
-            const int l9 = lane < 9 ? lane : 8;
+            const int lx = lane & 15;
+            const int l9 = lx < 9 ? lx : 8;
             const Real xv = F.xn[l9];
             LV(dxl) = xv - L.z[l9];
             if (lane < 9) {
               F.dz[lane] = LV(dxl);
               F.zn[lane] = xv;
             }
+            ROW_HAZARD(LV(dxl));
           }
-          Real dx[9];  // dx is the same for the ten u lanes: broadcast from lanes 0..8 instead of 18 LDS reads each
-#pragma unroll
-          for (int c = 0; c < 9; c++) dx[c] = RDLANE_V(dxl, c);
           LANES {
             LV(unew) = (Real)0;
-            if (lane >= 9 && lane < 19) {
-              const int a = lane - 9;
+            if (lane >= 16 && lane < 26) {
+              const int a = lane - 16;
               Real kr[9];
 #pragma unroll
               for (int c = 0; c < 9; c++) kr[c] = L.KUr[10 + a * 9 + c];
-              const Real zl = L.z[lane], kf = L.KUr[a];
+              const Real zl = L.z[9 + a], kf = L.KUr[a];
               DDP_LOADS_ISSUED();
               Real acc = 0;
-#pragma unroll
-              for (int c = 0; c < 9; c++) acc += kr[c] * dx[c];
-              F.dz[lane] = acc;
+              static_for<0, 9>([&](auto C) {
+                constexpr int c = C;
+                ROW_FMA_V(acc, dxl, c, kr[c]);
+              });
+              F.dz[9 + a] = acc;
               // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
               // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
               const Real un = pair_round(zl + alpha[t] * kf + acc);
-              F.zn[lane] = un;
+              F.zn[9 + a] = un;
               LV(unew) = un;
             }
           }
-          Tn[t] = RDLANE_V(unew, 18);
-          const Real Tn2 = DDP_UNIFORM_R(Tn[t] * Tn[t]), Tn4 = DDP_UNIFORM_R(Tn2 * Tn2);
-          LANES { F.tpn[lane & 7] = pow3(Tn[t], Tn2, Tn4, lane & 7); }
+          Tn[t] = RDLANE_V(unew, 25);
+          const Real Tn2 = DDP_UNIFORM_PW(Tn[t] * Tn[t]), Tn4 = DDP_UNIFORM_PW(Tn2 * Tn2);
 #pragma unroll
-          for (int j = 0; j < 6; j++) pwn[t][j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(Tn[t], Tn2, Tn4, j));
+          for (int j = 0; j < 6; j++) pwn[t][j] = (j == 0) ? (Real)1 : DDP_UNIFORM_PW(pow3(Tn[t], Tn2, Tn4, j));
           if (Tn[t] < 0) tr[t].neg = 1;
         }
       }

@@ -74,15 +74,25 @@ def test_free_space_full_batch_fp32(built, free_batch):
     sub = free_batch.select(np.arange(512, 768))
     s0, s1 = s.plan(p0, p1, sub)
     assert np.array_equal(s1.bez, g1.bez[512:768]) and np.array_equal(s1.iter_used, g1.iter_used[512:768])
-    # sample parity against the fp64 oracle: 32 problems spread over the batch.  rtn == 1 is a stagnation exit
-    # ((dJ)^2 < 0.01 J, ddp_optimizer.cpp:374), not a KKT point, and about one N = 100 problem in thirty is
-    # ill-conditioned enough for float storage to stop tens of iterations away from fp64 (measured on this sample:
-    # median 1.3e-7, 90 % 1.3e-6, one problem 0.64; tests/soak/f32_fullsize_dev.py) - hence quantiles, not a maximum
+    # sample parity against the fp64 oracle: 32 problems spread over the batch, phase 1 from IDENTICAL inputs (the
+    # device's own phase-0 result, which the fused plan hands over on the device: durations where rtn == 2, monomial
+    # coefficients, feasibility flags).  With the iterate stored as hi + lo float pairs float storage follows the fp64
+    # iterates through the stagnation exits (ddp_optimizer.cpp:374) too: SURVEY.md 8(c)'s fp32 tolerances hold for EVERY
+    # problem of the sample.  (r02 needed a 15 % allowance here: single-float iterates left the oracle at the exits of
+    # 11 % of these problems.  One problem of this sample is a knife edge of the ALGORITHM - at the barrier update that
+    # precedes its exit opterr lands at 25 or at 76 around the exit rule's threshold of 50, ddp_optimizer.cpp:340-378,
+    # depending on a 6e-8 perturbation of the INPUTS, and the cost at exit differs by 2.8x -, which is why both sides
+    # must be given bit-identical inputs; tests/test_gpu_n100.py has the controls.)
     idx = np.arange(0, B, 128)
-    r0, r1 = refapi.plan_batch(p0, p1, free_batch.select(idx))
-    assert (g1.rtn[idx] == r1.rtn).mean() >= 0.9
+    b1 = free_batch.astype(np.float32).with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, free_batch.T0.astype(np.float32)),
+                                                 infeas_in=g0.infeas_out, init_poly=g0.poly).select(idx)
+    r1, _ = refapi.solve_batch(p1, b1.astype(np.float64))
+    assert (g1.rtn[idx] == r1.rtn).all()
     dev = np.abs(g1.cost[idx] / r1.cost - 1)
-    assert np.median(dev) < 1e-5 and np.quantile(dev, 0.85) < 1e-3, np.sort(dev)[::-1][:5]
+    # every problem within 1e-3 - except, at most, the knife-edge one (it flips with a 1e-7 change anywhere in the float
+    # storage path; with the r03 build it does not)
+    assert np.median(dev) < 1e-6 and (dev < 1e-3).sum() >= len(dev) - 1, np.sort(dev)[::-1][:5]
+    assert np.sort(np.abs(g1.iter_used[idx] - r1.iter_used))[-2] <= 1
     idx = np.array([0, 777, 2048, 4095])
     r0, r1 = refapi.plan_batch(p0, p1, free_batch.select(idx))
     # at a FIXED iteration count the two precisions follow the same path much more closely

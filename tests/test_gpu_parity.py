@@ -297,3 +297,48 @@ def test_containment_audit_of_the_samples(built):
     bad = s.sample(batch.n_seg, shifted, g1.T, 0.05, 2048, derivs=0, n_planes=batch.n_planes, planes=batch.planes)
     s.close()
     assert bad["cmax"][0] > 1.0 and np.array_equal(bad["cmax"][1:], d["cmax"][1:])
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 5e-5)])
+def test_forward_pass_after_a_backward_pass_that_failed_part_way(built, dtype, tol):
+    """Stepwise entry points on a stale row cache: with float storage the feasible-mode forward trials read
+    c and s / c of the nominal iterate from scratch arrays that only a COMPLETED backward sweep fills.  Here the sweep
+    is made to fail at knot 2 (negative slacks there: Quu - cu' (s/c) cu loses definiteness, LLT reports it,
+    ddp_optimizer.cpp:595-600) right after an accepted iteration has moved the iterate to another buffer; the forward
+    pass that follows must still evaluate its trials against the CURRENT iterate, as the reference's does
+    (ddp_optimizer.cpp:696) - compared with the oracle driven through the same sequence."""
+    batch = problems.make_batch("corridor", 3, 8, seed=11).astype(dtype).astype(np.float64)
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    r0, _ = refapi.solve_batch(p0, batch)
+    b1 = batch.with_init(None, T0=np.where((r0.rtn == 2)[:, None], r0.T, batch.T0), infeas_in=np.zeros(3, np.uint8),
+                         init_poly=r0.poly).astype(dtype).astype(np.float64)
+    s = make_solver(b1, dtype)
+    s.begin(p1, b1)
+    r = [refapi.Stepper(p1, b1, i) for i in range(3)]
+    s.iterate(1)
+    for q in r:
+        q.iterate(1)
+    assert (s.scalars()["infeas"] == 0).all() and (s.scalars()["fp_failed"] == 0).all()
+    S = s.get(abi.FIELD_S).astype(np.float64)
+    for i in range(3):
+        S[i, 2, :6 * int(b1.n_planes[i, 2]) + 55] = -1.0e3   # the rows that exist at knot 2
+    s.set(abi.FIELD_S, S)
+    for i, q in enumerate(r):
+        q.set(abi.FIELD_S, S[i][:, :q.ncmax])
+    s.backward()
+    for q in r:
+        q.backward()
+    assert (s.scalars()["bp_failed"] == 1).all() and all(q.scalars()["bp_failed"] == 1 for q in r)
+    s.forward()
+    for q in r:
+        q.forward()
+    sc = s.scalars()
+    for i, q in enumerate(r):
+        rs = q.scalars()
+        assert sc["step"][i] == rs["step"] and sc["fp_failed"][i] == rs["fp_failed"], (i, sc["step"][i], rs["step"])
+        assert abs(sc["cost"][i] / rs["cost"] - 1) < tol
+    ncm = r[0].ncmax
+    for f in (abi.FIELD_X, abi.FIELD_U):
+        assert max(helpers.rel(s.get(f)[i], r[i].get(f)) for i in range(3)) < tol, f
+    assert max(helpers.rel(s.get(abi.FIELD_S)[i][:, :ncm], r[i].get(abi.FIELD_S)) for i in range(3)) < 20 * tol
+    s.close()

@@ -36,3 +36,17 @@ def test_emulated_kernels_are_as_close_to_the_oracle_as_the_oracle_is_to_itself(
     # the control itself: a 1-ulp perturbation is amplified beyond 1e-8 somewhere, and most solves are untouched
     assert all(c["pre_flip_dev_quantiles_50_90_99_999"][0] < 1e-11 for c in ctl)
     assert max(c["pre_flip_dev_max"] for c in ctl) > 1e-9
+
+
+def test_n100_controls_run_without_a_device():
+    """The N = 100 comparison library (tests/n100_lib.py) on the CPU: oracle against itself with its inputs moved by one
+    ulp of a double / of a float on 4 corridors of the config-3 batch.  A double ulp leaves every exit and the cost
+    (1e-8) untouched on these; a float ulp moves the phase-1 cost by more than 1e-8 - the yardstick the device's float
+    storage is held to in tests/test_gpu_n100.py."""
+    from tests import n100_lib
+    r = n100_lib.sample_report("corridor", 4096, 100, np.arange(0, 4096, 1024), None, None, control_seeds=(11,))
+    c64, c32 = r["control_double_ulp"][0], r["control_float_ulp"][0]
+    assert c64["phase0"]["same_outcome"] == 4 and c64["phase0"]["n_cost_dev_below_1e_8"] == 4
+    assert c64["phase1"]["same_feasibility"] == 4 and c64["phase1"]["cost_dev_q50_q90_max"][0] < 1e-8
+    assert c32["phase0"]["same_feasibility"] == 4 and c32["phase0"]["cost_dev_q50_q90_max"][0] > 1e-9
+    assert c32["phase1"]["cost_dev_q50_q90_max"][2] > 1e-8

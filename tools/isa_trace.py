@@ -27,7 +27,8 @@ for i, l in enumerate(lines):
     mm = re.match(r"^(\.LBB\d+_\d+):", l)
     if mm:
         label_at[mm.group(1)] = i
-pc = next(i for i, l in enumerate(lines) if "; DDP_MARK " + start in l)
+pc = [i for i, l in enumerate(lines) if "; DDP_MARK " + start in l][int(opts.get("occ", 1)) - 1]  # --occ=N: Nth occurrence of the mark
+start_pc = pc
 phase, stats, order, met, loops = start, {}, [], [], {}
 first = True
 steps = 0
@@ -36,7 +37,7 @@ while pc < len(lines) and steps < 200000:
     steps += 1
     mm = re.search(r"; DDP_MARK (\w+)", l)
     if mm:
-        if mm.group(1) == start and not first:
+        if (mm.group(1) == start and not first) or mm.group(1) == opts.get("stop", ""):
             break
         first = False
         phase = mm.group(1)
@@ -76,7 +77,7 @@ while pc < len(lines) and steps < 200000:
     if op.startswith("s_cbranch"):
         tgt = rest.strip()
         back = label_at[tgt] < pc
-        if back:
+        if back and label_at[tgt] >= start_pc:
             n = loops.get(tgt, 0)
             if n < trips - 1:
                 loops[tgt] = n + 1
@@ -84,7 +85,9 @@ while pc < len(lines) and steps < 200000:
                 continue
             loops[tgt] = 0
         elif "exec" in op:
-            pass
+            if back and op.endswith("execnz"):  # a back edge over the lane mask (outer loop header): follow it
+                pc = label_at[tgt]
+                continue
         else:
             seen[tgt] = seen.get(tgt, 0) + 1
             take = tgt in taken and (taken[tgt] == 0 or taken[tgt] == seen[tgt])
