@@ -155,7 +155,8 @@ inline T emu_uniform(T x, int line) {
 #if defined(DDP_MARKS)  // phase markers in the .s for static instruction accounting (tools/phase_count.py)
 #define DDP_MARK(name) asm volatile("; DDP_MARK " name ::: "memory")
 #elif defined(DDP_TIMING)  // per-phase cycle accounting with s_memtime (tools/phase_timing.py); debug builds only
-#define DDP_MARK(name) direct::phase_tick(name)
+#define DDP_MARK(name) direct::phase_tick(name, DDP_TICK_OBJ.tick)
+#define DDP_TICK_OBJ (*this)
 #else
 #define DDP_MARK(name)
 #endif
@@ -188,8 +189,11 @@ constexpr int kPLim = 32;  // DIRECT_P_LIMIT
 
 #if !defined(DIRECT_EMULATE)
 #if defined(DDP_TIMING)
+// Per-phase cycle accounting of workgroup 0 (debug builds; tools/phase_timing.py).  Cheap enough not to distort what it
+// measures: s_memtime, one scalar subtraction and two fire-and-forget LDS atomics per mark; the running state (last
+// time stamp, phase that is open) lives in two wave-uniform members of the Wave object, the totals in LDS until the
+// "Z_E" mark at the end of the kernel adds them to g_phase_cycles.  No vmcnt wait: the HBM prefetch stays in flight.
 __device__ unsigned long long g_phase_cycles[64];
-__device__ unsigned long long g_phase_last;
 __device__ __forceinline__ constexpr int phase_id(const char* n) {
   // B_L 0 B_T1 1 B_T2 2 B_R1 3 B_S 4 B_S2 5 B_H 6 B_C 7 B_G 8 B_R2 9 B_END 10 F_L 11 F_D 12 F_T 13 F_R 14 F_END 15
   if (n[0] == 'Z') return 19;
@@ -198,20 +202,33 @@ __device__ __forceinline__ constexpr int phase_id(const char* n) {
                         : n[2] == 'S' ? (n[3] == '2' ? 5 : 4) : n[2] == 'H' ? 6 : n[2] == 'C' ? 7 : n[2] == 'G' ? 8 : 10)
                      : (n[2] == 'L' ? 11 : n[2] == 'D' ? 12 : n[2] == 'T' ? 13 : n[2] == 'R' ? 14 : 15);
 }
+struct TickState {
+  unsigned long long tlast;
+  int open;  // id of the phase that is running
+};
 // time since the previous mark is charged to the phase that ENDS here (= the previous mark's phase)
-__device__ int g_phase_last_id;
-__device__ __forceinline__ void phase_tick(const char* name) {
+__device__ __forceinline__ void phase_tick(const char* name, TickState& ts) {
   if (blockIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    unsigned long long t = __builtin_readcyclecounter();
-    int& last_id = g_phase_last_id;
-    if (threadIdx.x == 0) {
-      if (name[0] == 'Z') g_phase_last = t;  // first mark of a launch: nothing to charge
-      g_phase_cycles[last_id] += t - g_phase_last;
-      g_phase_cycles[32 + last_id] += 1;
-      g_phase_last = t;
-      last_id = phase_id(name);
+    __shared__ unsigned long long s_acc[32];
+    __shared__ unsigned int s_cnt[32];
+    const unsigned long long t = __builtin_readcyclecounter();
+    if (name[0] == 'Z' && name[2] == '0') {  // first mark of the kernel
+      if (threadIdx.x < 32) { s_acc[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; }
+    } else {
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&s_acc[ts.open], t - ts.tlast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_cnt[ts.open], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (name[0] == 'Z' && name[2] == 'E') {  // last mark: totals to global memory
+        __syncthreads();
+        if (threadIdx.x < 32) {
+          atomicAdd(&g_phase_cycles[threadIdx.x], s_acc[threadIdx.x]);
+          atomicAdd(&g_phase_cycles[32 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+        }
+      }
     }
+    ts.tlast = t;
+    ts.open = phase_id(name);
   }
 }
 #endif
@@ -427,12 +444,13 @@ struct WaveLds {
   // value / d-dT base tables with Ek_inv folded in (fixed for the launch).  Rows 15..17: [F|G] and its
   // T-derivative, rows 18..20: the jerk Gram matrix R acting on u and its T-derivative (see ctrl_off()).
   Real WbE[126], WdE[126];
-  Real Rc[9];             // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1)
+  Real Rc[10];            // jerk Gram coefficients: R[a][a'] = Rc * T^(a+a'+1); Rc[9] = 0
   // Per-lane role descriptors of the backward sweep's assembly phases, packed (init_tables; fixed for the
   // launch).  They depend on the lane alone, but `lane` is laundered per phase (see LANES) so that the indices are
   // not hoisted into a hundred live registers - which made every knot re-derive them with ~40 integer
   // instructions per phase.  One ds_read_b32 and a few bit-field extracts replace that.
-  int lt[6][64];
+  int lt[8][64];                  // rows 0..3: phase H; 4..6: the three VZ passes of phase R1; 7: phase T2
+  unsigned short lt16[6][64];     // 0: value recursion of phase R2; 1: phase S; 2..4: phase H (operand offsets); 5: phase T1
   Real ones[5];           // 1.0: the neutral second factor of phase S's g rows (addressed like a plane component)
   // per knot, both sweeps
   Real tp[8];             // powers of T
@@ -442,12 +460,22 @@ struct WaveLds {
   union {
     struct {  // ---- backward sweep only
       // We = WbE o T-powers for rows 0..17; rows 15..17 are Z = [F|G] itself
-      Real We[108], dval[48];
+      alignas(16) Real We[108];  // layout we_idx(): [i][row]
+      Real dval[48];
       // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
       // (Acc) whatever Real is: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in
       // fp32 over ~100 knots (DESIGN.md "Precision").
       Acc fT[12], Ru[9], Rpu[9], Rppu[9];
-      Acc V[81], Vx[12];
+      // V is dead between phase R1 (VZ = V Z) and phase R2 (which rewrites it): two assembly operands of phases S .. H
+      // live in its storage meanwhile
+      union {
+        alignas(16) Acc V[81];
+        struct {
+          alignas(16) Acc Sd[48];  // layout ch_idx(): [axis][control row]
+          alignas(16) Acc dl[30];  // layout dl_idx(): [axis][velocity / acceleration control point]
+        };
+      };
+      Acc Vx[12];
       // Hxu[a][c] (9x10), Huu 10x10, both triangles stored.  Hxx | Hxu | Huu must stay consecutive
       // (phase H stores through one base pointer).  Phase C reads Huu into registers and never again, so
       // the gains it produces share that storage.
@@ -469,7 +497,9 @@ struct WaveLds {
       Acc Hz[20];
       union {
         struct {  // operands of the assembly: dead once phase H is done
-          Acc Sp[36], dl[27], Sd[48], hh[48], last[4];
+          alignas(16) Acc Sp[36];  // layout sp_idx(): [entry of the symmetric 3x3][control point]
+          alignas(16) Acc hh[48];  // layout ch_idx()
+          Acc last[4];
           Acc VZ[176];  // Vxx * Z
         };
         struct {
@@ -558,6 +588,30 @@ DDP_DEV Real powi(Real T, int e) {  // T^e for 0 <= e <= 7 without a register-ar
   return r;
 }
 
+// Two neighbouring elements with ONE load: 16 bytes for doubles, i.e. ds_read_b128, which reaches its rate from one
+// wave per SIMD where 8-byte reads need four (MI355X_MICROARCH.md, LDS) - the sweeps run at three.  p must be aligned
+// to two elements; the LDS layouts below (Wave::we_idx ...) are chosen so that it is.
+#if defined(DIRECT_EMULATE)
+template <typename T>
+DDP_DEV void ld2(const T* p, T& a, T& b) {
+  a = p[0];
+  b = p[1];
+}
+#else
+template <typename T>
+DDP_DEV void ld2(const T* p, T& a, T& b) {
+  typedef T __attribute__((ext_vector_type(2))) V2;  // a struct of two would be split into two scalar loads again
+  const V2 v = *reinterpret_cast<const V2*>(p);
+  a = v.x;
+  b = v.y;
+}
+#endif
+// element of an array at a BYTE offset (the per-lane role tables hold ready-made byte offsets)
+template <typename T>
+DDP_DEV T* byte_at(T* base, int byte_off) { return (T*)((char*)base + byte_off); }
+template <typename T>
+DDP_DEV const T* byte_at(const T* base, int byte_off) { return (const T*)((const char*)base + byte_off); }
+
 // T^e for 0 <= e <= 7 by binary powering from T, T^2, T^4 (3 selects + 2 multiplies)
 template <typename Real>
 DDP_DEV Real pow3(Real T, Real T2, Real T4, int e) {
@@ -600,8 +654,18 @@ struct Wave {
   TrajState& st;
   int b;  // trajectory
   int N;  // segments
+#if defined(DDP_TIMING) && !defined(DIRECT_EMULATE)
+  TickState tick;
+#endif
 
   DDP_DEV Wave(const Batch<St>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
+
+  // LDS layouts of the assembly operands of the backward sweep.  The index a consumer's inner loop runs over is the
+  // fastest one, so that two neighbours come with one 16-byte load (ld2).
+  static constexpr int we_idx(int row, int i) { return i * 18 + row; }   // We: 15 control rows + 3 rows of Z, 6 coefficients
+  static constexpr int sp_idx(int cp, int e) { return e * 6 + cp; }      // Sp: 6 position control points, 6 entries of the symmetric 3x3
+  static constexpr int dl_idx(int cp9, int d) { return d * 10 + cp9; }   // dl: 9 velocity / acceleration control points, 3 axes
+  static constexpr int ch_idx(int row, int d) { return d * 16 + row; }   // Sd, hh: 15 control rows, 3 axes
 
   // Knot (b, k) of the [B][nmax(+1)] arrays; k may differ between lanes.
   DDP_DEV St* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * x_stride<St>(); }
@@ -797,28 +861,39 @@ struct Wave {
         int a = lane / 3, a2 = lane % 3;
         double ca = (a + 1) * (a + 2) * (a + 3), cb = (a2 + 1) * (a2 + 2) * (a2 + 3);
         L.Rc[lane] = (Real)(ca * cb / (double)(a + a2 + 1));
+        L.Rc[9] = (Real)0;
         L.WbE[108 + a * 6 + a2] = (Real)0;  // rows 18..20: [0 0 0 | Rc[a][:]], exponent i - (2 - a) = a + a2 + 1
         L.WbE[108 + a * 6 + 3 + a2] = (Real)(ca * cb / (double)(a + a2 + 1));
         L.WdE[108 + a * 6 + a2] = (Real)0;  // d/dT: (a + a2 + 1) Rc, one power less
         L.WdE[108 + a * 6 + 3 + a2] = (Real)(ca * cb / (double)(a + a2 + 1)) * (Real)(a + a2 + 1);
       }
-      {  // lt[0..3]: phase H (18x18 block of the condensed system); lt[4]: value recursion of phase R2
+      {  // lt[0..3], lt[6..8]: phase H (18x18 block of the condensed system); lt[4]: value recursion of phase R2
+        // All fields are BYTE offsets, ready for the address: a bit-field extract each, no shift, no multiply.
         const int l62 = lane < 63 ? lane : 62;  // lane 63 redoes lane 62
         const int pr = l62 / 3, d = l62 % 3;
         const int i = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);
         const int i2 = i + pr - (6 * i - (i * (i - 1)) / 2);
         const int p = 3 * i + d;
         const int hasq = i >= 3 ? 1 : 0;
-        L.lt[0][lane] = i | (i2 << 3) | (d << 6) | (hasq << 8) | ((hasq ? (i - 3) * 3 + (i2 - 3) : 0) << 9) |
-                        ((hasq ? i + i2 - 5 : 0) << 13);
-        for (int d2 = 0; d2 < 3; d2++) {
+        const int e8 = (int)sizeof(Real), a8 = (int)sizeof(Acc);
+        // byte offsets of We[.][i], We[.][i2], dl[.][d]; index of the jerk Gram coefficient (Rc[9] = 0 for pairs without one)
+        L.lt[0][lane] = (we_idx(0, i) * e8) | ((we_idx(0, i2) * e8) << 10) | ((dl_idx(0, d) * a8) << 20) |
+                        ((hasq ? (i - 3) * 3 + (i2 - 3) : 9) << 28);
+        for (int t = 0; t < 3; t++) {  // the lane walks the column axes d2 = d, d + 1, d + 2 (mod 3): the first one is its own
+          const int d2 = (d + t) % 3;
           const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
           const int sidx = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);  // xx,xy,xz,yy,yz,zz
           const int q = 3 * i2 + d2;
           // [Hxu; Huu] is one 19x10 block behind Hxx: entry (p, q >= 9) sits at 81 + 10 p + (q - 9)
-          const int o1 = q < 9 ? p * 9 + q : p * 10 + q + 72;
-          const int o2 = q < 9 ? q * 9 + p : (p < 9 ? o1 : q * 10 + p + 72);
-          L.lt[1 + d2][lane] = sidx | (q << 3) | (o1 << 8) | (o2 << 17) | ((p <= q ? 1 : 0) << 26) | ((d2 == d ? 1 : 0) << 27);
+          int o1 = q < 9 ? p * 9 + q : p * 10 + q + 72;
+          int o2 = q < 9 ? q * 9 + p : (p < 9 ? o1 : q * 10 + p + 72);
+          // i == i2: the lower triangle of the diagonal block belongs to the lane of the other axis - this lane's copy
+          // goes to a slot nobody reads (Hz[19], behind Hxx | Hxu | Huu | Hz[0..18])
+          if (p > q) o1 = o2 = 81 + 90 + 100 + 19;
+          // bits 12..14 (t == 0): the power of T of the jerk Gram term; bits 28..31: Sp[.][sidx] in units of 16 bytes
+          L.lt[1 + t][lane] = (o1 * a8) | ((t == 0 && hasq ? i + i2 - 5 : 0) << 12) | ((o2 * a8) << 16) |
+                              ((sp_idx(0, sidx) * a8 / 16) << 28);
+          L.lt16[2 + t][lane] = (unsigned short)((d * 19 + q) * a8);
         }
         const int l45 = lane < 45 ? lane : 44;  // upper triangle (a, c2 >= a) of the 9x9 value matrix
         int a = 0, rem = l45;
@@ -826,17 +901,39 @@ struct Wave {
           rem -= 9 - a;
           a++;
         }
-        L.lt[4][lane] = a | ((a + rem) << 4);
+        L.lt16[0][lane] = (unsigned short)(a | ((a + rem) << 4));
         {  // lt[5]: phase S roles (lanes >= 54 redo lane 53)
           const int l54 = lane < 54 ? lane : 53;
           const bool isS = l54 < 36;
           const int e = l54 % 6, j = isS ? l54 / 6 : (l54 - 36) / 3;
           const int d0 = isS ? ((e < 3) ? 0 : (e < 5 ? 1 : 2)) : (l54 - 36) % 3;
           const int d1 = isS ? ((e < 3) ? e : (e < 5 ? e - 2 : 2)) : 0;
-          const int dst = isS ? l54 : (int)(&L.hh[0] - &L.Sp[0]) + (l54 - 36);  // Sp, dl, Sd, hh are consecutive members
-          L.lt[5][lane] = d0 | (d1 << 2) | ((isS ? 1 : 0) << 4) | (j << 5) | (dst << 8);
+          const int dst = isS ? sp_idx(j, e) : (int)(&L.hh[0] - &L.Sp[0]) + ch_idx(j, d0);  // hh follows Sp in the same struct
+          L.lt16[1][lane] = (unsigned short)(d0 | (d1 << 2) | ((isS ? 1 : 0) << 4) | (j << 5) | (dst << 8));
         }
         if (lane < 5) L.ones[lane] = (Real)1;
+        if (lane < 5) L.z[19 + lane] = (Real)0;  // read (against zero weights) by phase T2's clamp-free term loop
+        {  // lt16[5]: phase T1 - the exponents of entries e = lane and min(lane + 64, 107) of We, as offsets into tp
+          int ex[2];
+          for (int pass = 0; pass < 2; pass++) {
+            const int e = (lane + 64 * pass < 108) ? lane + 64 * pass : 107;
+            const int x = e % 6 - ctrl_off(e / 6);
+            ex[pass] = x < 0 ? 0 : x;
+          }
+          L.lt16[5][lane] = (unsigned short)((ex[0] * (int)sizeof(Real)) | ((ex[1] * (int)sizeof(Real)) << 6));
+        }
+        {  // lt[7]: phase T2 (lane 63 redoes lane 62)
+          const int l62 = lane < 63 ? lane : 62;
+          const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
+          L.lt[7][lane] = ((cr * 6 + o) * (int)sizeof(Real)) | (((3 * o + d) * (int)sizeof(Real)) << 10) | (o << 17);
+        }
+        for (int pass = 0; pass < 3; pass++) {  // lt[4..6]: the VZ passes of phase R1
+          const int e = (lane + 64 * pass < 162) ? lane + 64 * pass : 161;
+          const int a = e / 18, q = e % 18;
+          const int i = q / 3, d = q % 3;
+          L.lt[4 + pass][lane] = ((a * 9 + d) * (int)sizeof(Acc)) | ((we_idx(15, i) * (int)sizeof(Real)) << 10) |
+                                 (((a * 19 + q) * (int)sizeof(Acc)) << 20);
+        }
       }
       if (lane < 5) {  // pseudo-planes (n, o) of the non-plane rows: +/-v - vmax, +/-a - amax, -T + 0.3 (DDP:1237-1279)
         Real* q = &L.pl[4 * Lds::kPMax + 4 * lane];
@@ -1271,6 +1368,28 @@ struct Wave {
     PLA(int, pkn, RPL);  // row descriptors of the prefetched knot / of the knot being processed
     PLA(int, pkc, RPL);
     LANES { prefetch(LV(pre), LV(pkn), 0, lane, buf, N - 1, Pn, false, infeas); }
+    // Phase T1 of a knot with segment time Tx: the powers of T (read by phase H) and We = WbE o T-powers (rows 0..14:
+    // control points, rows 15..17: Z = [F | G]; read by phases R1, H, G).  Neither is read after phase G, and the next
+    // knot's T has been in the prefetch registers for a whole trip by then: the tables of knot k - 1 are built at the
+    // end of knot k's trip, where their two LDS round trips overlap phase R2 instead of opening the next trip.
+    PLV(int, tw_t1);
+    auto t1_tables = [&](Real Tx) {
+      const Real Tx2 = DDP_UNIFORM_R(Tx * Tx), Tx4 = DDP_UNIFORM_R(Tx2 * Tx2);
+      LANES { L.tp[lane & 7] = pow3(Tx, Tx2, Tx4, lane & 7); }
+      WSYNC();  // one wave: the LDS unit executes its instructions in order, the powers are there for the reads below
+      LANES {
+        // We[e] = WbE[e] * T^ex(e): the power comes from the eight-entry table just written (per-lane byte offsets
+        // from lt16[5]) instead of a select chain per entry
+        const int wt = LV(tw_t1);
+        const int e1 = lane + 64 < 108 ? lane + 64 : 107;
+        const Real w0 = L.WbE[lane], w1 = L.WbE[e1];
+        const Real p0 = *byte_at(L.tp, wt & 63), p1 = *byte_at(L.tp, wt >> 6);
+        DDP_LOADS_ISSUED();
+        const int r0 = (lane * 43) >> 8, r1 = (e1 * 43) >> 8;  // row = e / 6 (e < 108)
+        L.We[we_idx(r0, lane - 6 * r0)] = w0 * p0;  // WbE is 0 where the exponent would be negative
+        L.We[we_idx(r1, e1 - 6 * r1)] = w1 * p1;
+      }
+    };
 #pragma unroll 1
     for (int k_ = N - 1; k_ >= 0; k_--) {
       // the knot index is re-materialised every trip: as a visible induction variable it makes loop
@@ -1283,9 +1402,21 @@ struct Wave {
       PLA(Real, ry, RPL);
       PLA(Real, rc, RPL);
       PLA(Real, rr, RPL);  // r (feasible) or rhat (infeasible)
+      // Per-lane role descriptors (init_tables), each loaded ONE PHASE AHEAD of its use: a descriptor that is read in
+      // the phase that needs it puts a second LDS round trip (descriptor, then the operands it addresses) on the
+      // phase's critical path, and with three waves per SIMD those round trips are what the waves park on
+      PLV(int, tw_t2);
+      PLA(int, tw_r1, 3);
+      PLV(int, tw_s);
+      PLV(int, tw_h0);
+      PLA(int, tw_ho, 3);
+      PLA(int, tw_hv, 3);
+      PLV(int, tw_r2);
       DDP_MARK("B_L");
       // ---- L: this knot's data from the prefetch registers; issue the loads of the next knot
       LANES {
+        LV(tw_t1) = L.lt16[5][lane];
+        LV(tw_t2) = L.lt[7][lane];
         commit(LV(pre), lane, P, false);
         for (int i = 0; i < RPL; i++) {
           LV(rs)[i] = (Real)LV(pre).s[i];
@@ -1303,20 +1434,13 @@ struct Wave {
         LANES { prefetch(LV(pre), LV(pkn), same, lane, buf, k - 1, Pn, false, infeas); }
       }
       DDP_MARK("B_T1");
-      // ---- T1: powers of T, scaled value table, dynamics tables
-      const Real T2 = DDP_UNIFORM_R(T * T), T4 = DDP_UNIFORM_R(T2 * T2);
-      LANES {
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {  // rows 0..14: control points; rows 15..17: Z = [F | G]
-          const int e = (lane + 64 * pass < 108) ? lane + 64 * pass : 107;
-          const int cr = e / 6, i = e % 6, ex = i - ctrl_off(cr);
-          L.We[e] = L.WbE[e] * pow3(T, T2, T4, ex < 0 ? 0 : ex);  // WbE is 0 where ex < 0
-        }
-        L.tp[lane & 7] = pow3(T, T2, T4, lane & 7);
-      }
+      // ---- T1: powers of T, scaled value table, dynamics tables - done at the END of the previous knot's trip
+      // (t1_tables below phase R2), on the critical path of the sweep's first knot only
+      if (k_ == N - 1) t1_tables(T);
       WSYNC();
       DDP_MARK("B_T2");
       // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u (all lanes run all roles, clamped)
+      const Real T2 = DDP_UNIFORM_R(T * T), T4 = DDP_UNIFORM_R(T2 * T2);
       Real pw[6];  // T^j as wave-uniform operands
 #pragma unroll
       for (int j = 0; j < 6; j++) pw[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(T, T2, T4, j));
@@ -1324,18 +1448,21 @@ struct Wave {
         // One code path for 21 table rows x 3 axes (lanes 0..62, see ctrl_off()): rows 0..14 give the control
         // values and their d/dT; rows 15..17 give fT = (F' (x) I) x + (G' (x) I) u as the d/dT value
         // (DDP:1332); rows 18..20 give R u, R'u and R''u (DDP:1349-1355) as value, first and second derivative.
-        const int l62 = lane < 63 ? lane : 62;
-        const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
-        // summed over the exponent j = i - o (see fwd_pass, phase T): uniform powers, no table reads
+        // summed over the exponent j = i - o (see fwd_pass, phase T): uniform powers, no table reads.  lt[7]: byte
+        // offsets of the row's first live weight WbE[cr][o] and of z[3 o + d], and o; terms past the end of the
+        // row (j + o > 5) read a zero weight (WbE[108] = WdE[108] = 0) against a finite z (z[19..23] = 0)
+        const int w2 = LV(tw_t2);
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) LV(tw_r1)[pass] = L.lt[4 + pass][lane];
+        const int wbb = w2 & 1023, o = (w2 >> 17) & 3;
+        const Real* zb = byte_at(L.z, (w2 >> 10) & 127);
         Real v = 0, dv = 0, ddv = 0, z6[6], wb6[6], wd6[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-          const bool on = (j < 4) || (j + o < 6);  // o <= 2
-          const int i = on ? j + o : 5;
-          const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[cr * 6 + i];
-          z6[j] = L.z[3 * i + d];
-          wb6[j] = on ? wbv : (Real)0;
-          wd6[j] = on ? wdv : (Real)0;
+          const int wa = (j < 4 || j + o < 6) ? wbb + j * (int)sizeof(Real) : 108 * (int)sizeof(Real);
+          wb6[j] = *byte_at(L.WbE, wa);
+          wd6[j] = *byte_at(L.WdE, wa);
+          z6[j] = zb[3 * j];
         }
         DDP_LOADS_ISSUED();
 #pragma unroll
@@ -1361,6 +1488,7 @@ struct Wave {
       DDP_MARK("B_R1");
       // ---- R1: constraint rows -> D, g ; VZ = Vxx * Z
       LANES {
+        LV(tw_s) = L.lt16[1][lane];
         for (int i = 0; i < RPL; i++) {
           // every lane runs the row arithmetic (empty slots alias row 0); only the stores and the
           // running maxima are masked
@@ -1401,21 +1529,20 @@ struct Wave {
         }
 #pragma unroll
         for (int pass = 0; pass < 3; pass++) {  // VZ[a][q], q < 18: 162 three-term entries (idle lanes redo the last)
-          const int e = (lane + 64 * pass < 162) ? lane + 64 * pass : 161;
-          const int a = e / 18, q = e % 18;
-          const int i = q / 3, d = q % 3;
+          const int wz = LV(tw_r1)[pass];  // byte offsets: V[a][d] | We[row 15][i] << 10 | VZ[a][q] << 20 (loaded in phase T2)
+          const Acc* vp = byte_at(L.V, wz & 1023);
+          const Real* hp = byte_at(L.We, (wz >> 10) & 1023);
           Acc v3[3];
           Real h3[3];
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            v3[c] = L.V[a * 9 + 3 * c + d];
-            h3[c] = L.We[90 + c * 6 + i];
-          }
+          for (int c = 0; c < 3; c++) v3[c] = vp[3 * c];
+          h3[0] = hp[0];
+          ld2(hp + 1, h3[1], h3[2]);  // rows 16, 17
           DDP_LOADS_ISSUED();
           Acc acc = 0;
 #pragma unroll
           for (int c = 0; c < 3; c++) acc += v3[c] * h3[c];
-          L.VZ[a * 19 + q] = acc;
+          *byte_at(L.VZ, (wz >> 20) & 2047) = acc;
         }
         if (lane >= 34 && lane < 43) {  // the T column VZ[a][18] = V[a][:] . fT on lanes the third pass leaves idle
           const int a = lane - 34;
@@ -1439,23 +1566,40 @@ struct Wave {
       // removes the exec-mask bookkeeping of role branches.
       LANES {
         {  // lanes 0..35: S_j[d0][d1] = sum_q D_(jP+q) n_q[d0] n_q[d1]; lanes 36..53: h_j[d0] = sum_q g_(jP+q) n_q[d0] * 1
-          const int ws = L.lt[5][lane];  // d0 | d1 << 2 | isS << 4 | j << 5 | destination (doubles from Sp[0]) << 8
+          const int ws = LV(tw_s);  // (loaded in phase R1) d0 | d1 << 2 | isS << 4 | j << 5 | destination (doubles from Sp[0]) << 8
           const bool isS = (ws >> 4) & 1;
           const Acc* w = (isS ? L.drow : L.grow) + ((ws >> 5) & 7) * P;
           const Real* n0 = &L.pl[ws & 3];
           const Real* nf = isS ? &L.pl[(ws >> 2) & 3] : &L.ones[0];
           const int fstep = isS ? 4 : 0;
           Acc acc = 0;
+          int q = 0;
+#pragma unroll 1
+          for (; q + 6 <= P; q += 6) {  // six planes per trip: eighteen loads in flight before the first FMA (P >= 6 for every
+                                        // corridor the planner produces: a polytope of its decomposition has at least six faces)
+            Acc w6[6];
+            Real a6[6], f6[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+              w6[u] = w[q + u];
+              a6[u] = n0[4 * (q + u)];
+              f6[u] = nf[fstep * (q + u)];
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int u = 0; u < 6; u++) acc += w6[u] * a6[u] * f6[u];
+          }
 #pragma unroll 2
-          for (int q = 0; q < P; q++) acc += w[q] * n0[4 * q] * nf[fstep * q];
+          for (; q < P; q++) acc += w[q] * n0[4 * q] * nf[fstep * q];
           (&L.Sp[0])[(ws >> 8) & 255] = acc;
         }
         {  // velocity / acceleration rows: +/- pairs
           const int l27 = lane < 27 ? lane : 26;
           const int rp = 6 * P + (l27 < 15 ? l27 : 15 + l27);  // 6P + l | 6P + 30 + (l - 15)
           const int rm = rp + (l27 < 15 ? 15 : 12);
-          L.dl[l27] = L.drow[rp] + L.drow[rm];
-          L.hh[18 + l27] = L.grow[rp] - L.grow[rm];
+          const int cp9 = (l27 * 11) >> 5, d9 = l27 - 3 * cp9;  // l27 = 3 cp9 + axis
+          L.dl[dl_idx(cp9, d9)] = L.drow[rp] + L.drow[rm];
+          L.hh[ch_idx(6 + cp9, d9)] = L.grow[rp] - L.grow[rm];
         }
         L.last[0] = L.drow[nc - 1];
         L.last[1] = L.grow[nc - 1];
@@ -1464,16 +1608,22 @@ struct Wave {
       DDP_MARK("B_S2");
       // ---- S2: Sd = S_cr * dval[cr]
       LANES {
+        LV(tw_h0) = L.lt[0][lane];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          LV(tw_ho)[t] = L.lt[1 + t][lane];
+          LV(tw_hv)[t] = L.lt16[2 + t][lane];
+        }
         const int l45 = lane < 45 ? lane : 44;
         const int cr = l45 / 3, d = l45 % 3;
         const int crp = cr < 6 ? cr : 5;
-        const Acc* S = &L.Sp[crp * 6];  // xx,xy,xz,yy,yz,zz
+        const Acc* S = &L.Sp[sp_idx(crp, 0)];  // entries xx,xy,xz,yy,yz,zz of control point crp, six apart
         const Real* dv = &L.dval[crp * 3];
         // row d of the symmetric 3x3: (0,1,2) | (1,3,4) | (2,4,5)
         const int i0 = d, i1 = d == 0 ? 1 : (d == 1 ? 3 : 4), i2 = d == 2 ? 5 : (d == 1 ? 4 : 2);
-        const Acc pos = S[i0] * dv[0] + S[i1] * dv[1] + S[i2] * dv[2];
-        const Acc oth = L.dl[l45 < 18 ? 0 : l45 - 18] * L.dval[l45];
-        L.Sd[l45] = cr < 6 ? pos : oth;
+        const Acc pos = S[6 * i0] * dv[0] + S[6 * i1] * dv[1] + S[6 * i2] * dv[2];
+        const Acc oth = L.dl[dl_idx(cr < 6 ? 0 : cr - 6, d)] * L.dval[l45];
+        L.Sd[ch_idx(cr, d)] = cr < 6 ? pos : oth;
       }
       WSYNC();
       DDP_MARK("B_H");
@@ -1483,19 +1633,21 @@ struct Wave {
       // operands are loaded once for three entries, and the velocity / acceleration rows (which only touch
       // d2 == d) need no second pass over the stored block.
       LANES {
-        const int w0 = L.lt[0][lane];  // i | i2 << 3 | d << 6 | hasq << 8 | Rc index << 9 | T-power index << 13
-        const int i = w0 & 7, i2 = (w0 >> 3) & 7, d = (w0 >> 6) & 3;
+        const int w0 = LV(tw_h0);  // (loaded in phase S2) byte offsets of We[.][i] | We[.][i2] << 10 | dl[.][d] << 20; Rc index << 28
+        const Real* Wi = byte_at(L.We, w0 & 1023);
+        const Real* Wi2 = byte_at(L.We, (w0 >> 10) & 1023);
+        const Acc* dld = byte_at(L.dl, (w0 >> 20) & 255);
         Acc ww[6], adv = 0;
         Real hh3[3];
         {
           Real w1[6], w2[6];
 #pragma unroll
-          for (int cr = 0; cr < 6; cr++) {
-            w1[cr] = L.We[cr * 6 + i];
-            w2[cr] = L.We[cr * 6 + i2];
+          for (int cr = 0; cr < 6; cr += 2) {
+            ld2(Wi + cr, w1[cr], w1[cr + 1]);
+            ld2(Wi2 + cr, w2[cr], w2[cr + 1]);
           }
-#pragma unroll
-          for (int c = 0; c < 3; c++) hh3[c] = L.We[90 + c * 6 + i];
+          hh3[0] = Wi[15];
+          ld2(Wi + 16, hh3[1], hh3[2]);
           DDP_LOADS_ISSUED();
 #pragma unroll
           for (int cr = 0; cr < 6; cr++) {
@@ -1504,63 +1656,74 @@ struct Wave {
           }
         }
 #pragma unroll
-        for (int part = 0; part < 3; part++) {  // three batches of nine operands keep the live set small
-          Real w1[3], w2[3];
-          Acc dl3[3];
+        for (int part = 0; part < 3; part++) {  // the nine velocity / acceleration control points in batches of 4, 4, 1
+          Real w1[4], w2[4];
+          Acc dl4[4];
+          if (part < 2) {
 #pragma unroll
-          for (int c3 = 0; c3 < 3; c3++) {
-            const int cr = 3 * part + c3;
-            w1[c3] = L.We[(cr + 6) * 6 + i];
-            w2[c3] = L.We[(cr + 6) * 6 + i2];
-            dl3[c3] = L.dl[cr * 3 + d];
+            for (int c2 = 0; c2 < 4; c2 += 2) {
+              ld2(Wi + 6 + 4 * part + c2, w1[c2], w1[c2 + 1]);
+              ld2(Wi2 + 6 + 4 * part + c2, w2[c2], w2[c2 + 1]);
+              ld2(dld + 4 * part + c2, dl4[c2], dl4[c2 + 1]);
+            }
+          } else {
+            w1[0] = Wi[14];
+            w2[0] = Wi2[14];
+            dl4[0] = dld[8];
           }
           DDP_LOADS_ISSUED();
 #pragma unroll
-          for (int c3 = 0; c3 < 3; c3++) adv += w1[c3] * w2[c3] * dl3[c3];
-          DDP_PIN(adv);  // or the FMAs sink below the later batches' loads and all 27 operands stay live
+          for (int c2 = 0; c2 < (part < 2 ? 4 : 1); c2++) adv += w1[c2] * w2[c2] * dl4[c2];
+          DDP_PIN(adv);  // or the FMAs sink below the later batches' loads and all operands stay live
         }
         adv *= sig;
-        const bool hasq = (w0 >> 8) & 1;
-        const Real rc1 = L.Rc[(w0 >> 9) & 15], tp1 = L.tp[(w0 >> 13) & 7];
+        Acc* Hb = L.Hxx;  // Hxx | Hxu | Huu | Hz are consecutive members: byte offsets from Hxx[0] (see init_tables)
 #pragma unroll
-        for (int d2 = 0; d2 < 3; d2++) {
-          const int wd = L.lt[1 + d2][lane];  // S index | q << 3 | o1 << 8 | o2 << 17 | (p <= q) << 26 | (d2 == d) << 27
-          const int sidx = wd & 7, q = (wd >> 3) & 31;
+        for (int t = 0; t < 3; t++) {  // column axis d2 = (d + t) mod 3: t == 0 is the lane's own axis
+          const int wo = LV(tw_ho)[t], wv = LV(tw_hv)[t];
+          const Acc* vzq = byte_at(L.VZ, wv);
+          const Acc* sps = byte_at(L.Sp, ((unsigned)wo >> 24) & 0xf0);
           Acc sp6[6], vz3[3];
 #pragma unroll
-          for (int cr = 0; cr < 6; cr++) sp6[cr] = L.Sp[cr * 6 + sidx];
+          for (int cr = 0; cr < 6; cr += 2) ld2(sps + cr, sp6[cr], sp6[cr + 1]);
 #pragma unroll
-          for (int c = 0; c < 3; c++) vz3[c] = L.VZ[(3 * c + d) * 19 + q];
+          for (int c = 0; c < 3; c++) vz3[c] = vzq[3 * c * 19];
+          // quu (DDP:1349-1355): w_snap Rc T^(i + i2 - 5) on the lane's own axis; Rc[9] = 0 where the pair has none
+          Real rc1 = 0, tp1 = 0;
+          if (t == 0) {
+            rc1 = L.Rc[(unsigned)w0 >> 28];
+            tp1 = L.tp[(wo >> 12) & 7];
+          }
           DDP_LOADS_ISSUED();
           Acc ada = 0, zvz = 0;
 #pragma unroll
           for (int cr = 0; cr < 6; cr++) ada += ww[cr] * sp6[cr];
 #pragma unroll
           for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
-          const bool dd = (wd >> 27) & 1;
-          const Acc quu = (hasq && dd) ? wsn * rc1 * tp1 : (Acc)0;
+          const Acc quu = (t == 0) ? wsn * rc1 * tp1 : (Acc)0;
           Acc v = zvz + quu + sig * ada;
-          v = dd ? v + adv : v;
-          // Hxx | Hxu | Huu are consecutive members: element offsets from Hxx[0] (see init_tables)
-          Acc* Hb = L.Hxx;
-          if ((wd >> 26) & 1) {  // p <= q; i == i2: the lower triangle of the diagonal block belongs to the lane of the other axis
-            Hb[(wd >> 8) & 511] = v;
-            Hb[(wd >> 17) & 511] = v;
-          }
+          if (t == 0) v = v + adv;  // the velocity / acceleration rows only couple equal axes
+          *byte_at(Hb, wo & 0xfff) = v;
+          *byte_at(Hb, (wo >> 16) & 0xfff) = v;
         }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
           const int p = lane < 18 ? lane : lane - 18;
           const int i = p / 3, d = p % 3;
-          const Acc* vec = lane < 18 ? L.Sd : L.hh;
+          const Acc* vec = (lane < 18 ? L.Sd : L.hh) + ch_idx(0, d);
+          const Real* Wc = &L.We[we_idx(0, i)];
           Acc acc = 0;
+          Real z3[3];  // Z[.][i]: rows 15..17
           {
-            Real w1[15];
-            Acc v15[15];
+            Real w1[16];
+            Acc v15[16];
 #pragma unroll
-            for (int cr = 0; cr < 15; cr++) {
-              w1[cr] = L.We[cr * 6 + i];
-              v15[cr] = vec[cr * 3 + d];
+            for (int cr = 0; cr < 14; cr += 2) {
+              ld2(Wc + cr, w1[cr], w1[cr + 1]);
+              ld2(vec + cr, v15[cr], v15[cr + 1]);
             }
+            ld2(Wc + 14, w1[14], z3[0]);  // rows 14 and 15
+            ld2(Wc + 16, z3[1], z3[2]);
+            v15[14] = vec[14];
             DDP_LOADS_ISSUED();
 #pragma unroll
             for (int cr = 0; cr < 15; cr++) acc += w1[cr] * v15[cr];
@@ -1568,7 +1731,7 @@ struct Wave {
           if (lane < 18) {
             Acc zvz = 0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) zvz += L.We[90 + c * 6 + i] * L.VZ[(3 * c + d) * 19 + 18];
+            for (int c = 0; c < 3; c++) zvz += z3[c] * L.VZ[(3 * c + d) * 19 + 18];
             const Acc v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Acc)0) + sig * acc;
             if (p < 9) {
               L.Hxu[p * 10 + 9] = v;
@@ -1579,7 +1742,7 @@ struct Wave {
           } else {
             Acc zv = 0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) zv += L.We[90 + c * 6 + i] * L.Vx[3 * c + d];
+            for (int c = 0; c < 3; c++) zv += z3[c] * L.Vx[3 * c + d];
             L.Hz[p] = ((i >= 3) ? wsn * L.Ru[p - 9] : (Acc)0) + zv + acc;
           }
         }
@@ -1590,7 +1753,8 @@ struct Wave {
         LANES {
           const int t = lane < 45 ? lane : 44;
           const int a = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
-          const Acc dv = L.dval[t], sd = L.Sd[t], hv = L.hh[t];
+          const int tr = (t * 43) >> 7, td = t - 3 * tr;  // t = 3 row + axis
+          const Acc dv = L.dval[t], sd = L.Sd[ch_idx(tr, td)], hv = L.hh[ch_idx(tr, td)];
           const Acc ft = L.fT[a], vzt = L.VZ[a * 19 + 18], vxa = L.Vx[a];
           const Acc zu = L.z[9 + a], r2 = L.Rppu[a], r1 = L.Rpu[a];
           DDP_LOADS_ISSUED();
@@ -1664,17 +1828,22 @@ struct Wave {
       }
       // Back substitution L^T X = [y | Y] in the right-hand-side lanes: L[j][i] (j > i) is entry i of matrix lane j,
       // again a row broadcast folded into the FMA.  The lanes carry Z = -X, the gains themselves ([ku | Ku] = -X,
-      // DDP:561-564, 607-609):  x_i = (y_i - sum L_ji x_j) / L_ii  <=>  z_i = (y_i + sum L_ji z_j) * (-1 / L_ii) - the
-      // same products and sums in the same order, every intermediate the exact negative or the same value.
-      static_for_down<9, 0>([&](auto II) {
-        constexpr int i = II;
+      // DDP:561-564, 607-609):  x_i = (y_i - sum L_ji x_j) / L_ii  <=>  z_i = (y_i + sum L_ji z_j) * (-1 / L_ii).
+      // Column-oriented: as soon as z_j is final it is folded into EVERY unfinished row i < j (nine, eight, ...
+      // independent FMAs), so the serial chain is one FMA and one multiply per row instead of the whole row sum -
+      // the order Eigen's own triangular solve uses.
+      LANES_AGAIN(lane_c) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) LV(xs)[i] = LV(ls)[i];
+      }
+      static_for_down<9, 0>([&](auto JJ) {
+        constexpr int j = JJ;
         LANES_AGAIN(lane_c) {
-          Acc acc = LV(ls)[i];
-          static_for<i + 1, 10>([&](auto J) {
-            constexpr int j = J;
-            ROW_FMA(acc, ls, i, j, LV(xs)[j]);
+          LV(xs)[j] = LV(xs)[j] * (-LV(rd)[j]);
+          static_for<0, j>([&](auto I) {
+            constexpr int i = I;
+            ROW_FMA(LV(xs)[i], ls, i, j, LV(xs)[j]);
           });
-          LV(xs)[i] = acc * (-LV(rd)[i]);
         }
       });
       LANES_AGAIN(lane_c) {
@@ -1691,11 +1860,12 @@ struct Wave {
       DDP_MARK("B_G");
       // ---- G: cu*ku per control row; products for the V recursion
       LANES {
+        LV(tw_r2) = L.lt16[0][lane];
         if (lane < 45) {
           int cr = lane / 3, d = lane % 3;
           Acc acc = L.dval[lane] * L.KU[9];
 #pragma unroll
-          for (int i = 3; i < 6; i++) acc += L.We[cr * 6 + i] * L.KU[(i - 3) * 3 + d];
+          for (int i = 3; i < 6; i++) acc += L.We[we_idx(cr, i)] * L.KU[(i - 3) * 3 + d];
           L.G[lane] = (Real)acc;
         } else if (lane == 45) {
           L.G[45] = (Real)L.KU[9];  // the T_min row: A_r . ku = -ku_T
@@ -1736,7 +1906,7 @@ struct Wave {
         // are identically  Vxx = Hxx - Y'Y - lam Ku'Ku,   Vx = Hx - Y'y - lam Ku'ku   (10-term dots instead
         // of two 10x10x9 products).  V / Vx are dead since phases R1 / H: overwritten in place.
         {
-          const int wv = L.lt[4][lane];
+          const int wv = LV(tw_r2);
           const int a = wv & 15, c2 = wv >> 4;
           const int aa = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
           // lanes 0..44: (colA, colB) = Y columns 1+a, 1+c2;  lanes 45..53: Y column 1+aa against y (column 0)
@@ -1779,6 +1949,10 @@ struct Wave {
             L.Vx[aa] = vnew;
           }
         }
+      }
+      if (k > 0) {  // phase T1 of the next knot (its record arrived a trip ago)
+        const Real Tnx = (sizeof(St) < sizeof(double)) ? (Real)RDLANE_M(pre, zh, 18) + (Real)RDLANE_M(pre, zl, 18) : (Real)RDLANE_M(pre, zh, 18);
+        t1_tables(Tnx);
       }
       WSYNC();
     }

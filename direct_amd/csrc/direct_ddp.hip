@@ -21,6 +21,10 @@
 using namespace direct;
 
 // ---- kernels ---------------------------------------------------------------------------------------
+#if defined(DDP_TIMING)
+#undef DDP_TICK_OBJ
+#define DDP_TICK_OBJ W  // the marks of the kernels' own code (ddp_wave.h: those inside Wave use *this)
+#endif
 #ifndef DDP_WAVES_F32
 #define DDP_WAVES_F32 1
 #endif
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
       if (threadIdx.x == 0) __hip_atomic_fetch_max(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  DDP_MARK("Z_E");
 }
 
 // stepwise interface: mode 1 = one backwardpass(), 2 = one forwardpass()

@@ -3,8 +3,9 @@ import ctypes as C, sys
 import numpy as np
 sys.path.insert(0, ".")
 from direct_amd import abi, problems, solver
-B, N = 4096, 100
-b = problems.make_batch("corridor", B, N, seed=1000)
+kind = sys.argv[1] if len(sys.argv) > 1 else "corridor"
+B, N = (int(sys.argv[2]) if len(sys.argv) > 2 else 4096), 100
+b = problems.make_batch(kind, B, N, seed=1000)
 s = solver.DdpSolver(B, N, b.p_max, np.float32)
 g0 = s.solve(abi.phase0_params(), b)
 b1 = b.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, b.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
