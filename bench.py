@@ -183,7 +183,8 @@ def dry_run(args, cfg, rank, world, torch, dist, distributed, problems):
     block = torch.from_numpy(np.concatenate([batch.T0[li], batch.seeds[li].ravel()]))
     bc, bidx, owner, blk = distributed.gather_best(lc, first + li, block)
     if rank == 0:
-        print(json.dumps({"metric": "ddp_iterations_per_sec", "value": None, "dry": True, "n_gpus": world,
+        print(json.dumps({"metric": "ddp_iterations_per_sec", "value": None, "dry": True, "n_gpus": world, "scaling": args.scaling,
+                          "batch_per_gpu": B,
                           "dist_world_size": dist.get_world_size() if world > 1 else 1,
                           "gather": {"best_cost": bc, "best_index": bidx, "owner": owner,
                                      "block_checksum": float(blk.double().sum())}}))
@@ -208,6 +209,10 @@ def main():
                     help="no GPU: exercise launch, rendezvous (gloo), sharding and the gather on placeholder costs; "
                          "prints a line with value null (CPU test of the N > 1 plumbing, never a measurement)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 = max(512, 256 x usable host threads), capped by the batch")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's batch PER GPU (default, SURVEY.md 8e); strong: a fixed TOTAL of --total corridors "
+                         "split evenly over the GPUs")
+    ap.add_argument("--total", type=int, default=131072, help="total corridors of a strong-scaling run (config 5's 131072)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -220,6 +225,10 @@ def main():
     for k in ("batch", "nseg", "kind", "dtype"):
         if getattr(args, k):
             cfg[k] = getattr(args, k)
+    if args.scaling == "strong":  # fixed total, B / G per rank (shards stay aligned to the generator's chunk of 256)
+        if args.total % (args.gpus * 256):
+            raise SystemExit("--total must be a multiple of 256 x --gpus")
+        cfg["batch"] = args.total // args.gpus
     custom = any(cfg[k] != CONFIGS[args.config][k] for k in ("batch", "nseg", "kind", "dtype"))
 
     import torch  # first: the library then binds to the HIP runtime torch has already loaded
@@ -289,6 +298,13 @@ def main():
         dt = float(tmax.item())
     if s.sched_error():
         raise SystemExit("the ticket scheduler reported an error: results are invalid")
+    launch = s.launch_info()  # how the timed launch was scheduled + the sweep work it executed
+    rank_kernel_ms = [float(np.mean(kernel_ms))]
+    if world > 1:  # stragglers show: every rank's mean kernel time
+        km = torch.zeros(world, dtype=torch.float64, device=dev)
+        km[rank] = rank_kernel_ms[0]
+        dist.all_reduce(km, op=dist.ReduceOp.SUM)
+        rank_kernel_ms = [float(v) for v in km.tolist()]
     iters_step = int(outs["fwd_passes"].sum().item())
     # the mode every trajectory's timed iterations ran in (taken now: the secondary solves reuse the output arrays)
     infeas_mask = outs["infeas_out"].cpu().numpy().astype(bool)
@@ -374,6 +390,19 @@ def main():
             step()
         torch.cuda.synchronize()
         sustained = (time.perf_counter() - ts) * 1e3 / 100
+    # secondary: the SAME fixed-iteration solve with host buffers in and out (what a reference-side caller of the C-ABI
+    # sees: H2D of the corridors, k_begin, the hot kernel, k_finish, D2H of the results) - PCIe-inclusive, never `value`
+    e2e = None
+    if not args.no_secondary:
+        s.solve(params, batch1)  # first call: page-in of the host arrays
+        te = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            he = s.solve(params, batch1)
+        e2e_s = (time.perf_counter() - te) / reps
+        e2e = {"iter_per_s": float(he.fwd_passes.sum() / e2e_s), "ms_per_call": e2e_s * 1e3,
+               "what": "direct_ddp_solve_batch on host (numpy) arrays: pageable H2D + k_begin + hot kernel + k_finish + D2H, "
+                       "mean of %d calls" % reps}
     # secondary: the same batch with the reference's natural exits (DDP:335-396)
     natural, hbm_copy = None, None
     if not args.no_secondary:
@@ -407,7 +436,7 @@ def main():
         line = {
             "metric": "ddp_iterations_per_sec", "value": value, "unit": "iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             # arithmetic type of the path: double for both storage types
             "dtype": "f64", "storage_dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": "%s%s: %d %s corridors per GPU, N=%d segments, %s storage, polynomial-segment IPDDP "
@@ -415,17 +444,31 @@ def main():
                                    % (cfg["name"], " (modified)" if custom else "", B,
                                       "free-space" if cfg["kind"] == "free" else "polyhedron", N, cfg["dtype"], FIXED_ITERS),
                        "batch_per_gpu": B, "n_seg": N, "fixed_iters": FIXED_ITERS, "parallelism": "shard%d" % world,
-                       "storage_dtype": cfg["dtype"], "kind": cfg["kind"], "devices": devices},
+                       "storage_dtype": cfg["dtype"], "kind": cfg["kind"], "devices": devices,
+                       "total_corridors": B * world,
+                       # what the library actually did with this launch (direct_ddp_last_launch_info, rank 0)
+                       "schedule": {k: launch[k] for k in ("dynamic", "shared_search", "pair_trials", "single_steps",
+                                                           "n_buffers", "resident_waves")}},
             # bound "hbm" is the roofline BASELINE.json's north_star stipulates; the counters say the kernel is
             # instruction-issue bound, which roofline_compute prices
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["traffic_bytes_per_launch"],
+                         "traffic_kind": None if traffic is None else "static: PMC counters of a committed profile of this "
+                                                                      "workload, not measured in this run",
                          "traffic_source": None if traffic is None else traffic["_file"],
                          "peak_measured_copy": hbm_copy, "frac_of_measured_copy": None if not hbm_copy else achieved / hbm_copy,
                          "kernel": "k_iterate_dyn (ticket-scheduled k_iterate)", "kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "infeasible_mode_frac": float(infeas_mask.mean())},
+                         "infeasible_mode_frac": float(infeas_mask.mean()),
+                         # sweep work the launch really executed (forward trials cut short by the fraction-to-boundary
+                         # rule count the knots they reached): the yardstick for the algorithmic figure above, which
+                         # assumes ONE full forward trial per iteration
+                         "bwd_knot_visits": launch["bwd_knot_visits"], "fwd_trial_knot_visits": launch["fwd_knot_visits"],
+                         "algorithmic_knot_iterations": int(batch1.n_seg.sum()) * FIXED_ITERS,
+                         "traffic_bytes_per_executed_knot_visit": None if traffic is None else
+                         traffic["traffic_bytes_per_launch"] / max(1, launch["bwd_knot_visits"] + launch["fwd_knot_visits"])},
+            "kernel_ms_per_rank": rank_kernel_ms,
             "iters_per_step_rank0": iters_step, "gather": gather,
         }
         if sq is not None and "f64_flops_per_ddp_iteration" in sq["derived"] and "f64_arith_frac_of_valu" in sq["derived"]:
@@ -440,6 +483,8 @@ def main():
                                                 "workload, all 64 lanes of an instruction counted) x this run's kernel rate"}
         if sustained is not None:
             line["sustained_ms_per_step_100"] = sustained
+        if e2e is not None:
+            line["e2e_host_buffers"] = e2e
         if natural is not None:
             line["natural_exit"] = natural
         if label is not None:

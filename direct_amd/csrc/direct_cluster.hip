@@ -201,12 +201,14 @@ __global__ void k_mark(Dev D) {
   const int e = blockIdx.y;
   const Elem* E = &D.el[e];
   if (!E->live) return;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= E->n_active * 26) return;
-  int p;
-  const int id = neighbour_id(D, D.active[(size_t)e * D.ccap + t / 26], t % 26, &p);
-  // map == 1 || use || invalid || inside -> skip (CS:332-338): all four are bits of the one flag byte
-  if (id >= 0 && D.flags[(size_t)e * D.G + id] == 0) atomicMin(&D.key[(size_t)e * D.G + id], t);
+  const int total = E->n_active * 26;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {  // grid stride: the launch
+                                                                                                 // does not depend on n_active
+    int p;
+    const int id = neighbour_id(D, D.active[(size_t)e * D.ccap + t / 26], t % 26, &p);
+    // map == 1 || use || invalid || inside -> skip (CS:332-338): all four are bits of the one flag byte
+    if (id >= 0 && D.flags[(size_t)e * D.G + id] == 0) atomicMin(&D.key[(size_t)e * D.G + id], t);
+  }
 }
 __global__ __launch_bounds__(256) void k_compact(Dev D) {
   __shared__ int wsum[4];
@@ -248,11 +250,13 @@ __device__ __forceinline__ float intbound_half(int ds) {
   if (ds == 0) return INFINITY;  // numeric_limits<double>::max() returned through float
   return (float)(0.5 / (double)(ds < 0 ? -ds : ds));
 }
-__device__ __forceinline__ int ray_blocked(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
+// RD(x, y, z) -> flag byte of a voxel (only F_INSIDE and F_OBS are looked at)
+template <typename RD>
+__device__ __forceinline__ int ray_blocked_t(const RD& rd, int cx, int cy, int cz, int target) {
   const int ex = px(target), ey = py(target), ez = pz(target);
-  if (fl[ex * D.max_yz + ey * D.max_z + ez] & F_INSIDE) return 0;  // only targets with inside_data == 0 are traced
+  if (rd(ex, ey, ez) & F_INSIDE) return 0;  // only targets with inside_data == 0 are traced
   const int mx = cx / 2 + (ex >> 1), my = cy / 2 + (ey >> 1), mz = cz / 2 + (ez >> 1);
-  if (fl[mx * D.max_yz + my * D.max_z + mz] & F_INSIDE) return 0;  // "midpoint" inside the cube: skipped
+  if (rd(mx, my, mz) & F_INSIDE) return 0;  // "midpoint" inside the cube: skipped
   int x = cx, y = cy, z = cz;
   const int dx = ex - x, dy = ey - y, dz = ez - z;
   const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0), sz = (dz > 0) - (dz < 0);
@@ -274,10 +278,13 @@ __device__ __forceinline__ int ray_blocked(const Dev& D, const uint8_t* fl, int 
     // each axis makes exactly |d| steps before the end voxel is reached; a ray that float rounding made miss its
     // end would leave the map (the reference then reads outside its arrays): cut off, reported as clear
     if (--budget < 0) return 0;
-    const uint8_t f = fl[x * D.max_yz + y * D.max_z + z];
+    const unsigned f = rd(x, y, z);
     if (f & F_INSIDE) return 0;
     if (f & F_OBS) return 1;
   }
+}
+__device__ __forceinline__ int ray_blocked(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
+  return ray_blocked_t([&](int x, int y, int z) -> unsigned { return fl[x * D.max_yz + y * D.max_z + z]; }, cx, cy, cz, target);
 }
 
 // one workgroup per candidate.  full = 1 (kernel-level parity entry point): no early exit, every row is complete
@@ -361,6 +368,82 @@ __global__ __launch_bounds__(64) void k_resolve(Dev D, int dry) {
   }
 }
 
+// The sequential accept loop (CS:360-384) of one round, one wave per seed, with the candidate's row of the bit matrix
+// fetched ONE CANDIDATE AHEAD: the loop is a chain of dependent global loads otherwise (1.5 us per candidate).
+__global__ __launch_bounds__(64) void k_resolve_pipe(Dev D) {
+  extern __shared__ unsigned long long acc[];  // accepted-candidate bitset, kwords words
+  const int e = blockIdx.x, lane = threadIdx.x;
+  Elem* E = &D.el[e];
+  if (!E->live) return;
+  const int n_cand = E->n_cand, n_clu = E->n_cluster;
+  if (n_cand == 0) return;
+  for (int w = lane; w < D.kwords; w += 64) acc[w] = 0ull;
+  __syncthreads();
+  int count = 0, overflow = 0;
+  const int* cd = D.cand + (size_t)e * D.kcap;
+  const uint8_t* cc = D.can_clu + (size_t)e * D.kcap;
+  int* cl = D.cluster + (size_t)e * D.ccap;
+  int* ac = D.active + (size_t)e * D.ccap;
+  uint8_t* fl = D.flags + (size_t)e * D.G;
+  constexpr int kW = 4;  // row words per lane held in registers: candidates up to 64 * 64 * kW
+  auto load_row = [&](int i, unsigned long long* r, int& okc, int& pc) {
+    okc = cc[i];
+    pc = cd[i];
+    const unsigned long long* row = D.blocked + ((size_t)e * D.kcap + i) * D.kwords;
+    const int nw = (i + 63) / 64;
+#pragma unroll
+    for (int q = 0; q < kW; q++) {
+      const int w = lane + 64 * q;
+      r[q] = (okc && w < nw) ? row[w] : 0ull;  // rows of rejected candidates were never written
+    }
+  };
+  unsigned long long rn[kW];
+  int okn, pn;
+  load_row(0, rn, okn, pn);
+  for (int i = 0; i < n_cand; i++) {
+    unsigned long long r[kW];
+#pragma unroll
+    for (int q = 0; q < kW; q++) r[q] = rn[q];
+    int ok = okn;
+    const int p = pn;
+    if (i + 1 < n_cand) load_row(i + 1, rn, okn, pn);
+    if (ok) {
+      int hit = 0;
+#pragma unroll
+      for (int q = 0; q < kW; q++) {
+        const int w = lane + 64 * q;
+        if (w < D.kwords) hit |= (r[q] & acc[w]) != 0ull;
+      }
+      for (int w = lane + 64 * kW; w < (i + 63) / 64; w += 64)  // beyond the registers (more than 16384 candidates)
+        hit |= (D.blocked[((size_t)e * D.kcap + i) * D.kwords + w] & acc[w]) != 0ull;
+      ok = !__any(hit);
+    }
+    if (lane == 0) {
+      D.accept[(size_t)e * D.kcap + i] = (uint8_t)ok;
+      if (ok) {
+        acc[i >> 6] |= 1ull << (i & 63);
+        if (n_clu + count < D.ccap) { cl[n_clu + count] = p; ac[count] = p; }
+        else overflow = 1;
+      } else {
+        fl[px(p) * D.max_yz + py(p) * D.max_z + pz(p)] |= F_INVALID;  // CS:380-383
+      }
+    }
+    count += ok;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  overflow = __any(overflow);
+  if (lane == 0) {
+    if (overflow) { E->rtn = DIRECT_CLUSTER_OVERFLOW; E->live = 0; E->n_cluster = D.ccap; E->n_active = 0; }
+    else {
+      E->n_cluster = n_clu + count;
+      E->n_active = count;
+      if (count == 0) E->live = 0;  // CS:386-387
+      else E->iters += 1;           // CS:389
+    }
+  }
+}
+
 __global__ void k_emit(Dev D, int batch, int32_t* vertex_idx, int32_t* cluster_xyz, int32_t* cluster_num, int32_t* iters,
                        int32_t* rtn) {
   const int e = blockIdx.y;
@@ -402,6 +485,7 @@ struct direct_cluster_handle_s {
   uint8_t* map = nullptr;
   uint8_t* inside_tmp = nullptr;
   int* seeds = nullptr;
+  int32_t *st_vertex = nullptr, *st_xyz = nullptr, *st_num = nullptr, *st_iters = nullptr, *st_rtn = nullptr;  // device staging of host outputs
   bool have_map = false;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -452,6 +536,7 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
   A(&D.can_clu, B * D.kcap); A(&D.accept, B * D.kcap);
   A(&D.blocked, B * D.kcap * (size_t)D.kwords * sizeof(unsigned long long));
   A(&D.el, B * sizeof(Elem));
+  A(&h->st_vertex, B * 24 * 4); A(&h->st_xyz, B * (size_t)D.ccap * 12); A(&h->st_num, B * 4); A(&h->st_iters, B * 4); A(&h->st_rtn, B * 4);
   D.map = h->map;
   if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
     st = cfail(DIRECT_ERR_DEVICE, "hipEventCreate failed");
@@ -506,43 +591,36 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
     return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
   };
   CHIP_TRY(fetch());
-  // polytopeCluster_cpu (CS:295-392): one round per trip; two small read-backs per round size the launches
-  for (int round = 0; round < itr_cluster_max; round++) {
-    int max_active = 0, live = 0;
-    for (const Elem& E : el)
-      if (E.live) { live++; max_active = std::max(max_active, E.n_active); }
+  // polytopeCluster_cpu (CS:295-392).  No launch of a round depends on a count the round produces (grid-stride or
+  // capacity-sized kernels over device-resident counters; workgroups of finished seeds return at once), so the host enqueues rounds
+  // blindly, kRoundsPerCheck at a time, and only then looks whether any seed is still growing: one read-back per
+  // kRoundsPerCheck rounds instead of three per round (the reference's CUDA twin, cluster_server.cu:628-685, copies
+  // per round as well).
+  constexpr int kRoundsPerCheck = 4;
+  for (int round = 0; round < itr_cluster_max;) {
+    int live = 0;
+    for (const Elem& E : el) live += E.live ? 1 : 0;
     if (!live) break;
-    hipLaunchKernelGGL(k_mark, dim3((max_active * 26 + 255) / 256, batch), dim3(256), 0, h->stream, D);
-    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, h->stream, D);
-    CHIP_TRY(hipGetLastError());
-    CHIP_TRY(fetch());
-    int max_cand = 0;
-    for (const Elem& E : el)
-      if (E.live) max_cand = std::max(max_cand, E.n_cand);
-    if (max_cand > 0) {
-      hipLaunchKernelGGL(k_convex, dim3(max_cand, batch), dim3(256), 0, h->stream, D, 0);
-      hipLaunchKernelGGL(k_resolve, dim3(batch), dim3(64), (size_t)D.kwords * 8, h->stream, D, 0);
-      CHIP_TRY(hipGetLastError());
-      CHIP_TRY(fetch());
+    const int n = std::min(kRoundsPerCheck, itr_cluster_max - round);
+    for (int r = 0; r < n; r++) {
+      hipLaunchKernelGGL(k_mark, dim3(128, batch), dim3(256), 0, h->stream, D);
+      hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, h->stream, D);
+      // one workgroup per candidate SLOT: the slots beyond a seed's candidate count return at once (640 k empty
+      // workgroups cost ~0.1 ms; a persistent ticket kernel with the rays' voxels staged in LDS was built and measured
+      // 1.6 - 2 x slower: thousands of short workgroups balance the seeds' very different loads better, and the flag
+      // bytes of a round's rays live in L2 anyway)
+      hipLaunchKernelGGL(k_convex, dim3(D.kcap, batch), dim3(256), 0, h->stream, D, 0);
+      hipLaunchKernelGGL(k_resolve_pipe, dim3(batch), dim3(64), (size_t)D.kwords * 8, h->stream, D);
     }
+    CHIP_TRY(hipGetLastError());
+    round += n;
+    CHIP_TRY(fetch());
   }
   int32_t *dv = vertex_idx, *dc = cluster_xyz, *dn = cluster_num, *di = cluster_iters, *dr = rtn;
-  std::vector<void*> tmp;
-  auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); };
-  if (mem == DIRECT_MEM_HOST) {
-    auto dev = [&](int32_t* hostp, size_t bytes) -> int32_t* {
-      if (!hostp) return nullptr;
-      void* q = nullptr;
-      if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
-      tmp.push_back(q);
-      return (int32_t*)q;
-    };
-    dv = dev(vertex_idx, (size_t)batch * 24 * 4); dc = dev(cluster_xyz, (size_t)batch * D.ccap * 12);
-    dn = dev(cluster_num, (size_t)batch * 4); di = dev(cluster_iters, (size_t)batch * 4); dr = dev(rtn, (size_t)batch * 4);
-    if ((vertex_idx && !dv) || (cluster_xyz && !dc) || (cluster_num && !dn) || (cluster_iters && !di) || (rtn && !dr)) {
-      cleanup();
-      return cfail(DIRECT_ERR_DEVICE, "staging buffers");
-    }
+  auto cleanup = [&]() {};
+  if (mem == DIRECT_MEM_HOST) {  // host outputs are staged in buffers the handle owns (allocated once, in create)
+    dv = vertex_idx ? h->st_vertex : nullptr; dc = cluster_xyz ? h->st_xyz : nullptr; dn = cluster_num ? h->st_num : nullptr;
+    di = cluster_iters ? h->st_iters : nullptr; dr = rtn ? h->st_rtn : nullptr;
   }
   hipLaunchKernelGGL(k_emit, dim3(64, batch), dim3(256), 0, h->stream, D, batch, dv, dc, dn, di, dr);
   hipError_t e = hipGetLastError();
