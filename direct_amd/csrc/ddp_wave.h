@@ -25,7 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 namespace direct {
-using std::fabs; using std::fmax; using std::fmin; using std::log; using std::pow; using std::sqrt;
+using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::log; using std::pow; using std::sqrt;
 // The emulator also CHECKS what the device code merely assumes: a value passed through DDP_UNIFORM_* (a
 // v_readfirstlane on the GPU) must be the same on every lane of the enclosing LANES block, otherwise the
 // GPU silently uses lane 0's value for all of them.  emu_lane is the lane being emulated (64 outside blocks).
@@ -455,7 +455,7 @@ struct WaveLds {
   // per knot, both sweeps
   Real tp[8];             // powers of T
   Real z[kXS];
-  Real pl[4 * kPMax + 20];  // the knot's planes, then five pseudo-planes for the velocity / acceleration / T rows
+  alignas(16) Real pl[4 * kPMax + 20];  // the knot's planes, then five pseudo-planes for the velocity / acceleration / T rows
   Real val[48], G[48];
   union {
     struct {  // ---- backward sweep only
@@ -982,6 +982,31 @@ struct Wave {
     return k;
   }
   DDP_DEV RowK<Real> row_slot(int slot, int lane, int P) const { return row_unpack(row_pack(slot, lane, P)); }
+  // The row phases of the sweeps gather the operands of ALL their rows first (plane, three entries of the vector the
+  // row multiplies) and compute afterwards: one LDS round trip per phase instead of two or three per row.
+  struct Row3 {
+    Real a, b, c;
+  };
+  DDP_DEV RowK<Real> row_unpack2(int pk) const {  // the plane as two 16-byte loads
+    RowK<Real> k;
+    const Real* n = &L.pl[4 * (pk >> 16)];
+    ld2(n, k.n0, k.n1);
+    ld2(n + 2, k.n2, k.o);
+    k.r = (pk & 255) - 1;
+    k.a0 = (pk >> 8) & 255;
+    return k;
+  }
+  DDP_DEV Row3 row_ops(const Real* A, int pk) const {
+    const Real* p = A + ((pk >> 8) & 255);
+    Row3 v;
+    v.a = p[0];
+    v.b = p[1];
+    v.c = p[2];
+    return v;
+  }
+  // explicit fused operations in a fixed order: left to the compiler, the contraction of  n0 a + n1 b + n2 c  differs
+  // between instantiations of the same source (static and ticket-scheduled kernel), and with it the last bit
+  DDP_DEV Real row_dot(const RowK<Real>& k, const Row3& v) const { return fma(k.n2, v.c, fma(k.n1, v.b, k.n0 * v.a)); }
   // A_r . w
   DDP_DEV Real row_lin(const Real* A, const RowK<Real>& k) const {
     return k.n0 * A[k.a0] + k.n1 * A[k.a0 + 1] + k.n2 * A[k.a0 + 2];
@@ -1489,13 +1514,22 @@ struct Wave {
       // ---- R1: constraint rows -> D, g ; VZ = Vxx * Z
       LANES {
         LV(tw_s) = L.lt16[1][lane];
+        RowK<Real> rk1[RPL];
+        Row3 ov1[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; i++) {
+          rk1[i] = row_unpack2(LV(pkc)[i]);
+          ov1[i] = row_ops(L.val, LV(pkc)[i]);
+        }
+        DDP_LOADS_ISSUED();
+#pragma unroll
         for (int i = 0; i < RPL; i++) {
           // every lane runs the row arithmetic (empty slots alias row 0); only the stores and the
           // running maxima are masked
-          const RowK<Real> rk = row_unpack(LV(pkc)[i]);
+          const RowK<Real>& rk = rk1[i];
           const int r = rk.r;
           const bool in = r >= 0;
-          Real c = row_c(L.val, rk), s = LV(rs)[i], y = LV(ry)[i];
+          Real c = row_dot(rk, ov1[i]) + rk.o - (Real)B.k.shift, s = LV(rs)[i], y = LV(ry)[i];
           Real D, g, rv, frcp_reuse = (Real)0;
           if (infeas) {  // DDP:535-539, 554
             Real rm = s * y - mu;
@@ -1877,10 +1911,19 @@ struct Wave {
       LANES {
         GSt* ksg = SpU(sp.KS, k);
         GSt* kyg = SpU(sp.KY, k);
+        RowK<Real> rk2[RPL];
+        Row3 og2[RPL];
+#pragma unroll
         for (int i = 0; i < RPL; i++) {
-          const RowK<Real> rk = row_unpack(LV(pkc)[i]);
+          rk2[i] = row_unpack2(LV(pkc)[i]);
+          og2[i] = row_ops(L.G, LV(pkc)[i]);
+        }
+        DDP_LOADS_ISSUED();
+#pragma unroll
+        for (int i = 0; i < RPL; i++) {
+          const RowK<Real>& rk = rk2[i];
           const int r = rk.r;
-          const Real cuku = row_lin(L.G, rk);
+          const Real cuku = row_dot(rk, og2[i]);
           const Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
           if (infeas) {  // DDP:568, 571
             const Real y = LV(ry)[i];
@@ -2358,19 +2401,33 @@ struct Wave {
       LANES {
 #pragma unroll
         for (int t = 0; t < NT; t++) LV(bad)[t] = 0;
-        for (int i = 0; i < RPL; i++) {
-          // branch-free rows: empty slots alias row 0, their stores / reductions are masked
-          const RowK<Real> rk = row_unpack(LV(pkc)[i]);
-          const int r = rk.r;
-          const bool in = r >= 0;
-          const Real s = LV(rs)[i];
+        RowK<Real> rks_[RPL];
+        Row3 oo[RPL];
 #pragma unroll
-          for (int t = 0; t < NT; t++) {
-            if (tr[t].alive) {
-              typename Lds::FwdT& F = L.ft[t];
-              GSt* sn = SpU(sp.S[1 + t], k);
-              const Real az = row_lin(F.G, rk);
-              const Real cn = row_c(F.valn, rk);
+        for (int i = 0; i < RPL; i++) {
+          rks_[i] = row_unpack2(LV(pkc)[i]);
+          if (!kRowCache && !infeas) oo[i] = row_ops(L.val, LV(pkc)[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          if (tr[t].alive) {
+            Row3 og[RPL], ov[RPL];  // one trial's operands at a time: both trials' would not fit the register file
+#pragma unroll
+            for (int i = 0; i < RPL; i++) {
+              og[i] = row_ops(L.ft[t].G, LV(pkc)[i]);
+              ov[i] = row_ops(L.ft[t].valn, LV(pkc)[i]);
+            }
+            DDP_LOADS_ISSUED();
+            GSt* sn = SpU(sp.S[1 + t], k);
+#pragma unroll
+            for (int i = 0; i < RPL; i++) {
+              // branch-free rows: empty slots alias row 0, their stores / reductions are masked
+              const RowK<Real>& rk = rks_[i];
+              const int r = rk.r;
+              const bool in = r >= 0;
+              const Real s = LV(rs)[i];
+              const Real az = row_dot(rk, og[i]);
+              const Real cn = row_dot(rk, ov[i]) + rk.o - (Real)B.k.shift;
               Real snew;
               if (infeas) {  // DDP:680-687
                 GSt* yn = SpU(sp.Y[1 + t], k);
@@ -2388,7 +2445,7 @@ struct Wave {
               } else {  // DDP:694-703
                 // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
                 // once (phase R1) instead of every trial re-deriving them from the old control values
-                const Real co = kRowCache ? LV(rky)[i] : row_c(L.val, rk);
+                const Real co = kRowCache ? LV(rky)[i] : row_dot(rk, oo[i]) + rk.o - (Real)B.k.shift;
                 const Real q = kRowCache ? LV(ry)[i] : s * frcp(co);
                 snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - q * az);
                 LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
