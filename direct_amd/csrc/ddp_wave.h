@@ -753,6 +753,10 @@ struct Wave {
   // is issue-bound; with double storage the large configurations are HBM-bound and the trials
   // recompute, as the reference's forward pass does (DDP:696).
   static constexpr bool kRowCache = sizeof(St) < sizeof(double);
+  // Float storage halves the prefetch registers: its instantiations can afford to gather the operands of all rows (and
+  // the gains of phase D) in ONE batch of loads; with double storage the same batches spill inside the sweeps, and a
+  // spill reload waits for every outstanding load, the HBM prefetch included
+  static constexpr bool kWide = sizeof(St) < sizeof(double) && RPL <= 2;
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
     St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
@@ -990,8 +994,15 @@ struct Wave {
   DDP_DEV RowK<Real> row_unpack2(int pk) const {  // the plane as two 16-byte loads
     RowK<Real> k;
     const Real* n = &L.pl[4 * (pk >> 16)];
-    ld2(n, k.n0, k.n1);
-    ld2(n + 2, k.n2, k.o);
+    if (kWide) {
+      ld2(n, k.n0, k.n1);
+      ld2(n + 2, k.n2, k.o);
+    } else {  // (16-byte loads want four consecutive registers: one more constraint where there are none to spare)
+      k.n0 = n[0];
+      k.n1 = n[1];
+      k.n2 = n[2];
+      k.o = n[3];
+    }
     k.r = (pk & 255) - 1;
     k.a0 = (pk >> 8) & 255;
     return k;
@@ -2227,6 +2238,10 @@ struct Wave {
       for (int t = 0; t < NT; t++) {
         LV(plog)[t].init(); LV(serr)[t] = 0; LV(nviol)[t] = 0;
         if (lane < 9) L.ft[t].xn[lane] = ldx(XpU(0, 0), lane);
+        if (lane < 5) {  // read against zero weights by phase T's clamp-free term loop
+          L.ft[t].zn[19 + lane] = (Real)0;
+          L.ft[t].dz[19 + lane] = (Real)0;
+        }
       }
     }
     WSYNC();
@@ -2259,7 +2274,9 @@ struct Wave {
       PLA(Real, ry, RPL);
       PLA(Real, rks, RPL);
       PLA(Real, rky, RPL);
+      PLV(int, tw_ft);
       LANES {
+        if (kWide) LV(tw_ft) = L.lt[7][lane];
         commit(LV(pre), lane, P, true);
         for (int i = 0; i < RPL; i++) {
           LV(rs)[i] = (Real)LV(pre).s[i];
@@ -2295,11 +2312,24 @@ struct Wave {
           PLV(Real, dxl);
           // x lanes: 0..8, and a second copy in lanes 16..24 of the ROW OF 16 that holds the ten u lanes (16..25): every
           // dx[c] then reaches the u lanes as a DPP row broadcast folded into the FMA, not through two v_readlane
+          PLA(Real, kr, 9);
+          PLV(Real, zlv);
+          PLV(Real, kfv);
           LANES {
             const int lx = lane & 15;
             const int l9 = lx < 9 ? lx : 8;
             const Real xv = F.xn[l9];
-            LV(dxl) = xv - L.z[l9];
+            const Real zv = L.z[l9];
+            // the u lanes' gains and old controls in the same batch of loads (lanes outside 16..25 read lane 25's)
+            const int a = lane < 16 ? 0 : (lane < 26 ? lane - 16 : 9);
+            if (kWide) {
+#pragma unroll
+              for (int c = 0; c < 9; c++) LV(kr)[c] = L.KUr[10 + a * 9 + c];
+              LV(zlv) = L.z[9 + a];
+              LV(kfv) = L.KUr[a];
+            }
+            DDP_LOADS_ISSUED();
+            LV(dxl) = xv - zv;
             if (lane < 9) {
               F.dz[lane] = LV(dxl);
               F.zn[lane] = xv;
@@ -2310,20 +2340,22 @@ struct Wave {
             LV(unew) = (Real)0;
             if (lane >= 16 && lane < 26) {
               const int a = lane - 16;
-              Real kr[9];
+              if (!kWide) {  // double storage: no registers to carry them across the block boundary
 #pragma unroll
-              for (int c = 0; c < 9; c++) kr[c] = L.KUr[10 + a * 9 + c];
-              const Real zl = L.z[9 + a], kf = L.KUr[a];
-              DDP_LOADS_ISSUED();
+                for (int c = 0; c < 9; c++) LV(kr)[c] = L.KUr[10 + a * 9 + c];
+                LV(zlv) = L.z[9 + a];
+                LV(kfv) = L.KUr[a];
+                DDP_LOADS_ISSUED();
+              }
               Real acc = 0;
               static_for<0, 9>([&](auto C) {
                 constexpr int c = C;
-                ROW_FMA_V(acc, dxl, c, kr[c]);
+                ROW_FMA_V(acc, dxl, c, LV(kr)[c]);
               });
               F.dz[9 + a] = acc;
               // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
               // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
-              const Real un = pair_round(zl + alpha[t] * kf + acc);
+              const Real un = pair_round(LV(zlv) + alpha[t] * LV(kfv) + acc);
               F.zn[9 + a] = un;
               LV(unew) = un;
             }
@@ -2345,8 +2377,14 @@ struct Wave {
           LANES {
             {  // lanes 0..44: control values; 45..53: x+ (rows of [F|G]); 54..62: jerk-cost products (rows of R)
               const int l62 = lane < 63 ? lane : 62;
-              const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
-              const int crd = cr < 15 ? cr : 14;  // the d/dT table has no rows for the dynamics / cost (unused there)
+              // lt[7] (loaded in phase L): byte offsets of the row's first live weight WbE[cr][o] and of entry 3 o + d of
+              // a knot record, and o - see phase T2 of the backward sweep; terms past the end of the row read a zero
+              // weight against entries 19..23 of the records, which the round's prologue has zeroed
+              const int w2 = kWide ? LV(tw_ft) : L.lt[7][lane];  // (double storage: no register to carry it from phase L)
+              const int wbb = w2 & 1023, o = (w2 >> 17) & 3;
+              const Real* zop = byte_at(L.z, (w2 >> 10) & 127);
+              const Real* dzp = byte_at(F.dz, (w2 >> 10) & 127);
+              const Real* znp = byte_at(F.zn, (w2 >> 10) & 127);
               Real dvo = 0, vn = 0, gf = 0, vo = 0;
               // Summed over the exponent j = i - o instead of the coefficient index i (same terms, same
               // order: the i < o terms have zero weight): the power T^j is then the same for every lane and
@@ -2357,14 +2395,12 @@ struct Wave {
 #pragma unroll
                 for (int jj = 0; jj < 3; jj++) {
                   const int j = 3 * half + jj;
-                  const bool on = (j < 4) || (j + o < 6);  // o <= 2
-                  const int i = on ? j + o : 5;
-                  const Real wbv = L.WbE[cr * 6 + i], wdv = L.WdE[crd * 6 + i];
-                  wb6[jj] = on ? wbv : (Real)0;
-                  wd6[jj] = on ? wdv : (Real)0;
-                  zo6[jj] = L.z[3 * i + d];
-                  dz6[jj] = F.dz[3 * i + d];
-                  zn6[jj] = F.zn[3 * i + d];
+                  const int wa = (j < 4 || j + o < 6) ? wbb + j * (int)sizeof(Real) : 108 * (int)sizeof(Real);
+                  wb6[jj] = *byte_at(L.WbE, wa);
+                  wd6[jj] = *byte_at(L.WdE, wa);
+                  zo6[jj] = zop[3 * j];
+                  dz6[jj] = dzp[3 * j];
+                  zn6[jj] = znp[3 * j];
                 }
                 DDP_LOADS_ISSUED();
 #pragma unroll
@@ -2401,58 +2437,106 @@ struct Wave {
       LANES {
 #pragma unroll
         for (int t = 0; t < NT; t++) LV(bad)[t] = 0;
-        RowK<Real> rks_[RPL];
-        Row3 oo[RPL];
+        if (kWide) {
+          RowK<Real> rks_[RPL];
+          Row3 oo[RPL];
 #pragma unroll
-        for (int i = 0; i < RPL; i++) {
-          rks_[i] = row_unpack2(LV(pkc)[i]);
-          if (!kRowCache && !infeas) oo[i] = row_ops(L.val, LV(pkc)[i]);
-        }
+          for (int i = 0; i < RPL; i++) {
+            rks_[i] = row_unpack2(LV(pkc)[i]);
+            if (!kRowCache && !infeas) oo[i] = row_ops(L.val, LV(pkc)[i]);
+          }
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-          if (tr[t].alive) {
-            Row3 og[RPL], ov[RPL];  // one trial's operands at a time: both trials' would not fit the register file
+          for (int t = 0; t < NT; t++) {
+            if (tr[t].alive) {
+              constexpr int kG = RPL;  // rows gathered per batch of loads
+              GSt* sn = SpU(sp.S[1 + t], k);
 #pragma unroll
-            for (int i = 0; i < RPL; i++) {
-              og[i] = row_ops(L.ft[t].G, LV(pkc)[i]);
-              ov[i] = row_ops(L.ft[t].valn, LV(pkc)[i]);
-            }
-            DDP_LOADS_ISSUED();
-            GSt* sn = SpU(sp.S[1 + t], k);
+              for (int i0 = 0; i0 < RPL; i0 += kG) {
+              Row3 og[kG], ov[kG];  // one trial's operands at a time: both trials' would not fit the register file
 #pragma unroll
-            for (int i = 0; i < RPL; i++) {
-              // branch-free rows: empty slots alias row 0, their stores / reductions are masked
-              const RowK<Real>& rk = rks_[i];
-              const int r = rk.r;
-              const bool in = r >= 0;
-              const Real s = LV(rs)[i];
-              const Real az = row_dot(rk, og[i]);
-              const Real cn = row_dot(rk, ov[i]) + rk.o - (Real)B.k.shift;
-              Real snew;
-              if (infeas) {  // DDP:680-687
-                GSt* yn = SpU(sp.Y[1 + t], k);
-                const Real y = LV(ry)[i];
-                const Real ynew = (Real)(St)(y + alpha[t] * LV(rky)[i] - az);
-                snew = (Real)(St)(s + alpha[t] * LV(rks)[i] + (s * frcp(y)) * az);
-                // bitwise, not short-circuit: the latter compiles to nested exec-masked branches per row
-                LV(bad)[t] |= (int)(in & ((ynew < omt * y) | (snew < omt * s)));
-                LV(plog)[t].mul(in ? ynew : (Real)1);
-                LV(serr)[t] += in ? fabs(cn + ynew) : (Real)0;
-                if (in) {
-                  yn[r] = (St)ynew;
-                  sn[r] = (St)snew;
-                }
-              } else {  // DDP:694-703
-                // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
-                // once (phase R1) instead of every trial re-deriving them from the old control values
-                const Real co = kRowCache ? LV(rky)[i] : row_dot(rk, oo[i]) + rk.o - (Real)B.k.shift;
-                const Real q = kRowCache ? LV(ry)[i] : s * frcp(co);
-                snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - q * az);
-                LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
-                LV(plog)[t].mul(in ? -cn : (Real)1);
-                if (in) sn[r] = (St)snew;
+              for (int i = i0; i < i0 + kG; i++) {
+                og[i - i0] = row_ops(L.ft[t].G, LV(pkc)[i]);
+                ov[i - i0] = row_ops(L.ft[t].valn, LV(pkc)[i]);
               }
-              LV(nviol)[t] += (int)(in & (cn >= (Real)2.0e-4));
+              DDP_LOADS_ISSUED();
+#pragma unroll
+              for (int i = i0; i < i0 + kG; i++) {
+                // branch-free rows: empty slots alias row 0, their stores / reductions are masked
+                const RowK<Real>& rk = rks_[i];
+                const int r = rk.r;
+                const bool in = r >= 0;
+                const Real s = LV(rs)[i];
+                const Real az = row_dot(rk, og[i - i0]);
+                const Real cn = row_dot(rk, ov[i - i0]) + rk.o - (Real)B.k.shift;
+                Real snew;
+                if (infeas) {  // DDP:680-687
+                  GSt* yn = SpU(sp.Y[1 + t], k);
+                  const Real y = LV(ry)[i];
+                  const Real ynew = (Real)(St)(y + alpha[t] * LV(rky)[i] - az);
+                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] + (s * frcp(y)) * az);
+                  // bitwise, not short-circuit: the latter compiles to nested exec-masked branches per row
+                  LV(bad)[t] |= (int)(in & ((ynew < omt * y) | (snew < omt * s)));
+                  LV(plog)[t].mul(in ? ynew : (Real)1);
+                  LV(serr)[t] += in ? fabs(cn + ynew) : (Real)0;
+                  if (in) {
+                    yn[r] = (St)ynew;
+                    sn[r] = (St)snew;
+                  }
+                } else {  // DDP:694-703
+                  // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
+                  // once (phase R1) instead of every trial re-deriving them from the old control values
+                  const Real co = kRowCache ? LV(rky)[i] : row_dot(rk, oo[i]) + rk.o - (Real)B.k.shift;
+                  const Real q = kRowCache ? LV(ry)[i] : s * frcp(co);
+                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - q * az);
+                  LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
+                  LV(plog)[t].mul(in ? -cn : (Real)1);
+                  if (in) sn[r] = (St)snew;
+                }
+                LV(nviol)[t] += (int)(in & (cn >= (Real)2.0e-4));
+              }
+              }
+            }
+          }
+        } else {  // double storage: row by row, both trials of a row together (the registers hold no more)
+          for (int i = 0; i < RPL; i++) {
+            // branch-free rows: empty slots alias row 0, their stores / reductions are masked
+            const RowK<Real> rk = row_unpack(LV(pkc)[i]);
+            const int r = rk.r;
+            const bool in = r >= 0;
+            const Real s = LV(rs)[i];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+              if (tr[t].alive) {
+                typename Lds::FwdT& F = L.ft[t];
+                GSt* sn = SpU(sp.S[1 + t], k);
+                const Real az = row_lin(F.G, rk);
+                const Real cn = row_c(F.valn, rk);
+                Real snew;
+                if (infeas) {  // DDP:680-687
+                  GSt* yn = SpU(sp.Y[1 + t], k);
+                  const Real y = LV(ry)[i];
+                  const Real ynew = (Real)(St)(y + alpha[t] * LV(rky)[i] - az);
+                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] + (s * frcp(y)) * az);
+                  // bitwise, not short-circuit: the latter compiles to nested exec-masked branches per row
+                  LV(bad)[t] |= (int)(in & ((ynew < omt * y) | (snew < omt * s)));
+                  LV(plog)[t].mul(in ? ynew : (Real)1);
+                  LV(serr)[t] += in ? fabs(cn + ynew) : (Real)0;
+                  if (in) {
+                    yn[r] = (St)ynew;
+                    sn[r] = (St)snew;
+                  }
+                } else {  // DDP:694-703
+                  // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
+                  // once (phase R1) instead of every trial re-deriving them from the old control values
+                  const Real co = kRowCache ? LV(rky)[i] : row_c(L.val, rk);
+                  const Real q = kRowCache ? LV(ry)[i] : s * frcp(co);
+                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - q * az);
+                  LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
+                  LV(plog)[t].mul(in ? -cn : (Real)1);
+                  if (in) sn[r] = (St)snew;
+                }
+                LV(nviol)[t] += (int)(in & (cn >= (Real)2.0e-4));
+              }
             }
           }
         }

@@ -63,7 +63,8 @@ def lib():
         L.direct_ddp_best_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p]
         L.direct_ddp_sched_error.argtypes = [C.c_void_p, C.c_void_p]
-        L.direct_ddp_last_launch_info.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "direct_ddp_last_launch_info"):  # absent from libraries of earlier rounds (tools/ab_libs.sh A/B runs)
+            L.direct_ddp_last_launch_info.argtypes = [C.c_void_p, C.c_void_p]
         L.direct_rccl_unique_id.argtypes = [C.c_void_p]
         L.direct_rccl_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.direct_rccl_comm_destroy.argtypes = [C.c_void_p]
