@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_configs.py -q 2>&1 | grep -E "^FAILED|passed|failed" | head -12
-echo -n "free f64 N=100 B=4096: "; python tools/prof_one.py free f64 4096 100 20 | tail -1
-echo -n "corridor f64 N=300 B=4096: "; python tools/prof_one.py corridor f64 4096 300 20 | tail -1
-python tools/ab_time.py free f32 5 4096 | tail -1
+bash tools/profile_round.sh r03 > gpurun_out/r03_profile.log 2>&1
+tail -3 gpurun_out/r03_profile.log
+for c in "r03_config3 corridor f32 4096 100 20" "r03_config4 corridor f64 16384 300 20" "r03_config5 corridor f32 16384 100 20"; do bash tools/pmc_config.sh $c 2>&1 | tail -1 | cut -c1-300; done
