@@ -390,7 +390,7 @@ constexpr int kMaxBuf = 12;  // iterate buffers: `cur` + one per concurrently ev
 template <typename Real>
 struct Batch {
   int B, nmax, pmax, ncs;  // ncs = row stride of S/Y/KS/KY (>= 6*pmax+55)
-  int fcap, nbuf, help_early, pad2;  // nbuf: iterate buffers in use (3, or kMaxBuf with the shared line search);
+  int fcap, nbuf, help_early, tail_thresh;  // nbuf: iterate buffers in use (3, or kMaxBuf with the shared line search);
                                      // help_early: single-step searches are open to helpers from step 0 on
   const int32_t* n_seg;
   const Real* x0;
@@ -413,6 +413,9 @@ struct Batch {
   TrajState* st;
   HelpSlot* help;  // [B], or null: every line search stays with its owner
   int* sched_err;  // the launch's sticky error flag (spin limits of the shared line search)
+  int* live;  // trajectories of the launch still in their outer loop (ticket scheduler; null otherwise): when no more
+              // than tail_thresh are left the line searches switch to single steps open from step 0 - few trajectories on
+              // many waves, the tail of a natural-exit launch (scheduling only)
   unsigned long long* visits;  // [2] knots executed by backward sweeps / by forward trials (observability; may be null)
   SolveConst k;
 };
@@ -2635,7 +2638,11 @@ struct Wave {
     double* filt = B.filt + (size_t)b * B.fcap * 2;
     // rounds: {0}, then the pairs (2r-1, 2r), r = 1..5, or the single steps r = 1..10 (few trajectories on many waves:
     // every step then finds a wave of its own)
-    const int pair = helper ? (last_round == 5 ? 1 : 0) : ((B.k.pair_trials && !infeas) ? 1 : 0);
+    int tail = 0;  // few trajectories left on many waves (see Batch::live)
+#if !defined(DIRECT_EMULATE)
+    if (!helper && hs != nullptr && B.live != nullptr) tail = a_load(B.live) <= B.tail_thresh ? 1 : 0;
+#endif
+    const int pair = helper ? (last_round == 5 ? 1 : 0) : ((B.k.pair_trials && !infeas && !tail) ? 1 : 0);
     const int share = (!helper && !infeas && hs != nullptr) ? 1 : 0;
     if (!helper) last_round = pair ? 5 : 10;
     Accept A;
@@ -2643,7 +2650,7 @@ struct Wave {
     A.stepsize = 0.0; A.cost = 0.0; A.costq = 0.0; A.logcost = 0.0; A.err = 0.0; A.sumlog = 0.0; A.errsum = 0.0;
     int r_eval = 0;  // owner: the first round whose results have not been judged yet
     int opened = 0;
-    if (share && !pair && B.k.pair_trials == 0 && B.help_early) {
+    if (share && !pair && (B.k.pair_trials == 0 || tail) && B.help_early) {
       // few trajectories on many waves: the search is open from step 0 on - the waves that would evaluate the later
       // steps have nothing else to do, and when step 0 is rejected the answer of steps 1 .. 10 is already there
       share_open(hs, cur, mu_d, tag, last_round, 0);

@@ -176,6 +176,8 @@ __global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B
     if (!help) {
       if (run) W.store_state();
       const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
+      if (run && fin && B.live != nullptr && threadIdx.x == 0)  // this chunk took the trajectory out of its outer loop
+        __hip_atomic_fetch_add(B.live, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       // max, not store: done_epoch only ever grows, and a trajectory that a timed-out waiter has retired
       // (kDoneBit | n_epochs, below) stays retired when its straggling chunk completes afterwards
@@ -334,6 +336,7 @@ struct direct_ddp_handle_s {
   int g_ranks = 0;
   // dynamic scheduling of k_iterate_dyn: [0] ticket, [1] error flag, [2..] done_epoch[max_batch]
   int* sched = nullptr;
+  int* live = nullptr;                   // [1] unfinished trajectories of the running launch (Batch::live)
   unsigned long long* visits = nullptr;  // [2] sweep-work counters of the last hot-kernel launch (direct_ddp_last_launch_info)
   direct_ddp_launch_info_t last_info = {};
   int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device
@@ -381,6 +384,7 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   B.help = nullptr;  // set by the dynamic launch only
   B.sched_err = h->sched + 1;
   B.visits = nullptr;  // set by launch_iterate_t (the hot-kernel launch only)
+  B.live = nullptr;    // set by the ticket-scheduled launch with a shared line search
   B.KU = (Real*)h->KU; B.KS = (Real*)h->KS; B.KY = (Real*)h->KY; B.filt = h->filt; B.st = h->st;
   SolveConst& k = B.k;
   k.max_vel = p.max_vel; k.max_acc = p.max_acc; k.w_snap = p.w_snap; k.w_term = p.w_terminal;
@@ -450,6 +454,11 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
         (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
         Bt.help = h->help;
         Bt.help_early = h->help_early;
+        // the launch's tail: when at most sched_slots / single_ratio trajectories are left (natural exits), their line
+        // searches go to single steps open from step 0, as a batch that small would from the start
+        (void)hipMemsetD32Async((hipDeviceptr_t)h->live, h->B, 1, h->stream);
+        Bt.live = h->live;
+        Bt.tail_thresh = h->single_ratio > 0 ? h->sched_slots / h->single_ratio : 0;
         li.shared_search = 1;
         li.single_steps = Bt.k.pair_trials ? 0 : 1;
       }
@@ -635,6 +644,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->best_idx, 16); A(&h->best_cost, 16);
   A(&h->sched, (B + 2) * sizeof(int));
   A(&h->visits, 2 * sizeof(unsigned long long));
+  A(&h->live, 16);
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
   if (const char* ev = getenv("DIRECT_DDP_PRIO")) h->sched_prio = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_PAIR")) h->pair_trials = atoi(ev);
