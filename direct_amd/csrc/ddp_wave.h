@@ -755,7 +755,10 @@ struct Wave {
   // That trades HBM traffic (two words per row and direction) for VALU work: right for float storage, where the kernel
   // is issue-bound; with double storage the large configurations are HBM-bound and the trials
   // recompute, as the reference's forward pass does (DDP:696).
-  static constexpr bool kRowCache = sizeof(St) < sizeof(double);
+#ifndef DDP_ROWCACHE
+#define DDP_ROWCACHE 1
+#endif
+  static constexpr bool kRowCache = DDP_ROWCACHE && sizeof(St) < sizeof(double);
   // Float storage halves the prefetch registers: its instantiations can afford to gather the operands of all rows (and
   // the gains of phase D) in ONE batch of loads; with double storage the same batches spill inside the sweeps, and a
   // spill reload waits for every outstanding load, the HBM prefetch included
