@@ -51,6 +51,10 @@ typedef enum {
   DIRECT_ERR_NO_DEVICE = 4    /* no gfx950 device visible: there is no CPU fallback */
 } direct_status_t;
 
+/* Storage type of every array at this boundary and of the solver's arrays in device memory; the arithmetic is double
+ * for both.  With DIRECT_F32 the handle keeps the ITERATE itself (states, polynomial coefficients, durations) as
+ * hi + lo float pairs internally, so that a float solve follows the double one to its exit;
+ * gains, slacks and duals are single floats. */
 typedef enum { DIRECT_F32 = 0, DIRECT_F64 = 1 } direct_dtype_t;
 typedef enum { DIRECT_MEM_HOST = 0, DIRECT_MEM_DEVICE = 1 } direct_mem_t;
 

@@ -14,8 +14,8 @@ s = open("/tmp/v2/direct_amd/csrc/ddp_wave.h").read()
 s = sub(s, "  int neg_time, nseg, nc0, npos;", "  int neg_time, nseg, nc0, npos;\n  long long cyc_bwd, cyc_fwd; int n_rounds, n_fetched;")
 s = sub(s, "    if (!helper) {\n      while (true) {  // DDP:297-310", "    long long t0_ = __builtin_readcyclecounter();\n    if (!helper) {\n      while (true) {  // DDP:297-310")
 s = sub(s, "    fwd_pass(helper);\n    if (helper) return;", "    long long t1_ = __builtin_readcyclecounter();\n    fwd_pass(helper);\n    if (helper) return;\n    long long t2_ = __builtin_readcyclecounter();\n    st.cyc_bwd += t1_ - t0_; st.cyc_fwd += t2_ - t1_;")
-s = sub(s, "      if (mine >= 0) {\n        if (pair && mine > 0)", "      if (mine >= 0) {\n        if (!helper) st.n_rounds++;\n        if (pair && mine > 0)")
-s = sub(s, "          if (!fetch_results(hs, r_eval, tag, o)) {", "          st.n_fetched++;\n          if (!fetch_results(hs, r_eval, tag, o)) {")
+s = sub(s, "      if (mine >= 0) {\n        if (nt == 2)", "      if (mine >= 0) {\n        if (!helper) st.n_rounds++;\n        if (nt == 2)")
+s = sub(s, "          if (!fetch_results(hs, r_eval, pair ? 2 * r_eval - 1 : r_eval, pair ? 2 : 1, tag, o)) {", "          st.n_fetched++;\n          if (!fetch_results(hs, r_eval, pair ? 2 * r_eval - 1 : r_eval, pair ? 2 : 1, tag, o)) {")
 s = sub(s, "    st.fwd_passes = 0;\n  }", "    st.fwd_passes = 0;\n    st.cyc_bwd = 0; st.cyc_fwd = 0; st.n_rounds = 0; st.n_fetched = 0;\n  }")
 open("/tmp/v2/direct_amd/csrc/ddp_wave.h", "w").write(s)
 h = open("/tmp/v2/direct_amd/csrc/direct_ddp.hip").read()

@@ -1,17 +1,20 @@
 #!/bin/bash
-# bench.py on BASELINE configs 3, 4, 5 (per-GPU shard) and config 2 at B = 16384 -> gpurun_out/rNN_configs.json
-R=${1:-r02}
-cd ${GRAFT_REPO_ROOT:-$PWD}
-mkdir -p gpurun_out
-{
-  echo "["
-  python bench.py --config 3 --no-cpu-baseline --no-secondary --steps 10; echo ","
-  python bench.py --config 4 --no-cpu-baseline --no-secondary --steps 4 --warmup 1; echo ","
-  python bench.py --config 5 --no-cpu-baseline --no-secondary --steps 6 --warmup 1; echo ","
-  python bench.py --config 2 --batch 16384 --no-cpu-baseline --no-secondary --steps 6 --warmup 1
-  echo "]"
-} > gpurun_out/${R}_configs.json 2> gpurun_out/${R}_configs.err
-python -c "
-import json; d=json.load(open('gpurun_out/${R}_configs.json'))
-for x in d: print(x['config']['workload'][:60], '%.3f M iter/s' % (x['value']/1e6), 'kernel %.1f ms' % x['roofline']['kernel_ms'], 'hbm frac %.3f' % x['roofline']['frac'])
-"
+# bench lines of the other single-GPU configurations + the cluster bench of a round (run through gpurun from the repo root):
+#   gpurun_out/rNN_configs.json, rNN_cluster_bench.json, rNN_cluster_kernel_stats.csv   usage: tools/configs_round.sh r03
+R=${1:-r03}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out; mkdir -p $OUT
+cd $ROOT; export PYTHONPATH=$ROOT
+python - > $OUT/${R}_configs.json 2> $OUT/${R}_configs.err <<PY
+import json, subprocess, sys
+out = {}
+for c in (3, 4, 5):
+    r = subprocess.run([sys.executable, "bench.py", "--config", str(c), "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    out["config%d" % c] = json.loads(lines[-1]) if lines else {"error": r.stderr[-500:]}
+print(json.dumps(out, indent=1))
+PY
+python tests/soak/cluster_bench.py 64 2>/dev/null | tail -1 > $OUT/${R}_cluster_bench.json
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/cst
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cst -o c -- python $ROOT/tests/soak/cluster_bench.py 64 > /dev/null 2>&1
+cp $(find /tmp/cst -name "*kernel_stats.csv" | head -1) $OUT/${R}_cluster_kernel_stats.csv
