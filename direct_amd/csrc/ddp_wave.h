@@ -1098,11 +1098,43 @@ struct Wave {
     const int infeas = DDP_UNIFORM_I(st.infeas);
     double qsum = 0.0;
     int neg = 0;
+    // The next knot's record and planes are loaded a knot ahead (registers), the dual rows of a knot at its top: the
+    // sweep used to expose a global-memory round trip per knot, and with do_roll it re-read from HBM the state it had
+    // just written (k_begin was 1.7 % of the benchmark's step).
+    PLV(Real, zr);
+    PLA(St, plr, 2);
+    int Pn = np_(0);
+    LANES {
+      LV(zr) = ldx(Xp(buf, 0), lane < 19 ? lane : 18);
+      const int pend = 4 * Pn - 1;
+      LV(plr)[0] = planes_(0)[lane < pend ? lane : pend];
+      LV(plr)[1] = planes_(0)[lane + 64 < pend ? lane + 64 : pend];
+    }
     for (int k = 0; k < N; k++) {
-      const int P = np_(k);
+      const int P = Pn;
+      PLA(Real, yv, RPL);
       LANES {
-        if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
-        for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
+        // x_k of a roll is what the previous knot produced - rounded as the store / load pair would round it
+        const bool rolled = do_roll && k > 0 && lane < 9;
+        if (lane < 19) L.z[lane] = rolled ? pair_round(L.ft[0].xnx[lane]) : LV(zr);
+        if (lane < 4 * P) L.pl[lane] = (Real)LV(plr)[0];
+        if (lane + 64 < 4 * P) L.pl[lane + 64] = (Real)LV(plr)[1];
+        if (infeas) {
+          const St* yk = Sp_(B.Y[buf], k);
+          for (int i = 0; i < RPL; i++) {
+            const int r = (row_pack(i, lane, P) & 255) - 1;
+            LV(yv)[i] = (Real)yk[r >= 0 ? r : 0];
+          }
+        }
+      }
+      if (k + 1 < N) {
+        Pn = np_(k + 1);
+        LANES {
+          LV(zr) = ldx(Xp(buf, k + 1), lane < 19 ? lane : 18);
+          const int pend = 4 * Pn - 1;
+          LV(plr)[0] = planes_(k + 1)[lane < pend ? lane : pend];
+          LV(plr)[1] = planes_(k + 1)[lane + 64 < pend ? lane + 64 : pend];
+        }
       }
       WSYNC();
       const Real T = L.z[18];
@@ -1118,14 +1150,13 @@ struct Wave {
       WSYNC();
       qsum += knot_cost(T, L.ft[0].qp);
       LANES {
-        const St* yk = Sp_(B.Y[buf], k);
         for (int i = 0; i < RPL; i++) {
           const RowK<Real> rk = row_slot(i, lane, P);
           const int r = rk.r;
           if (r >= 0) {
             Real c = row_c(L.val, rk);
             if (infeas) {
-              Real y = yk[r];
+              Real y = LV(yv)[i];
               LV(plog).mul(y);
               LV(serr) += fabs(c + y);
             } else {
