@@ -17,8 +17,9 @@ class Config(C.Structure):
 
 EXPORTS = ("direct_cluster_create", "direct_cluster_destroy", "direct_cluster_last_error", "direct_cluster_set_map",
            "direct_cluster_polygon_generation_batch", "direct_cluster_convex_test", "direct_cluster_last_ms",
-           "direct_cluster_set_stream")
+           "direct_cluster_set_stream", "direct_cluster_hull_planes_batch")
 CLUSTER_OK, CLUSTER_OVERFLOW, CLUSTER_BAD_SEED = 0, 1, 2
+HULL_OK, HULL_OVERFLOW, HULL_FLAT = 0, 1, 3
 _BOUND = False
 
 
@@ -36,6 +37,8 @@ def _lib():
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
         L.direct_cluster_last_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.direct_cluster_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.direct_cluster_hull_planes_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                                        C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
         _BOUND = True
     return L
 
@@ -93,6 +96,37 @@ class ClusterGenerator:
         _check(_lib().direct_cluster_convex_test(self.h, inside.ctypes.data, n, cand.ctypes.data, cluster.shape[0],
                                                  cluster.ctypes.data, clu.ctypes.data, cc.ctypes.data, acc.ctypes.data))
         return clu, cc[:n * (n - 1) // 2], acc
+
+    def hull_planes(self, resolution, map_lower, clusters=None, plane_capacity=256, vertex_capacity=1024, batch=None):
+        """getConvexPoly's hull + Polyhedron::hrep + polyHrep2Utils (poly_utils.cpp:301-389, 127-206) for a batch of
+        clusters.  clusters=None: those of the last polygon_generation, still on the device (`batch` of them);
+        otherwise a list of [n][3] voxel-index arrays.  -> dict(planes: list of [P][4], plane_int, vertices: list of
+        [V][3], center [B][3], degenerate, n_planes, n_vertices, rtn)"""
+        lower = np.ascontiguousarray(map_lower, np.float64)
+        if clusters is not None:
+            B = len(clusters)
+            xyz = np.zeros((B, self.ccap, 3), np.int32)
+            num = np.zeros(B, np.int32)
+            for b, c in enumerate(clusters):
+                c = np.ascontiguousarray(c, np.int32).reshape(-1, 3)
+                assert len(c) <= self.ccap
+                xyz[b, :len(c)] = c
+                num[b] = len(c)
+            px, pn = xyz.ctypes.data, num.ctypes.data
+        else:
+            B, px, pn = int(batch), None, None
+        pl = np.zeros((B, plane_capacity, 4), np.float64)
+        pi = np.zeros((B, plane_capacity, 4), np.int64)
+        vt = np.zeros((B, vertex_capacity, 3), np.float64)
+        ctr = np.zeros((B, 3), np.float64)
+        npl, nv, deg, rtn = (np.zeros(B, np.int32) for _ in range(4))
+        _check(_lib().direct_cluster_hull_planes_batch(self.h, B, abi.MEM_HOST, px, pn, float(resolution), lower.ctypes.data,
+                                                       int(plane_capacity), int(vertex_capacity), abi.MEM_HOST, pl.ctypes.data,
+                                                       pi.ctypes.data, npl.ctypes.data, vt.ctypes.data, nv.ctypes.data,
+                                                       ctr.ctypes.data, deg.ctypes.data, rtn.ctypes.data))
+        cut = lambda a, n, cap: [a[b, :min(int(n[b]), cap)].copy() for b in range(B)]
+        return dict(planes=cut(pl, npl, plane_capacity), plane_int=cut(pi, npl, plane_capacity),
+                    vertices=cut(vt, nv, vertex_capacity), center=ctr, degenerate=deg, n_planes=npl, n_vertices=nv, rtn=rtn)
 
     def set_stream(self, hip_stream):
         _check(_lib().direct_cluster_set_stream(self.h, C.c_void_p(hip_stream)))

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/direct_cluster.h"
+#include "hull_core.h"
 
 namespace {
 
@@ -465,6 +466,8 @@ __global__ void k_emit(Dev D, int batch, int32_t* vertex_idx, int32_t* cluster_x
   (void)batch;
 }
 
+#include "hull_kernels.h"
+
 thread_local std::string g_cerr;
 direct_status_t cfail(direct_status_t st, const std::string& msg) {
   g_cerr = msg;
@@ -491,6 +494,10 @@ struct direct_cluster_handle_s {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   std::vector<void*> allocs;
+  HullDev H = {};          // scratch of hull_planes_batch, allocated by its first call
+  bool have_hull = false;
+  void* hull_out = nullptr;  // device staging of its host outputs
+  size_t hull_out_bytes = 0;
 };
 
 extern "C" {
@@ -553,6 +560,7 @@ direct_status_t direct_cluster_destroy(direct_cluster_handle_t h) {
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
   for (void* p : h->allocs) (void)hipFree(p);
+  if (h->hull_out) (void)hipFree(h->hull_out);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -692,6 +700,97 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
     for (int i = 0; i < n_candidate; i++)
       for (int j = 0; j < i; j++)
         can_can[(size_t)i * (i - 1) / 2 + j] = ((rows[(size_t)i * D.kwords + (j >> 6)] >> (j & 63)) & 1ull) ? 0 : 1;
+  return DIRECT_OK;
+}
+
+direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int32_t batch, int32_t mem_in,
+                                                 const int32_t* cluster_xyz, const int32_t* cluster_num, double resolution,
+                                                 const double* map_lower, int32_t plane_capacity, int32_t vertex_capacity,
+                                                 int32_t mem, double* planes, int64_t* plane_int, int32_t* n_planes,
+                                                 double* vertices, int32_t* n_vertices, double* center, int32_t* degenerate,
+                                                 int32_t* rtn) {
+  if (!h || !map_lower) return cfail(DIRECT_ERR_INVALID, "null argument");
+  if (batch <= 0 || batch > h->cfg.max_batch) return cfail(DIRECT_ERR_INVALID, "batch exceeds the handle's max_batch");
+  if (cluster_xyz && !cluster_num) return cfail(DIRECT_ERR_INVALID, "cluster_xyz without cluster_num");
+  if (plane_capacity <= 0 || vertex_capacity <= 0 || !(resolution > 0)) return cfail(DIRECT_ERR_INVALID, "bad capacity / resolution");
+  CHIP_TRY(hipSetDevice(h->cfg.device));
+  Dev& D = h->D;
+  HullDev& H = h->H;
+  const size_t B = h->cfg.max_batch;
+  if (!h->have_hull) {
+    H.QX = 2 * D.max_x + 1; H.QY = 2 * D.max_y + 1; H.QZ = 2 * D.max_z + 1;
+    H.half_words = (size_t)H.QY * H.QZ + (size_t)H.QX * H.QZ + (size_t)H.QX * H.QY;
+    H.line_words = 2 * H.half_words;
+    auto A = [&](auto pp, size_t bytes) -> hipError_t {
+      void* q = nullptr;
+      hipError_t e = hipMalloc(&q, bytes);
+      if (e != hipSuccess) return e;
+      h->allocs.push_back(q);
+      *pp = (typename std::remove_pointer<decltype(pp)>::type)q;
+      return hipSuccess;
+    };
+    CHIP_TRY(A(&H.he, B * sizeof(HullElem)));
+    CHIP_TRY(A(&H.lines, B * H.line_words * sizeof(int)));
+    CHIP_TRY(A(&H.cand, B * 3 * hull::kCandCap * sizeof(int)));
+    CHIP_TRY(A(&H.first, B * hull::kCandCap * sizeof(int)));
+    CHIP_TRY(A(&H.isv, B * hull::kCandCap * sizeof(int)));
+    CHIP_TRY(A(&H.raw, B * hull::kRawCap * 4 * sizeof(hull::i64)));
+    CHIP_TRY(A(&H.sorted, B * hull::kRawCap * 4 * sizeof(hull::i64)));
+    CHIP_TRY(A(&H.vq, B * hull::kCandCap * 3 * sizeof(int)));
+    h->have_hull = true;
+  }
+  // device views of the outputs: the caller's pointers, or one staging block for host outputs
+  const size_t nb = (size_t)batch;
+  const size_t sz[8] = {nb * plane_capacity * 4 * sizeof(double), nb * plane_capacity * 4 * sizeof(long long), nb * sizeof(int32_t),
+                        nb * vertex_capacity * 3 * sizeof(double), nb * sizeof(int32_t), nb * 3 * sizeof(double),
+                        nb * sizeof(int32_t), nb * sizeof(int32_t)};
+  void* user[8] = {planes, plane_int, n_planes, vertices, n_vertices, center, degenerate, rtn};
+  void* dev[8];
+  if (mem == DIRECT_MEM_HOST) {
+    size_t total = 0, off[8];
+    for (int i = 0; i < 8; i++) { off[i] = total; total += (sz[i] + 255) & ~(size_t)255; }
+    if (total > h->hull_out_bytes) {
+      if (h->hull_out) {
+        CHIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->hull_out);
+        h->hull_out = nullptr; h->hull_out_bytes = 0;
+      }
+      CHIP_TRY(hipMalloc(&h->hull_out, total));
+      h->hull_out_bytes = total;
+    }
+    for (int i = 0; i < 8; i++) dev[i] = user[i] ? (char*)h->hull_out + off[i] : nullptr;
+  } else {
+    for (int i = 0; i < 8; i++) dev[i] = user[i];
+  }
+  const int32_t *sx = cluster_xyz, *sn = cluster_num;
+  void *tx = nullptr, *tn = nullptr;
+  if (cluster_xyz && mem_in == DIRECT_MEM_HOST) {  // caller-provided voxels from the host: staged in the generation's own staging block
+    CHIP_TRY(hipMalloc(&tn, nb * sizeof(int32_t)));
+    CHIP_TRY(hipMemcpyAsync(h->st_xyz, cluster_xyz, nb * (size_t)D.ccap * 12, hipMemcpyHostToDevice, h->stream));
+    CHIP_TRY(hipMemcpyAsync(tn, cluster_num, nb * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    sx = h->st_xyz; sn = (const int32_t*)tn;
+  }
+  (void)tx;
+  CHIP_TRY(hipEventRecord(h->ev0, h->stream));
+  CHIP_TRY(hipMemset2DAsync(H.lines, H.line_words * sizeof(int), 0x7f, H.half_words * sizeof(int), nb, h->stream));
+  CHIP_TRY(hipMemset2DAsync(H.lines + H.half_words, H.line_words * sizeof(int), 0x80, H.half_words * sizeof(int), nb, h->stream));
+  hipLaunchKernelGGL(k_hull_src, dim3(32, batch), dim3(256), 0, h->stream, D, H, batch, sx, sn);
+  hipLaunchKernelGGL(k_hull_lines, dim3(batch), dim3(256), 0, h->stream, D, H);
+  hipLaunchKernelGGL(k_hull_cand, dim3(batch), dim3(256), 0, h->stream, D, H);
+  hipLaunchKernelGGL(k_hull_edges, dim3(64, batch), dim3(256), 0, h->stream, H);
+  hipLaunchKernelGGL(k_hull_finish, dim3(batch), dim3(256), 0, h->stream, H, resolution, map_lower[0], map_lower[1], map_lower[2],
+                     plane_capacity, vertex_capacity, (double*)dev[0], (long long*)dev[1], (int32_t*)dev[2], (double*)dev[3],
+                     (int32_t*)dev[4], (double*)dev[5], (int32_t*)dev[6], (int32_t*)dev[7]);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+  h->timed = e == hipSuccess;
+  if (mem == DIRECT_MEM_HOST)
+    for (int i = 0; i < 8 && e == hipSuccess; i++)
+      if (user[i]) e = hipMemcpyAsync(user[i], dev[i], sz[i], hipMemcpyDeviceToHost, h->stream);
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  if (tn) (void)hipFree(tn);
+  if (e != hipSuccess || e2 != hipSuccess)
+    return cfail(DIRECT_ERR_DEVICE, std::string("hull_planes_batch: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   return DIRECT_OK;
 }
 

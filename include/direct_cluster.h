@@ -77,7 +77,39 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
                                            const int32_t* candidate_xyz, int32_t n_cluster, const int32_t* cluster_xyz,
                                            uint8_t* can_clu, uint8_t* can_can, uint8_t* accept);
 
-/* HIP-event time [ms] of the kernels of the last polygon_generation_batch / convex_test call */
+/* ---- hull -> planes (the tail of SURVEY.md 8f-4): cluster voxels -> the polytope the DDP path consumes ---------
+ * Replaces, for a batch of clusters, what polyhedronGenerator does with the result of polygonGeneration
+ * (global_planner/src/utils/poly_utils.cpp):
+ *   getConvexPoly   :301-389  point set (voxel centres; the eight corners of every voxel when checkDegeneratePoly
+ *                             :236-273 finds the cluster flat along an axis), third_party/quickhull, vertex buffer
+ *   Polyhedron::hrep (eigen-cdd / cddlib), call sites :404-449, :470-480   V-rep -> A x <= b
+ *   polyHrep2Utils  :127-206  unit normals pointing outwards, plane (a, b, c, d) with a x + b y + c z + d <= 0 inside,
+ *                             axis-aligned faces of a solid cluster moved out by half a voxel, centre
+ * All of the reference's points lie on the half-voxel lattice q = 2 index + 1 (+/- 1 for corners), world coordinate
+ * x = q * resolution / 2 + map_lower, so the hull is computed in exact integer arithmetic: the planes are THE facet
+ * planes the two floating-point libraries approximate.  Not reproducible and therefore defined here: the ORDER of the
+ * rows (cdd's; here ascending (nx, ny, nz, K) of the primitive integer normal) and the per-plane vertex behind the
+ * centre (an argmin over residuals that are all ~1e-16; here the first corner, in cluster order, on the plane).
+ * Vertices are the corners of the hull in cluster order (quickhull's vertex buffer may also hold boundary points that
+ * are not corners; cdd's H-rep does not depend on them).
+ *
+ * cluster_xyz == NULL: the clusters of the last polygon_generation_batch, still resident on the device (no copy of
+ * the voxels in either direction).  Otherwise cluster_xyz[batch][cluster_capacity][3] / cluster_num[batch] in memory
+ * kind mem_in replace them.  Outputs in memory kind `mem`, any may be NULL:
+ *   planes[batch][plane_capacity][4] (double), plane_int[batch][plane_capacity][4] (int64: primitive normal and
+ *   offset on the lattice, n . q + K <= 0), n_planes[batch], vertices[batch][vertex_capacity][3], n_vertices[batch],
+ *   center[batch][3], degenerate[batch] (checkDegeneratePoly), rtn[batch] (codes below). */
+#define DIRECT_HULL_OK 0
+#define DIRECT_HULL_OVERFLOW 1 /* more planes / vertices than the capacities, or more than 2048 line-extreme points */
+#define DIRECT_HULL_FLAT 3     /* empty cluster, or the points do not span three dimensions (the reference's cdd call fails) */
+direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int32_t batch, int32_t mem_in,
+                                                 const int32_t* cluster_xyz, const int32_t* cluster_num, double resolution,
+                                                 const double* map_lower, int32_t plane_capacity, int32_t vertex_capacity,
+                                                 int32_t mem, double* planes, int64_t* plane_int, int32_t* n_planes,
+                                                 double* vertices, int32_t* n_vertices, double* center, int32_t* degenerate,
+                                                 int32_t* rtn);
+
+/* HIP-event time [ms] of the kernels of the last polygon_generation_batch / convex_test / hull_planes_batch call */
 /* The HIP stream (hipStream_t) the handle enqueues its copies, kernels and timing events on; NULL (the default) is
  * the legacy default stream.  Mirrors direct_ddp_set_stream. */
 direct_status_t direct_cluster_set_stream(direct_cluster_handle_t h, void* hip_stream);
