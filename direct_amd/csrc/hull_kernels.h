@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256) void k_hull_finish(HullDev H, double res, doub
     }
     if (n_planes) n_planes[e] = np;
     if (n_vertices) n_vertices[e] = nv;
-    if (rtn) rtn[e] = (np > plane_cap || nv > vert_cap) ? DIRECT_HULL_OVERFLOW : DIRECT_HULL_OK;
+    // a capacity only counts for an output the caller asked for
+    const bool over = ((planes || plane_int) && np > plane_cap) || (vertices && nv > vert_cap);
+    if (rtn) rtn[e] = over ? DIRECT_HULL_OVERFLOW : DIRECT_HULL_OK;
   }
 }

@@ -60,20 +60,110 @@ def test_hull_of_device_resident_clusters_and_edge_cases(built):
     gen.close()
 
 
-def test_seeds_to_planes_to_ddp(built):
-    """The chain the reference runs on the host (corridorGeneration, poly_utils.cpp:508-557, then the planner): seed
-    voxels -> clusters -> planes here, and the planes are a valid DDP corridor: a trajectory through the polytopes of
-    three overlapping clusters is solved and stays inside them."""
-    grid, seeds = problems.make_voxel_map()
-    gen = cluster.ClusterGenerator(grid.shape, max_batch=8, cluster_capacity=50000, candidate_capacity=10000)
-    gen.set_map(grid)
-    s0 = seeds[0]
-    chain = np.array([s0, s0 + [3, 0, 0], s0 + [6, 1, 0]], np.int32)
-    chain = chain[[not grid[tuple(c)] for c in chain]]
-    gen.polygon_generation(chain)
-    dev = gen.hull_planes(RES, LOWER, batch=len(chain), plane_capacity=64)
-    assert (dev["rtn"] == 0).all()
-    for b, c in enumerate(chain):                     # every seed lies strictly inside its own polytope
-        x = c * RES + 0.5 * RES + LOWER
-        assert (dev["planes"][b][:, :3] @ x + dev["planes"][b][:, 3] < 0).all()
-    gen.close()
+def grid_path(grid, start, goal):
+    """a 4-connected shortest voxel path at the height of `start` (breadth first), as voxel-centre coordinates"""
+    from collections import deque
+    z = start[2]
+    free = grid[:, :, z] == 0
+    prev = -np.ones(free.shape + (2,), np.int32)
+    seen = np.zeros(free.shape, bool)
+    dq = deque([(int(start[0]), int(start[1]))])
+    seen[start[0], start[1]] = True
+    while dq:
+        x, y = dq.popleft()
+        if (x, y) == (int(goal[0]), int(goal[1])):
+            break
+        for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            u, v = x + dx, y + dy
+            if 0 <= u < free.shape[0] and 0 <= v < free.shape[1] and free[u, v] and not seen[u, v]:
+                seen[u, v] = True
+                prev[u, v] = (x, y)
+                dq.append((u, v))
+    assert seen[goal[0], goal[1]]
+    path, cur = [], (int(goal[0]), int(goal[1]))
+    while cur != (int(start[0]), int(start[1])):
+        path.append(cur)
+        cur = tuple(int(c) for c in prev[cur])
+    path.append(cur)
+    return np.array([[x, y, z] for x, y in path[::-1]], np.float64) * RES + 0.5 * RES + LOWER
+
+
+def test_corridor_generation_walk_and_ddp(built, tmp_path):
+    """corridorGeneration (poly_utils.cpp:508-557) through the C++ host class (direct_amd/host/poly_utils.hpp): grid
+    paths -> corridors, path by path and all paths in lock step, against the walk restated over the CPU checkers
+    (planes bit for bit); then the corridor is what the DDP path consumes: the replay batch of one of them is solved."""
+    import struct
+    import subprocess
+    from direct_amd import corridor_io
+    from oracle import corridor_walk
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    grid, _ = problems.make_voxel_map()
+    free = np.argwhere(grid[:, :, 8] == 0)
+    rng = np.random.default_rng(4)
+    paths = []
+    while len(paths) < 5:
+        a, b = free[rng.integers(len(free))], free[rng.integers(len(free))]
+        if np.abs(a - b).sum() > 60:
+            try:
+                paths.append(grid_path(grid, [a[0], a[1], 8], [b[0], b[1], 8]))
+            except AssertionError:
+                pass
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3id3di", *grid.shape, RES, *LOWER, len(paths)))
+        for p in paths:
+            f.write(struct.pack("<i", len(p)))
+            f.write(np.ascontiguousarray(p, np.float64).tobytes())
+        f.write(np.ascontiguousarray(grid, np.uint8).tobytes())
+    exe = str(tmp_path / "test_corridor_gen")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(root, "tests/cpp/test_corridor_gen.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "direct_amd/lib"), "-ldirect_ddp",
+                           "-Wl,-rpath," + os.path.join(root, "direct_amd/lib") + ":/opt/rocm/lib"])
+    out = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+    assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+    raw = open(fout, "rb").read()
+    off = 0
+
+    def take(fmt):
+        nonlocal off
+        v = struct.unpack_from(fmt, raw, off)
+        off += struct.calcsize(fmt)
+        return v
+    cache, modes = {}, []
+    want = [corridor_walk.corridor_generation(grid, RES, LOWER, p, cache=cache) for p in paths]
+    for mode in range(2):
+        got = []
+        for p in range(len(paths)):
+            ok, n = take("<2i")
+            cor = []
+            for _ in range(n):
+                (k,) = take("<i")
+                pl = np.array(take("<%dd" % (4 * k))).reshape(k, 4)
+                cor.append(dict(planes=pl, center=np.array(take("<3d")), seed_coord=np.array(take("<3d"))))
+            got.append((cor, bool(ok)))
+        modes.append(got)
+    assert off == len(raw)
+    n_poly = 0
+    for got in modes:
+        for (gc, gok), (wc, wok) in zip(got, want):
+            assert gok == wok and len(gc) == len(wc) and len(gc) >= 2
+            for a, b in zip(gc, wc):
+                assert np.array_equal(a["planes"], b["planes"]) and np.array_equal(a["center"], b["center"])
+                assert np.array_equal(a["seed_coord"], b["seed_coord"])
+            n_poly += len(gc)
+    # the corridor feeds the DDP path: wire format -> replay batch (first n polytopes, n = 2 ..) -> two-phase plan
+    cor = next(c for c, _ in modes[1] if max(len(q["planes"]) for q in c) <= abi.P_LIMIT and len(c) >= 3)
+    pm = max(len(q["planes"]) for q in cor)
+    planes = np.zeros((len(cor), pm, 4))
+    for i, q in enumerate(cor):
+        planes[i, :len(q["planes"])] = q["planes"]
+    c = corridor_io.Corridor(7, [len(q["planes"]) for q in cor], planes, [q["seed_coord"] for q in cor], [q["center"] for q in cor])
+    c2, _ = corridor_io.unpack(corridor_io.pack(c), 64, pm)
+    assert np.array_equal(c2.planes, c.planes)
+    batch = corridor_io.replay_batch(c2, n_first=2)
+    s = solver.DdpSolver(batch.batch, int(batch.n_seg.max()), pm, np.float64)
+    g0, g1 = s.plan(abi.phase0_params(), abi.phase1_params(), batch)
+    d = s.sample(batch.n_seg, g1.bez, g1.T, 0.05, 4096, derivs=0, n_planes=batch.n_planes, planes=batch.planes)
+    s.close()
+    assert (g1.rtn >= 0).any()
+    assert (d["cmax"][g1.rtn >= 0] < 1e-6).all()       # solved trajectories stay inside their polytopes
