@@ -185,7 +185,7 @@ DDP_DEV void static_for_down(F&& f) {  // B, B-1, ..., E
   }
 }
 
-constexpr int kPLim = 32;  // DIRECT_P_LIMIT
+constexpr int kPLim = 54;  // DIRECT_P_LIMIT: (64 * 6 - 55) / 6, six row slots per lane
 
 #if !defined(DIRECT_EMULATE)
 #if defined(DDP_TIMING)
@@ -763,8 +763,13 @@ struct Wave {
   // the gains of phase D) in ONE batch of loads; with double storage the same batches spill inside the sweeps, and a
   // spill reload waits for every outstanding load, the HBM prefetch included
   static constexpr bool kWide = sizeof(St) < sizeof(double) && RPL <= 2;
+  // Field widths of the packed row descriptor: rows fit eight bits up to four row slots per lane (6 P + 55 <= 255);
+  // the five- and six-slot kernels (polytopes of 34 .. 54 planes) take a ninth bit from a0 (< 64).
+  static constexpr int kRB = RPL > 4 ? 9 : 8;
+  static constexpr int kRMask = (1 << kRB) - 1, kAMask = (1 << (16 - kRB)) - 1;
+  static constexpr int kNPL = (4 * Lds::kPMax + 63) / 64 > 2 ? (4 * Lds::kPMax + 63) / 64 : 2;  // plane words per lane
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
-    St zh, zl, pl[2], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
+    St zh, zl, pl[kNPL], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
   };
   DDP_DEV void prefetch(Pre& p, int* pkv, int pk_valid, int lane, int buf, int k, int P, bool fwd, int infeas) const {
     (void)buf;
@@ -773,8 +778,7 @@ struct Wave {
     p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 19 ? lane : 18)] : (St)0;  // see ldx()
     GCSt* pk = planesU(k);
     const int pend = 4 * P - 1;
-    p.pl[0] = pk[lane < pend ? lane : pend];
-    p.pl[1] = pk[lane + 64 < pend ? lane + 64 : pend];
+    for (int i = 0; i < kNPL; i++) p.pl[i] = pk[lane + 64 * i < pend ? lane + 64 * i : pend];
     GCSt* sk = SpU(sp.S[0], k);
     GCSt* yk = SpU(sp.Y[0], k);
     GCSt* ksk = SpU(sp.KS, k);
@@ -783,7 +787,7 @@ struct Wave {
       // the knot's row descriptors: computed once, carried to its row phases; they only depend on P,
       // so a run of knots with the same plane count (every free-space corridor) reuses them
       if (!pk_valid) pkv[i] = row_pack(i, lane, P);
-      const int r = (pkv[i] & 255) - 1;
+      const int r = (pkv[i] & kRMask) - 1;
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0; their results are masked
       p.s[i] = sk[rc];
       if (infeas || (fwd && kRowCache)) p.y[i] = yk[rc];  // feasible forward pass: q = s / c of the old iterate (written by phase R1)
@@ -802,8 +806,8 @@ struct Wave {
     Real z = (Real)p.zh;
     if (sizeof(St) < sizeof(double)) z += (Real)p.zl;
     if (lane < 19) L.z[lane] = z;
-    if (lane < 4 * P) L.pl[lane] = (Real)p.pl[0];
-    if (lane + 64 < 4 * P) L.pl[lane + 64] = (Real)p.pl[1];
+    for (int i = 0; i < kNPL; i++)
+      if (lane + 64 * i < 4 * P) L.pl[lane + 64 * i] = (Real)p.pl[i];
     if (fwd) {
       L.KUr[lane] = (Real)p.ku[0];
       if (lane + 64 < 100) L.KUr[lane + 64] = (Real)p.ku[1];
@@ -967,7 +971,7 @@ struct Wave {
     const int rq = pv ? rp : 0;
     const int j = (int)(DDP_UMUL24((unsigned)rq, kInvP[P]) >> 16);  // rq / P: the control point
     const int q = rq - (int)DDP_UMUL24((unsigned)j, (unsigned)P);   // the plane
-    int pk = (pv ? rp + 1 : 0) | ((3 * j) << 8) | (q << 16);
+    int pk = (pv ? rp + 1 : 0) | ((3 * j) << kRB) | (q << 16);
     if (last) {  // lanes 0..54: velocity (30), acceleration (24), T_min (1) rows  (DDP:1236-1238, 1274-1279)
       const bool isv = lane < 30, isa = lane < 54;
       const int l2 = lane - 30;
@@ -975,7 +979,7 @@ struct Wave {
       const int a0a = 31 + (l2 < 12 ? l2 : l2 - 12);         // 33 + . - 2
       const int a0 = isv ? a0v : (isa ? a0a : 43);
       const int pp = isv ? (lane < 15 ? 0 : 1) : (isa ? (l2 < 12 ? 2 : 3) : 4);
-      const int po = (6 * P + lane + 1) | (a0 << 8) | ((Lds::kPMax + pp) << 16);
+      const int po = (6 * P + lane + 1) | (a0 << kRB) | ((Lds::kPMax + pp) << 16);
       pk = lane < 55 ? po : pk;
     }
     return pk;
@@ -987,8 +991,8 @@ struct Wave {
     k.n1 = n[1];
     k.n2 = n[2];
     k.o = n[3];
-    k.r = (pk & 255) - 1;
-    k.a0 = (pk >> 8) & 255;
+    k.r = (pk & kRMask) - 1;
+    k.a0 = (pk >> kRB) & kAMask;
     return k;
   }
   DDP_DEV RowK<Real> row_slot(int slot, int lane, int P) const { return row_unpack(row_pack(slot, lane, P)); }
@@ -1009,12 +1013,12 @@ struct Wave {
       k.n2 = n[2];
       k.o = n[3];
     }
-    k.r = (pk & 255) - 1;
-    k.a0 = (pk >> 8) & 255;
+    k.r = (pk & kRMask) - 1;
+    k.a0 = (pk >> kRB) & kAMask;
     return k;
   }
   DDP_DEV Row3 row_ops(const Real* A, int pk) const {
-    const Real* p = A + ((pk >> 8) & 255);
+    const Real* p = A + ((pk >> kRB) & kAMask);
     Row3 v;
     v.a = p[0];
     v.b = p[1];
@@ -1102,13 +1106,12 @@ struct Wave {
     // sweep used to expose a global-memory round trip per knot, and with do_roll it re-read from HBM the state it had
     // just written (k_begin was 1.7 % of the benchmark's step).
     PLV(Real, zr);
-    PLA(St, plr, 2);
+    PLA(St, plr, kNPL);
     int Pn = np_(0);
     LANES {
       LV(zr) = ldx(Xp(buf, 0), lane < 19 ? lane : 18);
       const int pend = 4 * Pn - 1;
-      LV(plr)[0] = planes_(0)[lane < pend ? lane : pend];
-      LV(plr)[1] = planes_(0)[lane + 64 < pend ? lane + 64 : pend];
+      for (int i = 0; i < kNPL; i++) LV(plr)[i] = planes_(0)[lane + 64 * i < pend ? lane + 64 * i : pend];
     }
     for (int k = 0; k < N; k++) {
       const int P = Pn;
@@ -1117,12 +1120,12 @@ struct Wave {
         // x_k of a roll is what the previous knot produced - rounded as the store / load pair would round it
         const bool rolled = do_roll && k > 0 && lane < 9;
         if (lane < 19) L.z[lane] = rolled ? pair_round(L.ft[0].xnx[lane]) : LV(zr);
-        if (lane < 4 * P) L.pl[lane] = (Real)LV(plr)[0];
-        if (lane + 64 < 4 * P) L.pl[lane + 64] = (Real)LV(plr)[1];
+        for (int i = 0; i < kNPL; i++)
+          if (lane + 64 * i < 4 * P) L.pl[lane + 64 * i] = (Real)LV(plr)[i];
         if (infeas) {
           const St* yk = Sp_(B.Y[buf], k);
           for (int i = 0; i < RPL; i++) {
-            const int r = (row_pack(i, lane, P) & 255) - 1;
+            const int r = (row_pack(i, lane, P) & kRMask) - 1;
             LV(yv)[i] = (Real)yk[r >= 0 ? r : 0];
           }
         }
@@ -1132,8 +1135,7 @@ struct Wave {
         LANES {
           LV(zr) = ldx(Xp(buf, k + 1), lane < 19 ? lane : 18);
           const int pend = 4 * Pn - 1;
-          LV(plr)[0] = planes_(k + 1)[lane < pend ? lane : pend];
-          LV(plr)[1] = planes_(k + 1)[lane + 64 < pend ? lane + 64 : pend];
+          for (int i = 0; i < kNPL; i++) LV(plr)[i] = planes_(k + 1)[lane + 64 * i < pend ? lane + 64 * i : pend];
         }
       }
       WSYNC();

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_begin(Batch<St> B) {
 
 // the hot kernel: n trips of the outer loop (ddp_optimizer.cpp:295-412) per trajectory
 template <typename St, int RPL>
-__global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate(Batch<St> B, int n_iters) {
+__global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate(Batch<St> B, int n_iters) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
   W.load_state();
@@ -128,7 +128,7 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, uns
   return (int)t;
 }
 template <typename St, int RPL>
-__global__ __launch_bounds__(64, MinWaves<St>::v) void k_iterate_dyn(Batch<St> B, int n_iters, Sched S) {
+__global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate_dyn(Batch<St> B, int n_iters, Sched S) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, 0);
   W.init_tables();
@@ -407,7 +407,9 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   do {                                                                                                   \
     if ((h)->rpl <= 2) hipLaunchKernelGGL((KERNEL<Real, 2>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
     else if ((h)->rpl == 3) hipLaunchKernelGGL((KERNEL<Real, 3>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<Real, 4>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__);       \
+    else if ((h)->rpl == 4) hipLaunchKernelGGL((KERNEL<Real, 4>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
+    else if ((h)->rpl == 5) hipLaunchKernelGGL((KERNEL<Real, 5>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<Real, 6>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__);       \
   } while (0)
 
 template <typename Real>
@@ -421,7 +423,9 @@ static int resident_slots(direct_ddp_handle_t h, int n_cu) {
   hipError_t e;
   if (h->rpl <= 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 2>, 64, 0);
   else if (h->rpl == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 3>, 64, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 4>, 64, 0);
+  else if (h->rpl == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 4>, 64, 0);
+  else if (h->rpl == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 5>, 64, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 6>, 64, 0);
   return (e == hipSuccess && per_cu > 0) ? per_cu * n_cu : 0;
 }
 template <typename Real>

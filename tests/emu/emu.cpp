@@ -38,7 +38,9 @@ template <typename Cmp, typename Real, typename F>
 static void dispatch_c(Emu<Real>& E, F f) {
   if (E.rpl <= 2) for_each_wave<Cmp, Real, 2>(E, f);
   else if (E.rpl == 3) for_each_wave<Cmp, Real, 3>(E, f);
-  else for_each_wave<Cmp, Real, 4>(E, f);
+  else if (E.rpl == 4) for_each_wave<Cmp, Real, 4>(E, f);
+  else if (E.rpl == 5) for_each_wave<Cmp, Real, 5>(E, f);
+  else for_each_wave<Cmp, Real, 6>(E, f);
 }
 template <typename Real, typename F>
 static void dispatch(Emu<Real>& E, F f) {

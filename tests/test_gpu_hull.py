@@ -152,7 +152,8 @@ def test_corridor_generation_walk_and_ddp(built, tmp_path):
                 assert np.array_equal(a["seed_coord"], b["seed_coord"])
             n_poly += len(gc)
     # the corridor feeds the DDP path: wire format -> replay batch (first n polytopes, n = 2 ..) -> two-phase plan
-    cor = next(c for c, _ in modes[1] if max(len(q["planes"]) for q in c) <= abi.P_LIMIT and len(c) >= 3)
+    cor = max((c for c, _ in modes[1] if max(len(q["planes"]) for q in c) <= abi.P_LIMIT), key=len)   # P_LIMIT 54: all of them
+    assert len(cor) >= 3
     pm = max(len(q["planes"]) for q in cor)
     planes = np.zeros((len(cor), pm, 4))
     for i, q in enumerate(cor):

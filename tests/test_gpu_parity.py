@@ -256,10 +256,11 @@ def test_recorded_corridor_replay_in_one_batch(built):
     assert helpers.rel(g1.bez, r1.bez) < 1e-5
 
 
-@pytest.mark.parametrize("p_max", [20, 32])
+@pytest.mark.parametrize("p_max", [20, 32, 44, 54])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_many_planes_per_polytope(built, p_max, dtype):
-    """P up to 20 / 32 planes per polytope (nc = 175 / 247): the RPL = 3 / 4 kernels, both storage types."""
+    """P up to 20 / 32 / 44 / 54 planes per polytope (nc = 175 / 247 / 319 / 379): the kernels with three to six row
+    slots per lane, both storage types (real voxel clusters reach 40 planes: tests/test_gpu_hull.py)."""
     batch = helpers.with_extra_planes(problems.make_batch("corridor", 5, 9, seed=41), p_max, seed=p_max)
     batch = batch.astype(dtype).astype(np.float64)     # identical (rounded) inputs for the oracle
     p0, p1 = abi.phase0_params(), abi.phase1_params()
