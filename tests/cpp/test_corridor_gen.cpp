@@ -1,9 +1,10 @@
 // C++ host-side check (GPU needed): drives direct::polyhedronGenerator (direct_amd/host/poly_utils.hpp) like the
 // reference drives its corridor generator - a map, grid paths, corridorGeneration - once path by path and once for all
 // paths in lock step, and writes the corridors for tests/test_gpu_hull.py to compare with the CPU restatement.
-//   usage: test_corridor_gen <in.bin> <out.bin>
+//   usage: test_corridor_gen <in.bin> <out.bin> [seeds per device call, default 16]
 //   in : int32 X Y Z, double res, double lower[3], int32 n_paths, {int32 len, double pts[len][3]}*, uint8 map[X*Y*Z]
 //   out: per mode (0 = one by one, 1 = batch): per path: int32 ok, int32 n_poly, {int32 n_planes, double planes[n][4], center[3], seed[3]}*
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -33,10 +34,12 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> map((size_t)dims[0] * dims[1] * dims[2]);
   rd(f, map.data(), map.size());
   std::fclose(f);
-  direct::polyhedronGenerator gen(res, lower, dims[0], dims[1], dims[2], 1000, 50, 16);
+  const int max_batch = argc > 3 ? std::atoi(argv[3]) : 16;
+  direct::polyhedronGenerator gen(res, lower, dims[0], dims[1], dims[2], 1000, 50, max_batch);
   gen.setMap(map.data());
   FILE* o = std::fopen(argv[2], "wb");
   for (int mode = 0; mode < 2; mode++) {
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<direct::PlainCorridor> cors(np);
     std::vector<bool> ok(np);
     if (mode == 0) {
@@ -47,6 +50,7 @@ int main(int argc, char** argv) {
       ok = gen.corridorGenerationBatch(paths, ptr);
       std::printf("batch: %d device rounds for %d polytopes on %d paths\n", gen.lastRounds(), gen.lastPolytopes(), np);
     }
+    std::printf("mode %d: %.3f ms\n", mode, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     for (int p = 0; p < np; p++) {
       const int32_t okv = ok[p] ? 1 : 0, n = (int32_t)cors[p].polyhedrons.size();
       std::fwrite(&okv, 4, 1, o); std::fwrite(&n, 4, 1, o);
