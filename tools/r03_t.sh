@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-timeout 1500 python tests/soak/real_corridor_bench.py > gpurun_out/r03_real_corridors.json 2> gpurun_out/rc.err; tail -5 gpurun_out/rc.err; cut -c1-3000 gpurun_out/r03_real_corridors.json
+bash tools/profile_round.sh r03 > gpurun_out/r03_profile.log 2>&1; tail -2 gpurun_out/r03_profile.log | cut -c1-200
+head -4 gpurun_out/r03_bench_kernel_stats.csv | cut -c1-150
+cut -c1-300 gpurun_out/r03_bench.json
