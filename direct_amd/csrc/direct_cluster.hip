@@ -54,6 +54,8 @@ struct Dev {
   int* cand;               // [batch][kcap]
   uint8_t *can_clu, *accept;        // [batch][kcap]
   unsigned long long* blocked;      // [batch][kcap][kwords]
+  unsigned long long* accbits;      // [batch][kwords] accepted candidates of the round (k_resolve_fast -> k_apply)
+  int* accpre;                      // [batch][kwords] accepted candidates before word w
   Elem* el;                // [batch]
 };
 
@@ -252,12 +254,24 @@ __device__ __forceinline__ float intbound_half(int ds) {
   return (float)(0.5 / (double)(ds < 0 ? -ds : ds));
 }
 // RD(x, y, z) -> flag byte of a voxel (only F_INSIDE and F_OBS are looked at)
+// the two cheap tests in front of the walk: 1 when the ray has to be traced
 template <typename RD>
-__device__ __forceinline__ int ray_blocked_t(const RD& rd, int cx, int cy, int cz, int target) {
+__device__ __forceinline__ int ray_needs_walk_t(const RD& rd, int cx, int cy, int cz, int target) {
   const int ex = px(target), ey = py(target), ez = pz(target);
   if (rd(ex, ey, ez) & F_INSIDE) return 0;  // only targets with inside_data == 0 are traced
   const int mx = cx / 2 + (ex >> 1), my = cy / 2 + (ey >> 1), mz = cz / 2 + (ez >> 1);
   if (rd(mx, my, mz) & F_INSIDE) return 0;  // "midpoint" inside the cube: skipped
+  return 1;
+}
+template <typename RD>
+__device__ __forceinline__ int ray_walk_t(const RD& rd, int cx, int cy, int cz, int target);
+template <typename RD>
+__device__ __forceinline__ int ray_blocked_t(const RD& rd, int cx, int cy, int cz, int target) {
+  return ray_needs_walk_t(rd, cx, cy, cz, target) ? ray_walk_t(rd, cx, cy, cz, target) : 0;
+}
+template <typename RD>
+__device__ __forceinline__ int ray_walk_t(const RD& rd, int cx, int cy, int cz, int target) {
+  const int ex = px(target), ey = py(target), ez = pz(target);
   int x = cx, y = cy, z = cz;
   const int dx = ex - x, dy = ey - y, dz = ez - z;
   const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0), sz = (dz > 0) - (dz < 0);
@@ -284,6 +298,36 @@ __device__ __forceinline__ int ray_blocked_t(const RD& rd, int cx, int cy, int c
     if (f & F_OBS) return 1;
   }
 }
+// The walk as k_convex runs it - the same float sequence, cheaper around it: 1 / |d| from a table (built per workgroup
+// by the double division above; intbound_half(d) = 0.5 / |d| is exactly half of it: tested for every |d| < 2048), ONE
+// linear voxel index that moves by the axis' stride (a voxel has one index, so "end reached" is one compare).
+__device__ __forceinline__ void inv_table_init(float* inv /* shared[kDimLimit] */) {
+  for (int d = threadIdx.x; d < kDimLimit; d += blockDim.x) inv[d] = d ? (float)(1.0 / (double)d) : 0.0f;
+}
+__device__ __forceinline__ int ray_walk_lin(const Dev& D, const uint8_t* fl, const float* inv, int cx, int cy, int cz, int target) {
+  const int dx = px(target) - cx, dy = py(target) - cy, dz = pz(target) - cz;
+  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+  const int ix = dx < 0 ? -D.max_yz : D.max_yz, iy = dy < 0 ? -D.max_z : D.max_z, iz = dz < 0 ? -1 : 1;  // never taken for d == 0
+  const float tDX = inv[ax], tDY = inv[ay], tDZ = inv[az];
+  float tMaxX = dx ? 0.5f * tDX : INFINITY, tMaxY = dy ? 0.5f * tDY : INFINITY, tMaxZ = dz ? 0.5f * tDZ : INFINITY;
+  int id = cx * D.max_yz + cy * D.max_z + cz;
+  const int eid = px(target) * D.max_yz + py(target) * D.max_z + pz(target);
+  int budget = ax + ay + az;
+  for (;;) {
+    if (tMaxX < tMaxY) {
+      if (tMaxX < tMaxZ) { id += ix; tMaxX += tDX; }
+      else               { id += iz; tMaxZ += tDZ; }
+    } else {
+      if (tMaxY < tMaxZ) { id += iy; tMaxY += tDY; }
+      else               { id += iz; tMaxZ += tDZ; }
+    }
+    if (id == eid) return 0;
+    if (--budget < 0) return 0;
+    const unsigned f = fl[id];
+    if (f & F_INSIDE) return 0;
+    if (f & F_OBS) return 1;
+  }
+}
 __device__ __forceinline__ int ray_blocked(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
   return ray_blocked_t([&](int x, int y, int z) -> unsigned { return fl[x * D.max_yz + y * D.max_z + z]; }, cx, cy, cz, target);
 }
@@ -298,26 +342,92 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
   const int* cd = D.cand + (size_t)e * D.kcap;
   const int c = cd[i], cx = px(c), cy = py(c), cz = pz(c), n_clu = E->n_cluster;
   int bad = 0;
-  for (int base = 0; base < n_clu; base += 256) {
+  // About half of a candidate's rays towards the cluster end at the two cheap tests (the midpoint lies inside the
+  // inflated cube): left in place they idle through the walks of their wave.  The rays that have to be walked are
+  // queued (in order) and walked 256 at a time, every lane busy; the result is an AND, so the order is free.
+  __shared__ int queue[512];
+  __shared__ int wsum[4];
+  __shared__ float inv[kDimLimit];
+  inv_table_init(inv);  // (the first __syncthreads below comes before its first use)
+  int head = 0, count = 0;  // uniform over the workgroup
+  const int lane = tid & 63, wv = tid >> 6;
+  const auto rd = [&](int x, int y, int z) -> unsigned { return fl[x * D.max_yz + y * D.max_z + z]; };
+  for (int base = 0; base < n_clu || count > 0; base += 256) {
     // newest cluster voxels first, like the reference's loop (cluster_engine_cpu.cpp:41): they lie next to the
-    // candidate shell and are the likeliest to reject, so the early exit below comes sooner (the result is an AND)
+    // candidate shell and are the likeliest to reject, so the early exit below comes sooner
     const int t = n_clu - 1 - (base + tid);
-    if (t >= 0) bad |= ray_blocked(D, fl, cx, cy, cz, cl[t]);
-    if (!full && __syncthreads_or(bad)) {  // a rejected candidate's rays towards other candidates are never consulted
-      if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = 0;
-      return;
+    int tgt = 0, need = 0;
+    if (base < n_clu && t >= 0) {
+      tgt = cl[t];
+      need = ray_needs_walk_t(rd, cx, cy, cz, tgt);
+    }
+    const unsigned long long bal = __ballot(need);
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int off = count;
+    for (int w = 0; w < wv; w++) off += wsum[w];
+    if (need) queue[(head + off + __popcll(bal & ((1ull << lane) - 1ull))) & 511] = tgt;
+    count += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const bool last = base + 256 >= n_clu;
+    if (count >= 256 || (last && count > 0)) {
+      const int n = count < 256 ? count : 256;
+      if (tid < n) bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, queue[(head + tid) & 511]);
+      head = (head + n) & 511;
+      count -= n;
+      if (!full && __syncthreads_or(bad)) {  // a rejected candidate's rays towards other candidates are never consulted
+        if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = 0;
+        return;
+      }
     }
   }
   bad = __syncthreads_or(bad);
   if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = bad ? 0 : 1;
   if (bad && !full) return;
   unsigned long long* row = D.blocked + ((size_t)e * D.kcap + i) * D.kwords;
-  for (int base = 0; base < i; base += 256) {  // rays towards the candidates before this one
-    const int j = base + tid;
-    const int b = j < i ? ray_blocked(D, fl, cx, cy, cz, cd[j]) : 0;
-    const unsigned long long m = __ballot(b);
-    if ((tid & 63) == 0 && base + (tid & ~63) < i) row[(base + tid) >> 6] = m;
+  constexpr int kRowWords = 256;  // candidate capacities up to 16384 take the queued form
+  __shared__ unsigned long long srow[kRowWords];
+  if (D.kwords > kRowWords) {
+    for (int base = 0; base < i; base += 256) {  // rays towards the candidates before this one
+      const int j = base + tid;
+      const int b = j < i ? ray_blocked(D, fl, cx, cy, cz, cd[j]) : 0;
+      const unsigned long long m = __ballot(b);
+      if ((tid & 63) == 0 && base + (tid & ~63) < i) row[(base + tid) >> 6] = m;
+    }
+    return;
   }
+  // the same queue for the rays towards the earlier candidates: the row of the bit matrix is collected in LDS (a blocked
+  // ray is rare: one ds_or per hit) and written once
+  const int nw = (i + 63) / 64;
+  for (int w = tid; w < nw; w += 256) srow[w] = 0ull;
+  head = 0;
+  count = 0;
+  __syncthreads();
+  for (int base = 0; base < i || count > 0; base += 256) {
+    const int j = base + tid;
+    int need = 0;
+    if (base < i && j < i) need = ray_needs_walk_t(rd, cx, cy, cz, cd[j]);
+    const unsigned long long bal = __ballot(need);
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int off = count;
+    for (int w = 0; w < wv; w++) off += wsum[w];
+    if (need) queue[(head + off + __popcll(bal & ((1ull << lane) - 1ull))) & 511] = j;
+    count += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const bool last = base + 256 >= i;
+    if (count >= 256 || (last && count > 0)) {
+      const int n = count < 256 ? count : 256;
+      if (tid < n) {
+        const int jq = queue[(head + tid) & 511];
+        if (ray_walk_lin(D, fl, inv, cx, cy, cz, cd[jq])) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
+      }
+      head = (head + n) & 511;
+      count -= n;
+    }
+  }
+  __syncthreads();
+  for (int w = tid; w < nw; w += 256) row[w] = srow[w];
 }
 
 // the sequential accept loop (CS:360-384) for one seed: one wave.  dry = 1: only accept[] is written.
@@ -445,6 +555,151 @@ __global__ __launch_bounds__(64) void k_resolve_pipe(Dev D) {
   }
 }
 
+// candidates [i0, i1) of the accept loop with KW row words per lane (see k_resolve_fast)
+template <int KW>
+__device__ __forceinline__ void resolve_range(const Dev& D, int e, int lane, const unsigned long long* ccm, unsigned long long* acc, int i0, int i1) {
+  constexpr int KG = 32 / KW;
+  unsigned long long bufA[KG][KW], bufB[KG][KW];
+  int okA[KG], okB[KG];
+  auto load_group = [&](int g0, unsigned long long (*buf)[KW], int* okv) {
+    // a group lies inside one 64-candidate word of the cluster-test mask (KG divides 64, i0 is a multiple of 4096)
+    const int gw = (g0 < i1 ? g0 : i0) >> 6;
+    unsigned long long gm = 0ull;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (q == (gw >> 6)) gm = __shfl(ccm[q], gw & 63);
+#pragma unroll
+    for (int j = 0; j < KG; j++) {
+      const int i = g0 + j;
+      const int ic = i < i1 ? i : i0;
+      const int okc = i < i1 ? (int)((gm >> (i & 63)) & 1ull) : 0;
+      okv[j] = okc;
+      const unsigned long long* row = D.blocked + ((size_t)e * D.kcap + ic) * D.kwords;
+      const int nw = (i + 63) / 64;
+#pragma unroll
+      for (int q = 0; q < KW; q++) {
+        const int w = lane + 64 * q;
+        buf[j][q] = (okc && w < nw) ? row[w] : 0ull;  // rows of rejected candidates were never written
+      }
+    }
+  };
+  auto eval_group = [&](int g0, unsigned long long (*buf)[KW], const int* okv) {
+#pragma unroll
+    for (int j = 0; j < KG; j++) {
+      const int i = g0 + j;
+      if (i >= i1 || !okv[j]) continue;  // uniform
+      int hit = 0;
+#pragma unroll
+      for (int q = 0; q < KW; q++) hit |= (buf[j][q] & acc[q]) != 0ull;
+      if (__any(hit)) continue;
+      const int w = i >> 6;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (q == (w >> 6) && lane == (w & 63)) acc[q] |= 1ull << (i & 63);
+    }
+  };
+  load_group(i0, bufA, okA);
+  for (int g0 = i0; g0 < i1; g0 += 2 * KG) {
+    load_group(g0 + KG, bufB, okB);
+    eval_group(g0, bufA, okA);
+    load_group(g0 + 2 * KG, bufA, okA);
+    eval_group(g0 + KG, bufB, okB);
+  }
+}
+
+// The accept loop without a memory round trip on its serial chain (candidate capacities up to 64 * 64 * 4 = 16384; k_resolve_pipe
+// above stays for larger ones).  The accepted-candidate bitset lives in REGISTERS (word w in lane w % 64, slot w / 64),
+// the rows of the bit matrix arrive in groups of up to 32 candidates, two groups in flight, and nothing is written inside the
+// loop: k_resolve_pipe's per-candidate stores needed a release fence, i.e. a wait for every outstanding load - the
+// prefetched row included -, which made every candidate cost one global-memory latency (~1 us).  The decisions are the
+// same sequence (candidate i joins iff it sees the old cluster and every earlier candidate that has joined); cluster /
+// active appends, accept bytes and invalid flags are written afterwards by k_apply, one thread per candidate, from the bitset.
+__global__ __launch_bounds__(64) void k_resolve_fast(Dev D) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  Elem* E = &D.el[e];
+  if (!E->live) return;
+  const int n_cand = E->n_cand, n_clu = E->n_cluster;
+  if (n_cand == 0) return;
+  const int* cd = D.cand + (size_t)e * D.kcap;
+  const uint8_t* cc = D.can_clu + (size_t)e * D.kcap;
+  constexpr int kW = 4;
+  unsigned long long acc[kW] = {0ull, 0ull, 0ull, 0ull};
+  // the cluster-test results as a bitset: word w (candidates 64 w ..) in lane w % 64, slot w / 64
+  unsigned long long ccm[kW] = {0ull, 0ull, 0ull, 0ull};
+  const int nwords = (n_cand + 63) / 64;
+  for (int w0 = 0; w0 < nwords; w0 += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = (w0 + u) * 64 + lane;
+      v[u] = (w0 + u < nwords && i < n_cand) ? (int)cc[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const unsigned long long m = __ballot(v[u]);
+      const int w = w0 + u;
+#pragma unroll
+      for (int q = 0; q < kW; q++)
+        if (q == (w >> 6) && lane == (w & 63)) ccm[q] = m;
+    }
+  }
+  // candidates below 4096 only meet row words below 64 (one per lane), below 8192 two per lane, ...: the narrower the
+  // rows, the more candidates fit into the two groups in flight (32 / 16 / 8 per group)
+  resolve_range<1>(D, e, lane, ccm, acc, 0, n_cand < 4096 ? n_cand : 4096);
+  if (n_cand > 4096) resolve_range<2>(D, e, lane, ccm, acc, 4096, n_cand < 8192 ? n_cand : 8192);
+  if (n_cand > 8192) resolve_range<4>(D, e, lane, ccm, acc, 8192, n_cand);
+  // the bitset and its running counts for k_apply
+  int count = 0;
+#pragma unroll
+  for (int q = 0; q < kW; q++) {
+    const int c = __popcll(acc[q]);
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    const int w = q * 64 + lane;
+    if (w < D.kwords) {
+      D.accbits[(size_t)e * D.kwords + w] = acc[q];
+      D.accpre[(size_t)e * D.kwords + w] = count + inc - c;
+    }
+    count += __shfl(inc, 63);
+  }
+  if (lane == 0) {
+    E->pad0 = n_clu;  // where this round's voxels go (k_apply)
+    if (n_clu + count > D.ccap) { E->rtn = DIRECT_CLUSTER_OVERFLOW; E->live = 0; E->n_cluster = D.ccap; E->n_active = 0; }
+    else {
+      E->n_cluster = n_clu + count;
+      E->n_active = count;
+      if (count == 0) E->live = 0;  // CS:386-387
+      else E->iters += 1;           // CS:389
+    }
+  }
+}
+
+// what the accept loop decided, applied in parallel: accepted candidates join the cluster and become the active set of
+// the next round in candidate order (CS:371-379), the others are marked invalid (CS:380-383)
+__global__ __launch_bounds__(256) void k_apply(Dev D) {
+  const int e = blockIdx.y;
+  const Elem* E = &D.el[e];
+  if (!E->live) return;  // finished before this round, finished in it (nothing accepted), or overflowed (result not usable)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= E->n_cand) return;
+  const int w = i >> 6, b = i & 63;
+  const unsigned long long word = D.accbits[(size_t)e * D.kwords + w];
+  const int ok = (int)((word >> b) & 1ull);
+  const int p = D.cand[(size_t)e * D.kcap + i];
+  D.accept[(size_t)e * D.kcap + i] = (uint8_t)ok;
+  if (ok) {
+    const int r = D.accpre[(size_t)e * D.kwords + w] + __popcll(word & ((1ull << b) - 1ull));
+    D.cluster[(size_t)e * D.ccap + E->pad0 + r] = p;
+    D.active[(size_t)e * D.ccap + r] = p;
+  } else {
+    D.flags[(size_t)e * D.G + px(p) * D.max_yz + py(p) * D.max_z + pz(p)] |= F_INVALID;
+  }
+}
+
 __global__ void k_emit(Dev D, int batch, int32_t* vertex_idx, int32_t* cluster_xyz, int32_t* cluster_num, int32_t* iters,
                        int32_t* rtn) {
   const int e = blockIdx.y;
@@ -542,6 +797,7 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
   A(&D.cluster, B * D.ccap * sizeof(int)); A(&D.active, B * D.ccap * sizeof(int)); A(&D.cand, B * D.kcap * sizeof(int));
   A(&D.can_clu, B * D.kcap); A(&D.accept, B * D.kcap);
   A(&D.blocked, B * D.kcap * (size_t)D.kwords * sizeof(unsigned long long));
+  A(&D.accbits, B * (size_t)D.kwords * sizeof(unsigned long long)); A(&D.accpre, B * (size_t)D.kwords * sizeof(int));
   A(&D.el, B * sizeof(Elem));
   A(&h->st_vertex, B * 24 * 4); A(&h->st_xyz, B * (size_t)D.ccap * 12); A(&h->st_num, B * 4); A(&h->st_iters, B * 4); A(&h->st_rtn, B * 4);
   D.map = h->map;
@@ -618,7 +874,11 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
       // 1.6 - 2 x slower: thousands of short workgroups balance the seeds' very different loads better, and the flag
       // bytes of a round's rays live in L2 anyway)
       hipLaunchKernelGGL(k_convex, dim3(D.kcap, batch), dim3(256), 0, h->stream, D, 0);
-      hipLaunchKernelGGL(k_resolve_pipe, dim3(batch), dim3(64), (size_t)D.kwords * 8, h->stream, D);
+      if (D.kwords <= 256) {
+        hipLaunchKernelGGL(k_resolve_fast, dim3(batch), dim3(64), 0, h->stream, D);
+        hipLaunchKernelGGL(k_apply, dim3((D.kcap + 255) / 256, batch), dim3(256), 0, h->stream, D);
+      }
+      else hipLaunchKernelGGL(k_resolve_pipe, dim3(batch), dim3(64), (size_t)D.kwords * 8, h->stream, D);
     }
     CHIP_TRY(hipGetLastError());
     round += n;

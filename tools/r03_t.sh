@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-bash tools/profile_round.sh r03 > gpurun_out/r03_profile.log 2>&1; tail -2 gpurun_out/r03_profile.log | cut -c1-200
-head -4 gpurun_out/r03_bench_kernel_stats.csv | cut -c1-150
-cut -c1-300 gpurun_out/r03_bench.json
+timeout 600 python -m pytest tests/test_gpu_cluster.py tests/test_gpu_hull.py -x -q 2>&1 | tail -4
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o pc -- python $GRAFT_REPO_ROOT/tests/soak/cluster_bench.py > $GRAFT_REPO_ROOT/gpurun_out/r03_cluster_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/cb.err
+tail -1 $GRAFT_REPO_ROOT/gpurun_out/r03_cluster_bench.json | cut -c1-700
+f=$(find /tmp/pc -name '*kernel_stats.csv' | head -1); cp $f $GRAFT_REPO_ROOT/gpurun_out/r03_cluster_kernel_stats.csv; head -5 $f | cut -c1-150
