@@ -48,6 +48,8 @@ struct Dev {
   int max_x, max_y, max_z, max_yz, G;
   int ccap, kcap, kwords;  // cluster / candidate capacity, 64-bit words per candidate row
   const uint8_t* map;      // [G]
+  int* sat;                // [(max_x + 1)(max_y + 1)(max_z + 1)] obstacles in [0, x) x [0, y) x [0, z): summed-area table of map == 1
+  int sat_yz, sat_z;       // its strides
   uint8_t* flags;          // [batch][G]
   int* key;                // [batch][G]
   int *cluster, *active;   // [batch][ccap] packed voxels
@@ -68,6 +70,43 @@ __global__ void k_flags_init(Dev D, const uint8_t* inside /* or null */) {
     D.flags[e * D.G + i] = f;
     D.key[e * D.G + i] = KEY_NONE;
   }
+}
+
+// ---- summed-area table of the obstacles (once per map) ----------------------------------------------------
+// A ray's walk only visits voxels of the axis-aligned box spanned by its two ends (every axis makes exactly |d| steps,
+// see ray_walk_t), and it reports "blocked" only at a voxel with map == 1: a ray whose box holds no obstacle is clear
+// whatever else happens on the way.  In free space that is 85 - 97 % of the rays that pass the two cheap tests, and a
+// box sum is eight loads against ~25 dependent steps.
+__global__ void k_sat_fill(Dev D) {
+  const int n = (D.max_x + 1) * D.sat_yz;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int x = i / D.sat_yz, r = i - x * D.sat_yz, y = r / D.sat_z, z = r - y * D.sat_z;
+    D.sat[i] = (x > 0 && y > 0 && z > 0 && D.map[(x - 1) * D.max_yz + (y - 1) * D.max_z + (z - 1)] == 1) ? 1 : 0;
+  }
+}
+__global__ void k_sat_scan(Dev D, int axis) {  // running sums along one axis, one thread per line
+  const int nx = D.max_x + 1, ny = D.max_y + 1, nz = D.max_z + 1;
+  const int lines = axis == 0 ? ny * nz : (axis == 1 ? nx * nz : nx * ny);
+  const int len = axis == 0 ? nx : (axis == 1 ? ny : nz);
+  const int stride = axis == 0 ? D.sat_yz : (axis == 1 ? D.sat_z : 1);
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < lines; l += gridDim.x * blockDim.x) {
+    int base;
+    if (axis == 0) base = l;                                          // (y, z)
+    else if (axis == 1) base = (l / nz) * D.sat_yz + (l % nz);        // (x, z)
+    else base = l * nz;                                               // (x, y)
+    int acc = 0;
+    for (int k = 0; k < len; k++) {
+      acc += D.sat[base + k * stride];
+      D.sat[base + k * stride] = acc;
+    }
+  }
+}
+// obstacles in the box [lo, hi] (inclusive voxel coordinates)
+__device__ __forceinline__ int box_obstacles(const Dev& D, int x0, int y0, int z0, int x1, int y1, int z1) {
+  const int* S = D.sat;
+  const int a0 = x0 * D.sat_yz, a1 = (x1 + 1) * D.sat_yz, b0 = y0 * D.sat_z, b1 = (y1 + 1) * D.sat_z, c0 = z0, c1 = z1 + 1;
+  return S[a1 + b1 + c1] - S[a0 + b1 + c1] - S[a1 + b0 + c1] - S[a1 + b1 + c0] + S[a0 + b0 + c1] + S[a0 + b1 + c0] +
+         S[a1 + b0 + c0] - S[a0 + b0 + c0];
 }
 
 // exclusive position of `flag` among the flags of a 256-thread block + the block total (ordered compaction)
@@ -328,6 +367,15 @@ __device__ __forceinline__ int ray_walk_lin(const Dev& D, const uint8_t* fl, con
     if (f & F_OBS) return 1;
   }
 }
+// the tests in front of a walk as k_convex runs them: the reference's two, then the box test
+__device__ __forceinline__ int ray_needs_walk(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
+  const int ex = px(target), ey = py(target), ez = pz(target);
+  if (fl[ex * D.max_yz + ey * D.max_z + ez] & F_INSIDE) return 0;
+  const int mx = cx / 2 + (ex >> 1), my = cy / 2 + (ey >> 1), mz = cz / 2 + (ez >> 1);
+  if (fl[mx * D.max_yz + my * D.max_z + mz] & F_INSIDE) return 0;
+  return box_obstacles(D, cx < ex ? cx : ex, cy < ey ? cy : ey, cz < ez ? cz : ez, cx < ex ? ex : cx, cy < ey ? ey : cy,
+                       cz < ez ? ez : cz) != 0;
+}
 __device__ __forceinline__ int ray_blocked(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
   return ray_blocked_t([&](int x, int y, int z) -> unsigned { return fl[x * D.max_yz + y * D.max_z + z]; }, cx, cy, cz, target);
 }
@@ -359,7 +407,7 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
     int tgt = 0, need = 0;
     if (base < n_clu && t >= 0) {
       tgt = cl[t];
-      need = ray_needs_walk_t(rd, cx, cy, cz, tgt);
+      need = ray_needs_walk(D, fl, cx, cy, cz, tgt);
     }
     const unsigned long long bal = __ballot(need);
     if (lane == 0) wsum[wv] = __popcll(bal);
@@ -406,7 +454,7 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
   for (int base = 0; base < i || count > 0; base += 256) {
     const int j = base + tid;
     int need = 0;
-    if (base < i && j < i) need = ray_needs_walk_t(rd, cx, cy, cz, cd[j]);
+    if (base < i && j < i) need = ray_needs_walk(D, fl, cx, cy, cz, cd[j]);
     const unsigned long long bal = __ballot(need);
     if (lane == 0) wsum[wv] = __popcll(bal);
     __syncthreads();
@@ -792,6 +840,8 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
     h->allocs.push_back(q);
     *pp = (typename std::remove_pointer<decltype(pp)>::type)q;
   };
+  D.sat_z = cfg->max_z + 1; D.sat_yz = (cfg->max_y + 1) * D.sat_z;
+  A(&D.sat, (size_t)(cfg->max_x + 1) * D.sat_yz * sizeof(int));
   A(&h->map, G); A(&h->inside_tmp, G); A(&h->seeds, B * 3 * sizeof(int));
   A(&D.flags, B * G); A(&D.key, B * G * sizeof(int));
   A(&D.cluster, B * D.ccap * sizeof(int)); A(&D.active, B * D.ccap * sizeof(int)); A(&D.cand, B * D.kcap * sizeof(int));
@@ -829,6 +879,13 @@ direct_status_t direct_cluster_set_map(direct_cluster_handle_t h, int32_t mem, c
   CHIP_TRY(hipMemcpyAsync(h->map, map_data, (size_t)h->D.G, mem == DIRECT_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                           h->stream));
   CHIP_TRY(hipStreamSynchronize(h->stream));
+  {  // the obstacles' summed-area table for k_convex's box test
+    const Dev& D = h->D;
+    hipLaunchKernelGGL(k_sat_fill, dim3(1024), dim3(256), 0, h->stream, D);
+    for (int axis = 2; axis >= 0; axis--) hipLaunchKernelGGL(k_sat_scan, dim3(256), dim3(256), 0, h->stream, D, axis);
+    CHIP_TRY(hipGetLastError());
+    CHIP_TRY(hipStreamSynchronize(h->stream));
+  }
   h->have_map = true;
   return DIRECT_OK;
 }
