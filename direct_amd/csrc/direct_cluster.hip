@@ -14,6 +14,8 @@
 //                                       cluster voxel stops at once)
 //   the sequential accept loop CS:360-384 -> k_resolve (one wave; bit-matrix of candidate-candidate rays, the
 //                                       device form of paraResultCheck's packed triangle, cluster_engine.cu:37-67)
+// Not in the reference: a ray whose axis-aligned box holds no obstacle cannot be blocked (summed-area table of the map,
+// k_sat_*; per ray and per chunk of 256 cluster voxels, k_chunk_box) - the results are the reference's, most walks are not run.
 // Integer / byte work, HBM- and L2-bound: no MFMA anywhere.  Flag bytes of a seed's grid: bit0 use_data,
 // bit1 invalid_data, bit2 inside_data, bit3 map_data == 1 (one load per DDA step instead of two).
 #include <hip/hip_runtime.h>
@@ -50,6 +52,9 @@ struct Dev {
   const uint8_t* map;      // [G]
   int* sat;                // [(max_x + 1)(max_y + 1)(max_z + 1)] obstacles in [0, x) x [0, y) x [0, z): summed-area table of map == 1
   int sat_yz, sat_z;       // its strides
+  const float* inv;        // [kDimLimit] (float)(1.0 / (double)d), inv[0] = 0: the DDA's tDelta per |d| (ray_walk_lin)
+  int* cbox;               // [batch][nchunk][6] bounding box (lo xyz, hi xyz) of every 256 consecutive cluster voxels
+  int nchunk;              // (ccap + 255) / 256
   uint8_t* flags;          // [batch][G]
   int* key;                // [batch][G]
   int *cluster, *active;   // [batch][ccap] packed voxels
@@ -337,10 +342,10 @@ __device__ __forceinline__ int ray_walk_t(const RD& rd, int cx, int cy, int cz, 
     if (f & F_OBS) return 1;
   }
 }
-// The walk as k_convex runs it - the same float sequence, cheaper around it: 1 / |d| from a table (built per workgroup
+// The walk as k_convex runs it - the same float sequence, cheaper around it: 1 / |d| from a table (built once per handle
 // by the double division above; intbound_half(d) = 0.5 / |d| is exactly half of it: tested for every |d| < 2048), ONE
 // linear voxel index that moves by the axis' stride (a voxel has one index, so "end reached" is one compare).
-__device__ __forceinline__ void inv_table_init(float* inv /* shared[kDimLimit] */) {
+__global__ void k_inv_table(float* inv) {
   for (int d = threadIdx.x; d < kDimLimit; d += blockDim.x) inv[d] = d ? (float)(1.0 / (double)d) : 0.0f;
 }
 __device__ __forceinline__ int ray_walk_lin(const Dev& D, const uint8_t* fl, const float* inv, int cx, int cy, int cz, int target) {
@@ -368,9 +373,11 @@ __device__ __forceinline__ int ray_walk_lin(const Dev& D, const uint8_t* fl, con
   }
 }
 // the tests in front of a walk as k_convex runs them: the reference's two, then the box test
-__device__ __forceinline__ int ray_needs_walk(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
+// (any_target: the kernel-level entry point takes arbitrary targets; inside polygonGeneration a target is a cluster voxel or
+// a candidate, and neither lies inside the cube: CS:491-494, 301-353)
+__device__ __forceinline__ int ray_needs_walk(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target, int any_target) {
   const int ex = px(target), ey = py(target), ez = pz(target);
-  if (fl[ex * D.max_yz + ey * D.max_z + ez] & F_INSIDE) return 0;
+  if (any_target && (fl[ex * D.max_yz + ey * D.max_z + ez] & F_INSIDE)) return 0;
   const int mx = cx / 2 + (ex >> 1), my = cy / 2 + (ey >> 1), mz = cz / 2 + (ez >> 1);
   if (fl[mx * D.max_yz + my * D.max_z + mz] & F_INSIDE) return 0;
   return box_obstacles(D, cx < ex ? cx : ex, cy < ey ? cy : ey, cz < ez ? cz : ez, cx < ex ? ex : cx, cy < ey ? ey : cy,
@@ -378,6 +385,39 @@ __device__ __forceinline__ int ray_needs_walk(const Dev& D, const uint8_t* fl, i
 }
 __device__ __forceinline__ int ray_blocked(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target) {
   return ray_blocked_t([&](int x, int y, int z) -> unsigned { return fl[x * D.max_yz + y * D.max_z + z]; }, cx, cy, cz, target);
+}
+
+// bounding boxes of the cluster in chunks of 256 voxels (cluster order is spatially coherent: the cube's surface layer by
+// layer, then every round's shell): k_convex tests a candidate against a whole chunk's box before it looks at its rays
+__global__ __launch_bounds__(256) void k_chunk_box(Dev D) {
+  __shared__ int red[4][6];
+  const int e = blockIdx.y, m = blockIdx.x, tid = threadIdx.x;
+  const Elem* E = &D.el[e];
+  if (!E->live) return;
+  const int n = E->n_cluster;
+  if (m * 256 >= n) return;
+  const int t = m * 256 + tid;
+  int v[6] = {kDimLimit, kDimLimit, kDimLimit, -1, -1, -1};
+  if (t < n) {
+    const int p = D.cluster[(size_t)e * D.ccap + t];
+    v[0] = v[3] = px(p); v[1] = v[4] = py(p); v[2] = v[5] = pz(p);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int lo = __shfl_xor(v[a], d), hi = __shfl_xor(v[a + 3], d);
+      v[a] = lo < v[a] ? lo : v[a];
+      v[a + 3] = hi > v[a + 3] ? hi : v[a + 3];
+    }
+  if ((tid & 63) == 0)
+    for (int a = 0; a < 6; a++) red[tid >> 6][a] = v[a];
+  __syncthreads();
+  if (tid < 6) {
+    int r = red[0][tid];
+    for (int w = 1; w < 4; w++) r = tid < 3 ? (red[w][tid] < r ? red[w][tid] : r) : (red[w][tid] > r ? red[w][tid] : r);
+    D.cbox[((size_t)e * D.nchunk + m) * 6 + tid] = r;
+  }
 }
 
 // one workgroup per candidate.  full = 1 (kernel-level parity entry point): no early exit, every row is complete
@@ -395,19 +435,34 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
   // queued (in order) and walked 256 at a time, every lane busy; the result is an AND, so the order is free.
   __shared__ int queue[512];
   __shared__ int wsum[4];
-  __shared__ float inv[kDimLimit];
-  inv_table_init(inv);  // (the first __syncthreads below comes before its first use)
+  const float* inv = D.inv;
   int head = 0, count = 0;  // uniform over the workgroup
   const int lane = tid & 63, wv = tid >> 6;
   const auto rd = [&](int x, int y, int z) -> unsigned { return fl[x * D.max_yz + y * D.max_z + z]; };
-  for (int base = 0; base < n_clu || count > 0; base += 256) {
+  // whole chunks first: a chunk whose box, joined with the candidate, holds no obstacle cannot block it (k_chunk_box)
+  __shared__ unsigned char skip[256];
+  const int nch = (n_clu + 255) >> 8;
+  if (tid < nch) {
+    const int* bx = D.cbox + ((size_t)e * D.nchunk + tid) * 6;
+    skip[tid] = box_obstacles(D, cx < bx[0] ? cx : bx[0], cy < bx[1] ? cy : bx[1], cz < bx[2] ? cz : bx[2], cx > bx[3] ? cx : bx[3],
+                              cy > bx[4] ? cy : bx[4], cz > bx[5] ? cz : bx[5]) == 0;
+  }
+  __syncthreads();
+  auto walk_batch = [&]() {  // up to 256 queued rays, every lane busy
+    const int n = count < 256 ? count : 256;
+    if (tid < n) bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, queue[(head + tid) & 511]);
+    head = (head + n) & 511;
+    count -= n;
+  };
+  for (int m = nch - 1; m >= 0; m--) {
     // newest cluster voxels first, like the reference's loop (cluster_engine_cpu.cpp:41): they lie next to the
     // candidate shell and are the likeliest to reject, so the early exit below comes sooner
-    const int t = n_clu - 1 - (base + tid);
+    if (m < 256 && skip[m]) continue;
+    const int t = m * 256 + tid;
     int tgt = 0, need = 0;
-    if (base < n_clu && t >= 0) {
+    if (t < n_clu) {
       tgt = cl[t];
-      need = ray_needs_walk(D, fl, cx, cy, cz, tgt);
+      need = ray_needs_walk(D, fl, cx, cy, cz, tgt, full);
     }
     const unsigned long long bal = __ballot(need);
     if (lane == 0) wsum[wv] = __popcll(bal);
@@ -417,18 +472,15 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
     if (need) queue[(head + off + __popcll(bal & ((1ull << lane) - 1ull))) & 511] = tgt;
     count += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
-    const bool last = base + 256 >= n_clu;
-    if (count >= 256 || (last && count > 0)) {
-      const int n = count < 256 ? count : 256;
-      if (tid < n) bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, queue[(head + tid) & 511]);
-      head = (head + n) & 511;
-      count -= n;
+    if (count >= 256) {
+      walk_batch();
       if (!full && __syncthreads_or(bad)) {  // a rejected candidate's rays towards other candidates are never consulted
         if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = 0;
         return;
       }
     }
   }
+  while (count > 0) walk_batch();
   bad = __syncthreads_or(bad);
   if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = bad ? 0 : 1;
   if (bad && !full) return;
@@ -454,7 +506,7 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
   for (int base = 0; base < i || count > 0; base += 256) {
     const int j = base + tid;
     int need = 0;
-    if (base < i && j < i) need = ray_needs_walk(D, fl, cx, cy, cz, cd[j]);
+    if (base < i && j < i) need = ray_needs_walk(D, fl, cx, cy, cz, cd[j], full);
     const unsigned long long bal = __ballot(need);
     if (lane == 0) wsum[wv] = __popcll(bal);
     __syncthreads();
@@ -842,6 +894,11 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
   };
   D.sat_z = cfg->max_z + 1; D.sat_yz = (cfg->max_y + 1) * D.sat_z;
   A(&D.sat, (size_t)(cfg->max_x + 1) * D.sat_yz * sizeof(int));
+  D.nchunk = (cfg->cluster_capacity + 255) / 256;
+  float* invp = nullptr;
+  A(&invp, kDimLimit * sizeof(float));
+  D.inv = invp;
+  A(&D.cbox, B * (size_t)D.nchunk * 6 * sizeof(int));
   A(&h->map, G); A(&h->inside_tmp, G); A(&h->seeds, B * 3 * sizeof(int));
   A(&D.flags, B * G); A(&D.key, B * G * sizeof(int));
   A(&D.cluster, B * D.ccap * sizeof(int)); A(&D.active, B * D.ccap * sizeof(int)); A(&D.cand, B * D.kcap * sizeof(int));
@@ -851,6 +908,10 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
   A(&D.el, B * sizeof(Elem));
   A(&h->st_vertex, B * 24 * 4); A(&h->st_xyz, B * (size_t)D.ccap * 12); A(&h->st_num, B * 4); A(&h->st_iters, B * 4); A(&h->st_rtn, B * 4);
   D.map = h->map;
+  if (st == DIRECT_OK) {
+    hipLaunchKernelGGL(k_inv_table, dim3(1), dim3(256), 0, nullptr, invp);
+    if (hipDeviceSynchronize() != hipSuccess) st = cfail(DIRECT_ERR_DEVICE, "k_inv_table failed");
+  }
   if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess))
     st = cfail(DIRECT_ERR_DEVICE, "hipEventCreate failed");
   if (st != DIRECT_OK) {
@@ -930,6 +991,7 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
       // workgroups cost ~0.1 ms; a persistent ticket kernel with the rays' voxels staged in LDS was built and measured
       // 1.6 - 2 x slower: thousands of short workgroups balance the seeds' very different loads better, and the flag
       // bytes of a round's rays live in L2 anyway)
+      hipLaunchKernelGGL(k_chunk_box, dim3(D.nchunk, batch), dim3(256), 0, h->stream, D);
       hipLaunchKernelGGL(k_convex, dim3(D.kcap, batch), dim3(256), 0, h->stream, D, 0);
       if (D.kwords <= 256) {
         hipLaunchKernelGGL(k_resolve_fast, dim3(batch), dim3(64), 0, h->stream, D);
@@ -1003,6 +1065,7 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
   CHIP_TRY(hipMemsetAsync(D.blocked, 0, (size_t)n_candidate * D.kwords * 8, h->stream));
   CHIP_TRY(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(k_flags_init, dim3(std::min((D.G + 255) / 256, 4096), 1), dim3(256), 0, h->stream, D, (const uint8_t*)h->inside_tmp);
+  hipLaunchKernelGGL(k_chunk_box, dim3(D.nchunk, 1), dim3(256), 0, h->stream, D);
   hipLaunchKernelGGL(k_convex, dim3(n_candidate, 1), dim3(256), 0, h->stream, D, 1);
   hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), (size_t)D.kwords * 8, h->stream, D, 1);
   CHIP_TRY(hipGetLastError());
