@@ -73,10 +73,18 @@ class ClusterGenerator:
         assert g.shape == self.dims
         _check(_lib().direct_cluster_set_map(self.h, abi.MEM_HOST, g.ctypes.data))
 
-    def polygon_generation(self, seeds, itr_inflate_max=1000, itr_cluster_max=50):
-        """-> dict(vertex_idx [B][24], clusters: list of [n][3] arrays, cluster_num, iters, rtn)"""
+    def polygon_generation(self, seeds, itr_inflate_max=1000, itr_cluster_max=50, fetch_clusters=True):
+        """-> dict(vertex_idx [B][24], clusters: list of [n][3] arrays, cluster_num, iters, rtn).  fetch_clusters=False:
+        the voxels stay on the device (for hull_planes(batch=...)), clusters is None."""
         seeds = np.ascontiguousarray(seeds, np.int32).reshape(-1, 3)
         B = seeds.shape[0]
+        if not fetch_clusters:
+            v = np.zeros((B, 24), np.int32)
+            n, it, rtn = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+            _check(_lib().direct_cluster_polygon_generation_batch(self.h, B, seeds.ctypes.data, int(itr_inflate_max),
+                                                                  int(itr_cluster_max), abi.MEM_HOST, v.ctypes.data, None,
+                                                                  n.ctypes.data, it.ctypes.data, rtn.ctypes.data))
+            return dict(vertex_idx=v, clusters=None, cluster_num=n, iters=it, rtn=rtn)
         v = np.zeros((B, 24), np.int32)
         cl = np.zeros((B, self.ccap, 3), np.int32)
         n, it, rtn = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)

@@ -41,6 +41,12 @@ for rep in range(3):
     hp = gen.hull_planes(RES, LOWER, batch=n)
     hts.append(time.perf_counter() - t)
     hk.append(gen.last_ms())
+cts = []   # the chain as direct::polyhedronGenerator::getConvexPolyBatch runs it: clusters stay on the device, planes come back
+for rep in range(3):
+    t = time.perf_counter()
+    gen.polygon_generation(seeds, 1000, 50, fetch_clusters=False)
+    hp2 = gen.hull_planes(RES, LOWER, batch=n, vertex_capacity=1)
+    cts.append(time.perf_counter() - t)
 t = time.perf_counter()
 href = [hullapi.hull_planes(r["clusters"][b], RES, LOWER) for b in range(m)]
 hcpu = (time.perf_counter() - t) / m
@@ -60,5 +66,7 @@ print(json.dumps({"seeds": n, "map": dims, "obstacle_frac": float(grid.mean()), 
                   "cluster_voxels_mean": float(r["cluster_num"].mean()), "rounds_mean": float(r["iters"].mean()),
                   "device_wall_ms_best": min(ts) * 1e3, "device_event_ms": kms, "device_ms_per_seed": min(ts) * 1e3 / n,
                   "cpu_oracle_ms_per_seed": cpu * 1e3, "cpu_kind": "reference serialConvexTest + restated loops, 1 thread",
-                  "bit_identical_to_cpu_on_first_%d" % m: bool(same), "hull_planes": hull}))
+                  "bit_identical_to_cpu_on_first_%d" % m: bool(same), "hull_planes": hull,
+                  "seeds_to_planes_chain": {"wall_ms_best": min(cts) * 1e3, "ms_per_seed": min(cts) * 1e3 / n,
+                                            "same_planes": bool(all(np.array_equal(a, b) for a, b in zip(hp2["planes"], hp["planes"])))}}))
 gen.close()
