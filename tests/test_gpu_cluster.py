@@ -43,6 +43,20 @@ def test_polygon_generation_matches_golden(built):
     gen.close()
 
 
+def test_large_candidate_capacity_takes_the_general_kernels(built):
+    """Above 16384 candidates per round the row of the bit matrix no longer fits the registers / LDS of the fast
+    accept loop and of k_convex's queued candidate rays: the general kernels (k_resolve_pipe, un-queued rows) run
+    instead and must give the same clusters."""
+    g = np.load(os.path.join(GOLD, "cluster_polygon_48.npz"))
+    gen = cluster.ClusterGenerator(g["grid"].shape, max_batch=16, cluster_capacity=8192, candidate_capacity=20000)
+    gen.set_map(g["grid"])
+    r = gen.polygon_generation(g["seeds"])
+    assert (r["rtn"] == 0).all()
+    assert np.array_equal(r["cluster_num"], g["cluster_num"]) and np.array_equal(r["iters"], g["iters"])
+    assert np.array_equal(np.concatenate(r["clusters"]), g["cluster_xyz"])
+    gen.close()
+
+
 def test_polygon_generation_on_a_larger_map_against_the_oracle(built):
     """120 x 120 x 24 map, 48 seeds in one batch, against the oracle with the reference's serialConvexTest."""
     grid, seeds = problems.make_voxel_map()

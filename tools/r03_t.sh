@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-timeout 1500 python tests/soak/real_corridor_bench.py > gpurun_out/r03_real_corridors.json 2> gpurun_out/rc.err; tail -3 gpurun_out/rc.err; cut -c1-700 gpurun_out/r03_real_corridors.json
+timeout 900 python -m pytest tests/test_gpu_cluster.py -x -q > gpurun_out/gpu_suite.log 2>&1; grep -E "passed|failed|Error|assert" gpurun_out/gpu_suite.log | tail -5
