@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-timeout 900 python -m pytest tests/test_gpu_cluster.py -x -q > gpurun_out/gpu_suite.log 2>&1; grep -E "passed|failed|Error|assert" gpurun_out/gpu_suite.log | tail -5
+timeout 1500 python tests/soak/hull_soak.py 20 > gpurun_out/r03_hull_soak.json 2> gpurun_out/hs.err; tail -3 gpurun_out/hs.err; cut -c1-900 gpurun_out/r03_hull_soak.json
