@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-timeout 1500 python tests/soak/hull_soak.py 20 > gpurun_out/r03_hull_soak.json 2> gpurun_out/hs.err; tail -3 gpurun_out/hs.err; cut -c1-900 gpurun_out/r03_hull_soak.json
+for r in 0 1 2 3 4 6; do echo "mid ratio $r"; DIRECT_DDP_MID=$r timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(round(d['value']), d['natural_exit']['ms'], d['natural_exit']['kernel_ms'], round(d['natural_exit']['iter_per_s']))"; done
