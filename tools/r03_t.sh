@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-for r in 0 1 2 3 4 6; do echo "mid ratio $r"; DIRECT_DDP_MID=$r timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print(round(d['value']), d['natural_exit']['ms'], d['natural_exit']['kernel_ms'], round(d['natural_exit']['iter_per_s']))"; done
+timeout 2400 python tests/soak/parity_soak.py > gpurun_out/soak.log 2>&1; tail -3 gpurun_out/soak.log | cut -c1-600
+timeout 1500 python tests/soak/help_stress.py > gpurun_out/help_stress.log 2>&1; tail -2 gpurun_out/help_stress.log | cut -c1-400
