@@ -431,28 +431,41 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
   const int c = cd[i], cx = px(c), cy = py(c), cz = pz(c), n_clu = E->n_cluster;
   int bad = 0;
   // About half of a candidate's rays towards the cluster end at the two cheap tests (the midpoint lies inside the
-  // inflated cube): left in place they idle through the walks of their wave.  The rays that have to be walked are
-  // queued (in order) and walked 256 at a time, every lane busy; the result is an AND, so the order is free.
-  __shared__ int queue[512];
-  __shared__ int wsum[4];
-  const float* inv = D.inv;
-  int head = 0, count = 0;  // uniform over the workgroup
-  const int lane = tid & 63, wv = tid >> 6;
-  const auto rd = [&](int x, int y, int z) -> unsigned { return fl[x * D.max_yz + y * D.max_z + z]; };
-  // whole chunks first: a chunk whose box, joined with the candidate, holds no obstacle cannot block it (k_chunk_box)
+  // inflated cube) and most of the rest at the box test: left in place they idle through the walks of their wave.  The
+  // rays that have to be walked are queued (in order) and walked 64 at a time, every lane busy; the result is an AND, so
+  // the order is free.  Every WAVE keeps its own queue and takes every fourth run of 64 targets: no workgroup barrier
+  // inside the loops (two per 256 rays cost more than the tests between them), a flag in LDS carries the early exit.
+  __shared__ int queue[4][128];
+  __shared__ int s_bad;
   __shared__ unsigned char skip[256];
+  const float* inv = D.inv;
+  const int lane = tid & 63, wv = tid >> 6;
+  int* wq = queue[wv];
+  int head = 0, count = 0;  // uniform over the wave
+  // whole chunks first: a chunk whose box, joined with the candidate, holds no obstacle cannot block it (k_chunk_box)
   const int nch = (n_clu + 255) >> 8;
+  if (tid == 0) s_bad = 0;
   if (tid < nch) {
     const int* bx = D.cbox + ((size_t)e * D.nchunk + tid) * 6;
     skip[tid] = box_obstacles(D, cx < bx[0] ? cx : bx[0], cy < bx[1] ? cy : bx[1], cz < bx[2] ? cz : bx[2], cx > bx[3] ? cx : bx[3],
                               cy > bx[4] ? cy : bx[4], cz > bx[5] ? cz : bx[5]) == 0;
   }
   __syncthreads();
-  auto walk_batch = [&]() {  // up to 256 queued rays, every lane busy
-    const int n = count < 256 ? count : 256;
-    if (tid < n) bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, queue[(head + tid) & 511]);
-    head = (head + n) & 511;
+  // the wave's ordered append / take: LDS executes a wave's accesses in order, the barrier only stops the compiler
+  auto push = [&](int need, int val) {
+    const unsigned long long bal = __ballot(need);
+    if (need) wq[(head + count + __popcll(bal & ((1ull << lane) - 1ull))) & 127] = val;
+    count += __popcll(bal);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto take = [&](int n) {  // the lane's queued value (-1: none)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int v = lane < n ? wq[(head + lane) & 127] : -1;
+    head = (head + n) & 127;
     count -= n;
+    __builtin_amdgcn_wave_barrier();
+    return v;
   };
   for (int m = nch - 1; m >= 0; m--) {
     // newest cluster voxels first, like the reference's loop (cluster_engine_cpu.cpp:41): they lie next to the
@@ -464,23 +477,18 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
       tgt = cl[t];
       need = ray_needs_walk(D, fl, cx, cy, cz, tgt, full);
     }
-    const unsigned long long bal = __ballot(need);
-    if (lane == 0) wsum[wv] = __popcll(bal);
-    __syncthreads();
-    int off = count;
-    for (int w = 0; w < wv; w++) off += wsum[w];
-    if (need) queue[(head + off + __popcll(bal & ((1ull << lane) - 1ull))) & 511] = tgt;
-    count += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    if (count >= 256) {
-      walk_batch();
-      if (!full && __syncthreads_or(bad)) {  // a rejected candidate's rays towards other candidates are never consulted
-        if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = 0;
-        return;
-      }
+    push(need, tgt);
+    if (count >= 64) {
+      const int q = take(64);
+      bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, q);
+      if (!full && __any(bad)) s_bad = 1;  // a rejected candidate's rays towards other candidates are never consulted
     }
+    if (!full && *(volatile int*)&s_bad) break;
   }
-  while (count > 0) walk_batch();
+  if (count > 0 && !(!full && *(volatile int*)&s_bad)) {
+    const int q = take(count);
+    if (q >= 0) bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, q);
+  }
   bad = __syncthreads_or(bad);
   if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = bad ? 0 : 1;
   if (bad && !full) return;
@@ -496,35 +504,24 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
     }
     return;
   }
-  // the same queue for the rays towards the earlier candidates: the row of the bit matrix is collected in LDS (a blocked
+  // the same queues for the rays towards the earlier candidates: the row of the bit matrix is collected in LDS (a blocked
   // ray is rare: one ds_or per hit) and written once
   const int nw = (i + 63) / 64;
   for (int w = tid; w < nw; w += 256) srow[w] = 0ull;
   head = 0;
   count = 0;
   __syncthreads();
-  for (int base = 0; base < i || count > 0; base += 256) {
+  for (int base = 0; base < i; base += 256) {
     const int j = base + tid;
-    int need = 0;
-    if (base < i && j < i) need = ray_needs_walk(D, fl, cx, cy, cz, cd[j], full);
-    const unsigned long long bal = __ballot(need);
-    if (lane == 0) wsum[wv] = __popcll(bal);
-    __syncthreads();
-    int off = count;
-    for (int w = 0; w < wv; w++) off += wsum[w];
-    if (need) queue[(head + off + __popcll(bal & ((1ull << lane) - 1ull))) & 511] = j;
-    count += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    const bool last = base + 256 >= i;
-    if (count >= 256 || (last && count > 0)) {
-      const int n = count < 256 ? count : 256;
-      if (tid < n) {
-        const int jq = queue[(head + tid) & 511];
-        if (ray_walk_lin(D, fl, inv, cx, cy, cz, cd[jq])) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
-      }
-      head = (head + n) & 511;
-      count -= n;
+    push(j < i ? ray_needs_walk(D, fl, cx, cy, cz, cd[j], full) : 0, j);
+    if (count >= 64) {
+      const int jq = take(64);
+      if (ray_walk_lin(D, fl, inv, cx, cy, cz, cd[jq])) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
     }
+  }
+  if (count > 0) {
+    const int jq = take(count);
+    if (jq >= 0 && ray_walk_lin(D, fl, inv, cx, cy, cz, cd[jq])) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
   }
   __syncthreads();
   for (int w = tid; w < nw; w += 256) row[w] = srow[w];
