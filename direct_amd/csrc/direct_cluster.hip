@@ -344,7 +344,9 @@ __device__ __forceinline__ int ray_walk_t(const RD& rd, int cx, int cy, int cz, 
 }
 // The walk as k_convex runs it - the same float sequence, cheaper around it: 1 / |d| from a table (built once per handle
 // by the double division above; intbound_half(d) = 0.5 / |d| is exactly half of it: tested for every |d| < 2048), ONE
-// linear voxel index that moves by the axis' stride (a voxel has one index, so "end reached" is one compare).
+// linear voxel index that moves by the axis' stride (a voxel has one index, so "end reached" is one compare; no axis makes
+// more than |d| steps before the end is reached - the tMax of a finished axis is above 1, those of the others below - so
+// the index never leaves the box of the two ends and cannot alias another voxel's).
 __global__ void k_inv_table(float* inv) {
   for (int d = threadIdx.x; d < kDimLimit; d += blockDim.x) inv[d] = d ? (float)(1.0 / (double)d) : 0.0f;
 }
@@ -1140,14 +1142,17 @@ direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int3
     for (int i = 0; i < 8; i++) dev[i] = user[i];
   }
   const int32_t *sx = cluster_xyz, *sn = cluster_num;
-  void *tx = nullptr, *tn = nullptr;
-  if (cluster_xyz && mem_in == DIRECT_MEM_HOST) {  // caller-provided voxels from the host: staged in the generation's own staging block
-    CHIP_TRY(hipMalloc(&tn, nb * sizeof(int32_t)));
-    CHIP_TRY(hipMemcpyAsync(h->st_xyz, cluster_xyz, nb * (size_t)D.ccap * 12, hipMemcpyHostToDevice, h->stream));
-    CHIP_TRY(hipMemcpyAsync(tn, cluster_num, nb * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    sx = h->st_xyz; sn = (const int32_t*)tn;
+  if (cluster_xyz && mem_in == DIRECT_MEM_HOST) {  // caller-provided voxels from the host: the filled prefix of every row,
+                                                   // through the generation's own staging blocks (st_xyz, st_num)
+    for (int b = 0; b < batch; b++) {
+      const int n = cluster_num[b] < 0 ? 0 : (cluster_num[b] > D.ccap ? D.ccap : cluster_num[b]);
+      if (n > 0)
+        CHIP_TRY(hipMemcpyAsync(h->st_xyz + (size_t)b * D.ccap * 3, cluster_xyz + (size_t)b * D.ccap * 3, (size_t)n * 12,
+                                hipMemcpyHostToDevice, h->stream));
+    }
+    CHIP_TRY(hipMemcpyAsync(h->st_num, cluster_num, nb * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    sx = h->st_xyz; sn = h->st_num;
   }
-  (void)tx;
   CHIP_TRY(hipEventRecord(h->ev0, h->stream));
   CHIP_TRY(hipMemset2DAsync(H.lines, H.line_words * sizeof(int), 0x7f, H.half_words * sizeof(int), nb, h->stream));
   CHIP_TRY(hipMemset2DAsync(H.lines + H.half_words, H.line_words * sizeof(int), 0x80, H.half_words * sizeof(int), nb, h->stream));
@@ -1165,7 +1170,6 @@ direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int3
     for (int i = 0; i < 8 && e == hipSuccess; i++)
       if (user[i]) e = hipMemcpyAsync(user[i], dev[i], sz[i], hipMemcpyDeviceToHost, h->stream);
   hipError_t e2 = hipStreamSynchronize(h->stream);
-  if (tn) (void)hipFree(tn);
   if (e != hipSuccess || e2 != hipSuccess)
     return cfail(DIRECT_ERR_DEVICE, std::string("hull_planes_batch: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   return DIRECT_OK;

@@ -31,7 +31,8 @@ namespace hull {
 typedef long long i64;
 
 constexpr int kCandCap = 2048;     // candidates per cluster (24 KB of LDS in the edge kernel)
-constexpr int kRawCap = 32768;     // facet planes reported by edges, duplicates included
+constexpr int kRawCap = 8192;      // facet planes reported by edges, duplicates included (a few hundred for real clusters;
+                                   // bounds the O(m^2) duplicate removal of k_hull_finish)
 constexpr int LINE_MIN_INIT = 0x7f7f7f7f, LINE_MAX_INIT = (int)0x80808080;  // byte patterns: hipMemset can write them
 
 struct Lines {  // first / last point of every axis-parallel lattice line of one cluster (half-voxel lattice)

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_hull_edges(HullDev H) {
 __global__ __launch_bounds__(256) void k_hull_finish(HullDev H, double res, double lx, double ly, double lz, int plane_cap, int vert_cap,
                                                      double* planes, long long* plane_int, int32_t* n_planes, double* vertices,
                                                      int32_t* n_vertices, double* center, int32_t* degenerate, int32_t* rtn) {
-  __shared__ unsigned char uniq[hull::kRawCap];
+  __shared__ __attribute__((aligned(8))) unsigned char uniq[hull::kRawCap];
   __shared__ int wsum[4];
   __shared__ int base_s, np_s;
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -100,7 +100,7 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
  *   offset on the lattice, n . q + K <= 0), n_planes[batch], vertices[batch][vertex_capacity][3], n_vertices[batch],
  *   center[batch][3], degenerate[batch] (checkDegeneratePoly), rtn[batch] (codes below). */
 #define DIRECT_HULL_OK 0
-#define DIRECT_HULL_OVERFLOW 1 /* more planes / vertices than the capacity of an output that was asked for, or more than 2048 line-extreme points */
+#define DIRECT_HULL_OVERFLOW 1 /* more planes / vertices than the capacity of an output that was asked for, more than 2048 line-extreme points or 8192 plane reports of hull edges */
 #define DIRECT_HULL_FLAT 3     /* empty cluster, or the points do not span three dimensions (the reference's cdd call fails) */
 direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int32_t batch, int32_t mem_in,
                                                  const int32_t* cluster_xyz, const int32_t* cluster_num, double resolution,
