@@ -185,7 +185,7 @@ DDP_DEV void static_for_down(F&& f) {  // B, B-1, ..., E
   }
 }
 
-constexpr int kPLim = 54;  // DIRECT_P_LIMIT: (64 * 6 - 55) / 6, six row slots per lane
+constexpr int kPLim = 76;  // DIRECT_P_LIMIT: (64 * 8 - 55) / 6, eight row slots per lane
 
 #if !defined(DIRECT_EMULATE)
 #if defined(DDP_TIMING)
@@ -764,7 +764,7 @@ struct Wave {
   // spill reload waits for every outstanding load, the HBM prefetch included
   static constexpr bool kWide = sizeof(St) < sizeof(double) && RPL <= 2;
   // Field widths of the packed row descriptor: rows fit eight bits up to four row slots per lane (6 P + 55 <= 255);
-  // the five- and six-slot kernels (polytopes of 34 .. 54 planes) take a ninth bit from a0 (< 64).
+  // the kernels with five to eight slots (polytopes of 34 .. 76 planes: 6 P + 55 <= 511) take a ninth bit from a0 (< 64).
   static constexpr int kRB = RPL > 4 ? 9 : 8;
   static constexpr int kRMask = (1 << kRB) - 1, kAMask = (1 << (16 - kRB)) - 1;
   static constexpr int kNPL = (4 * Lds::kPMax + 63) / 64 > 2 ? (4 * Lds::kPMax + 63) / 64 : 2;  // plane words per lane

@@ -409,7 +409,9 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
     else if ((h)->rpl == 3) hipLaunchKernelGGL((KERNEL<Real, 3>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
     else if ((h)->rpl == 4) hipLaunchKernelGGL((KERNEL<Real, 4>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
     else if ((h)->rpl == 5) hipLaunchKernelGGL((KERNEL<Real, 5>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<Real, 6>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__);       \
+    else if ((h)->rpl == 6) hipLaunchKernelGGL((KERNEL<Real, 6>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
+    else if ((h)->rpl == 7) hipLaunchKernelGGL((KERNEL<Real, 7>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<Real, 8>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__);       \
   } while (0)
 
 template <typename Real>
@@ -425,7 +427,9 @@ static int resident_slots(direct_ddp_handle_t h, int n_cu) {
   else if (h->rpl == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 3>, 64, 0);
   else if (h->rpl == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 4>, 64, 0);
   else if (h->rpl == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 5>, 64, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 6>, 64, 0);
+  else if (h->rpl == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 6>, 64, 0);
+  else if (h->rpl == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 7>, 64, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 8>, 64, 0);
   return (e == hipSuccess && per_cu > 0) ? per_cu * n_cu : 0;
 }
 template <typename Real>

@@ -40,7 +40,9 @@ static void dispatch_c(Emu<Real>& E, F f) {
   else if (E.rpl == 3) for_each_wave<Cmp, Real, 3>(E, f);
   else if (E.rpl == 4) for_each_wave<Cmp, Real, 4>(E, f);
   else if (E.rpl == 5) for_each_wave<Cmp, Real, 5>(E, f);
-  else for_each_wave<Cmp, Real, 6>(E, f);
+  else if (E.rpl == 6) for_each_wave<Cmp, Real, 6>(E, f);
+  else if (E.rpl == 7) for_each_wave<Cmp, Real, 7>(E, f);
+  else for_each_wave<Cmp, Real, 8>(E, f);
 }
 template <typename Real, typename F>
 static void dispatch(Emu<Real>& E, F f) {

@@ -118,7 +118,7 @@ for mode in range(2):
     modes.append(cs)
 same = all(len(a[0]) == len(b[0]) and all(np.array_equal(x[0], y[0]) for x, y in zip(a[0], b[0])) for a, b in zip(*modes))
 all_cors = [c for c, ok in modes[1] if ok and len(c) >= 2]
-cors = [c for c in all_cors if max(len(q[0]) for q in c) <= abi.P_LIMIT]   # the DDP kernels take up to 54 planes per polytope
+cors = [c for c in all_cors if max(len(q[0]) for q in c) <= abi.P_LIMIT]   # the DDP kernels take up to DIRECT_P_LIMIT planes per polytope
 batches = []
 for c in cors:
     pm = max(len(q[0]) for q in c)

@@ -132,7 +132,7 @@ def test_line_initialisation_matches_oracle(kind):
     assert helpers.rel(g.T, o.T) < 1e-8
 
 
-@pytest.mark.parametrize("p_max", [20, 32, 44, 54])
+@pytest.mark.parametrize("p_max", [20, 32, 44, 54, 76])
 def test_many_planes_per_polytope(p_max):
     """P up to 20 / 32 planes: nc = 175 / 247 rows per knot, the RPL = 3 / 4 instantiations."""
     batch = helpers.with_extra_planes(problems.make_batch("corridor", 2, 6, seed=41), p_max, seed=p_max)

@@ -256,11 +256,11 @@ def test_recorded_corridor_replay_in_one_batch(built):
     assert helpers.rel(g1.bez, r1.bez) < 1e-5
 
 
-@pytest.mark.parametrize("p_max", [20, 32, 44, 54])
+@pytest.mark.parametrize("p_max", [20, 32, 44, 54, 76])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_many_planes_per_polytope(built, p_max, dtype):
-    """P up to 20 / 32 / 44 / 54 planes per polytope (nc = 175 / 247 / 319 / 379): the kernels with three to six row
-    slots per lane, both storage types (real voxel clusters reach 40 planes: tests/test_gpu_hull.py)."""
+    """P up to 20 / 32 / 44 / 54 / 76 planes per polytope (nc = 175 / 247 / 319 / 379 / 511): the kernels with three to
+    eight row slots per lane, both storage types (real voxel clusters reach 40 planes: tests/test_gpu_hull.py)."""
     batch = helpers.with_extra_planes(problems.make_batch("corridor", 5, 9, seed=41), p_max, seed=p_max)
     batch = batch.astype(dtype).astype(np.float64)     # identical (rounded) inputs for the oracle
     p0, p1 = abi.phase0_params(), abi.phase1_params()
@@ -271,10 +271,23 @@ def test_many_planes_per_polytope(built, p_max, dtype):
     if dtype == np.float64:
         assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
         assert (g1.rtn == r1.rtn).all() and (g1.iter_used == r1.iter_used).all()
-        assert np.abs(g1.cost / r1.cost - 1).max() < 1e-6 and helpers.rel(g1.T, r1.T) < 1e-6
+        # problems that run into the iteration limit (rtn 0; two of the five at P = 76) end wherever iteration 100 leaves
+        # them: the oracle against itself with inputs moved by one ulp is 3e-4 .. 2e-3 apart there.  Converged ones: 1e-6.
+        ok = r1.rtn == 1
+        assert ok.sum() >= 3
+        assert np.abs(g1.cost / r1.cost - 1)[ok].max() < 1e-6 and helpers.rel(g1.T[ok], r1.T[ok]) < 1e-6
+        assert np.abs(g1.cost / r1.cost - 1).max() < 2e-2
     else:
         assert (g0.rtn == r0.rtn).all() and (g1.rtn >= 0).all()
-        assert np.abs(g1.cost / r1.cost - 1).max() < 2e-2
+        # float storage: a trajectory whose phase 0 ends an iteration earlier or later than the oracle's (a 29-iteration
+        # phase 0 at P = 76) starts phase 1 elsewhere and may not converge within its 100 iterations - the emulated
+        # float path (tests/emu) gives the device's numbers bit for bit, the float-ulp control of the oracle shows the same
+        # sensitivity on the problems that hit the iteration limit.  Where both phases end like the oracle's: 2e-2.
+        same = (g0.iter_used == r0.iter_used) & (g1.rtn == r1.rtn) & (r1.rtn == 1)
+        assert same.sum() >= 2
+        assert np.abs(g1.cost / r1.cost - 1)[same].max() < 2e-2
+        if p_max <= 54:
+            assert np.abs(g1.cost / r1.cost - 1).max() < 2e-2
 
 
 def test_containment_audit_of_the_samples(built):
