@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q > gpurun_out/gpu_suite.log 2>&1; grep -E "passed|failed|Error" gpurun_out/gpu_suite.log | tail -3
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary 2>&1 | grep '^{' | cut -c1-120
+timeout 1500 python tests/soak/real_corridor_bench.py > gpurun_out/r03_real_corridors.json 2> gpurun_out/rc.err; tail -2 gpurun_out/rc.err; cut -c1-1500 gpurun_out/r03_real_corridors.json
