@@ -11,7 +11,7 @@ def sub(s, old, new, n=1):
 s = sub(s, "namespace {\n", "__device__ unsigned long long g_counts[4];\nnamespace {\n")
 s = sub(s, "  for (;;) {\n    if (tMaxX < tMaxY) {\n      if (tMaxX < tMaxZ) { id += ix; tMaxX += tDX; }", "  atomicAdd(&g_counts[1], 1ull);\n  for (;;) {\n    atomicAdd(&g_counts[2], 1ull);\n    if (tMaxX < tMaxY) {\n      if (tMaxX < tMaxZ) { id += ix; tMaxX += tDX; }")
 s = sub(s, "      need = ray_needs_walk(D, fl, cx, cy, cz, tgt, full);", "      need = ray_needs_walk(D, fl, cx, cy, cz, tgt, full);\n      atomicAdd(&g_counts[0], 1ull);")
-s = sub(s, "    if (base < i && j < i) need = ray_needs_walk(D, fl, cx, cy, cz, cd[j], full);", "    if (base < i && j < i) { need = ray_needs_walk(D, fl, cx, cy, cz, cd[j], full); atomicAdd(&g_counts[3], 1ull); }")
+s = sub(s, "    push(j < i ? ray_needs_walk(D, fl, cx, cy, cz, cd[j], full) : 0, j);", "    if (j < i) atomicAdd(&g_counts[3], 1ull);\n    push(j < i ? ray_needs_walk(D, fl, cx, cy, cz, cd[j], full) : 0, j);")
 s = sub(s, 'extern "C" {\n', 'extern "C" {\nvoid direct_cluster_debug_counts(unsigned long long* out, int reset) {\n  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_counts), 32);\n  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_counts), z, 32); }\n}\n')
 os.makedirs("/tmp/cc/direct_amd/csrc", exist_ok=True); os.makedirs("/tmp/cc/include", exist_ok=True)
 import shutil

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-timeout 3000 python tests/soak/n100_report.py > gpurun_out/n100.log 2>&1; tail -2 gpurun_out/n100.log | cut -c1-300; ls -la gpurun_out/r03_n100_parity.json
+timeout 600 python -m pytest tests/test_gpu_cluster.py tests/test_gpu_hull.py -x -q 2>&1 | tail -2
+timeout 900 python tests/soak/cluster_bench.py 2>/dev/null | tail -1 | cut -c1-330
+DIRECT_DDP_LIB=$PWD/build_variants/cluster_counts.so timeout 600 python tools/cluster_counts.py 2>&1 | tail -1
