@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
 timeout 600 python -m pytest tests/test_gpu_cluster.py tests/test_gpu_hull.py -x -q 2>&1 | tail -2
-timeout 900 python tests/soak/cluster_bench.py 2>/dev/null | tail -1 | cut -c1-330
-DIRECT_DDP_LIB=$PWD/build_variants/cluster_counts.so timeout 600 python tools/cluster_counts.py 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o pc -- python $GRAFT_REPO_ROOT/tests/soak/cluster_bench.py > $GRAFT_REPO_ROOT/gpurun_out/r03_cluster_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/cb.err
+tail -1 $GRAFT_REPO_ROOT/gpurun_out/r03_cluster_bench.json | cut -c1-330;  tail -1 $GRAFT_REPO_ROOT/gpurun_out/r03_cluster_bench.json | grep -o '"seeds_to_planes_chain.*'
+f=$(find /tmp/pc -name '*kernel_stats.csv' | head -1); cp $f $GRAFT_REPO_ROOT/gpurun_out/r03_cluster_kernel_stats.csv; head -5 $f | cut -c1-120
