@@ -161,6 +161,30 @@ def label_model_line(torch, dev, B, with_cpu):
     return out
 
 
+def corridor_clusters_line(dev):
+    """SURVEY.md 8(f-4), reported SEPARATELY: seed voxels -> voxel clusters -> polytope planes on the device
+    (include/direct_cluster.h; polyhedron_generator + poly_utils.cpp:127-206, 282-389), 64 seeds on a synthetic
+    200 x 200 x 40 map, clusters left on the device, planes back to the host.  Not part of `value`."""
+    from direct_amd import cluster, problems
+    dims = (200, 200, 40)
+    grid, seeds = problems.make_voxel_map(dims, seed=7, n_pillars=170, n_boxes=70, n_rings=12)
+    seeds = seeds[:64]
+    gen = cluster.ClusterGenerator(dims, max_batch=64, cluster_capacity=50000, candidate_capacity=10000, device=dev.index or 0)
+    gen.set_map(grid)
+    gen.polygon_generation(seeds[:2], fetch_clusters=False)
+    ts, hp, r = [], None, None
+    for _ in range(3):
+        t = time.perf_counter()
+        r = gen.polygon_generation(seeds, 1000, 50, fetch_clusters=False)
+        hp = gen.hull_planes(0.2, np.array([-20.0, -20.0, 0.0]), batch=len(seeds), plane_capacity=128, vertex_capacity=512)
+        ts.append(time.perf_counter() - t)
+    gen.close()
+    return {"workload": "64 seeds, 200x200x40 voxel map (1.6 % obstacles)", "ms_per_seed": min(ts) * 1e3 / len(seeds),
+            "wall_ms": min(ts) * 1e3, "cluster_voxels_mean": float(r["cluster_num"].mean()), "planes_mean": float(hp["n_planes"].mean()),
+            "planes_max": int(hp["n_planes"].max()), "seeds_ok": int(((r["rtn"] == 0) & (hp["rtn"] == 0)).sum()),
+            "note": "bit-identical to the reference's CPU path (clusters) / exact facet planes pinned against its quickhull: tests/test_gpu_cluster.py, tests/test_gpu_hull.py"}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -419,9 +443,13 @@ def main():
                    "iterations_max": int(fp.max()), "iterations_min": int(fp.min()),
                    "rtn_histogram": {str(int(v)): int(c) for v, c in zip(*np.unique(rt, return_counts=True))}}
         hbm_copy = hbm_copy_gbs(torch, dev)
-    label = None
+    label, clusters = None, None
     if not args.no_secondary and rank == 0:
         label = label_model_line(torch, dev, B, not args.no_cpu_baseline and world == 1)
+        try:
+            clusters = corridor_clusters_line(dev)
+        except Exception as ex:  # a secondary block never takes the line down
+            clusters = {"error": str(ex)[:200]}
 
     if rank == 0:
         # a trajectory that is still infeasible after the fixed iterations has moved y / ky as well: 10 nc instead of
@@ -489,6 +517,7 @@ def main():
             line["natural_exit"] = natural
         if label is not None:
             line["label_model"] = label
+            line["corridor_clusters"] = clusters
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
