@@ -103,6 +103,61 @@ def matching_profile(pattern, workload):
     return None
 
 
+def live_hbm_traffic(workload, timeout_s=240):
+    """HBM bytes of ONE timed launch from the PMC counters, measured NOW on this box: two separate rocprofv3 passes
+    (FETCH_SIZE and WRITE_SIZE cannot share one) over tools/prof_one.py, which runs this very workload (phase 0, then the
+    fixed-iteration phase-1 launch: the LAST k_iterate* dispatch of the process, checked against the HIP-event time the
+    script prints).  Units and the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes (counter x 1 KiB;
+    FETCH_SIZE reports half of the bytes read - the factors tools/hbm_calib measured for this access width are taken from
+    the newest profiles/r*_hbm_calib.json, 0.5 / 1.0 otherwise).  None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    cal = {"fetch_factor_dword": 0.5, "write_factor_dword": 1.0}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_calib.json")), reverse=True):
+        try:
+            cal.update({k: v for k, v in json.load(open(f)).items() if k in cal})
+            break
+        except (OSError, ValueError):
+            continue
+    out, ms = {}, {}
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, name)
+            cmd = [rp, "--pmc", name, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "q", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "prof_one.py"), workload["kind"], workload["dtype"], str(workload["batch"]),
+                   str(workload["nseg"]), str(workload["fixed_iters"])]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout_s)
+            ev = [float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("kernel ms")]
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not ev or not files:
+                return None
+            by = {}
+            for row in csv.DictReader(open(files[0])):
+                if "k_iterate" in row["Kernel_Name"] and row["Counter_Name"] == name:
+                    by[int(row["Dispatch_Id"])] = by.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
+            if not by:
+                return None
+            out[name] = by[max(by)]  # the last k_iterate* dispatch = the timed launch
+            ms[name] = ev[-1]
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_b = out["FETCH_SIZE"] * 1024.0 / cal["fetch_factor_dword"]
+    write_b = out["WRITE_SIZE"] * 1024.0 / cal["write_factor_dword"]
+    return {"traffic_bytes_per_launch": fetch_b + write_b, "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
+            "kernel_ms_under_pmc": [ms["FETCH_SIZE"], ms["WRITE_SIZE"]], "calibration": cal}
+
+
 def hbm_copy_gbs(torch, dev):
     """Measured HBM bandwidth of a device-to-device copy (read + write bytes / time): the second, measured
     denominator SURVEY.md 8(d) asks for next to the 8 TB/s datasheet figure."""
@@ -229,6 +284,9 @@ def main():
     ap.add_argument("--dtype", default="", choices=["", "f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the natural-exit run and the HBM copy microbench")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of the same workload in a "
+                         "subprocess, ~30 s); the newest committed profile of the workload is quoted instead")
     ap.add_argument("--dry", action="store_true",
                     help="no GPU: exercise launch, rendezvous (gloo), sharding and the gather on placeholder costs; "
                          "prints a line with value null (CPU test of the N > 1 plumbing, never a measurement)")
@@ -452,14 +510,38 @@ def main():
             clusters = {"error": str(ex)[:200]}
 
     if rank == 0:
-        # a trajectory that is still infeasible after the fixed iterations has moved y / ky as well: 10 nc instead of
-        # 5 nc words per knot
-        words = problems.algorithmic_words(batch1.n_planes, batch1.n_seg, infeasible=infeas_mask)
-        bytes_per_launch = words * np.dtype(np_dt).itemsize * FIXED_ITERS  # one launch = FIXED_ITERS iterations of B corridors
+        # SURVEY.md 8(d)'s algorithmic words, priced on the sweep work the launch really EXECUTED: every backward knot
+        # visit at the backward figure (119 + 2 nc + 4 P), and at most ONE forward trial-knot per backward knot visit
+        # ("one accepted line-search trial") at the forward figure (138 + 3 nc + 4 P) - but never more forward knots
+        # than were executed: in infeasible mode the fraction-to-boundary rule cuts most trials short after a few
+        # knots, and the unit-formula (one full forward trial per iteration) then over-counts by 2 x (config 4, r03).
+        # A trajectory that is still infeasible after the fixed iterations moves y / ky as well: the nc terms double.
+        wb, wf = problems.algorithmic_words(batch1.n_planes, batch1.n_seg, infeasible=infeas_mask, split=True)
+        knots = int(batch1.n_seg.sum())
+        isz = np.dtype(np_dt).itemsize
+        fwd_counted = min(launch["fwd_knot_visits"], launch["bwd_knot_visits"])
+        bytes_per_launch = (launch["bwd_knot_visits"] * (wb / knots) + fwd_counted * (wf / knots)) * isz
+        bytes_unit_formula = (wb + wf) * isz * FIXED_ITERS  # one launch = FIXED_ITERS iterations of B corridors, one full trial each
         avg_ms = float(np.mean(kernel_ms))
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_kind = None, None
+        if world == 1 and not args.no_live_traffic and not args.no_secondary:
+            traffic = live_hbm_traffic(workload)
+            if traffic is not None:  # the PMC passes must have run the launch that was timed above (10 %)
+                if max(abs(m / avg_ms - 1.0) for m in traffic["kernel_ms_under_pmc"]) > 0.10:
+                    traffic = None
+                else:
+                    traffic["_file"] = None
+                    traffic_kind = "live: FETCH_SIZE / WRITE_SIZE passes of this workload on this box, in this run (tools/prof_one.py under rocprofv3)"
+        if traffic is None:
+            traffic = matching_profile("r*_hbm_traffic.json", workload)
+            traffic_kind = None if traffic is None else "static: PMC counters of a committed profile of this workload, not measured in this run"
+        # never a numerator above what the counters saw cross the HBM interface (the kernels move less than SURVEY's
+        # figure where they can: the slack / dual gains never leave the wave)
+        numer, numer_kind = bytes_per_launch, "algorithmic bytes of the executed sweep work (SURVEY.md 8d words x executed knot visits)"
+        if traffic is not None and traffic["traffic_bytes_per_launch"] < numer:
+            numer, numer_kind = float(traffic["traffic_bytes_per_launch"]), "measured HBM traffic (below the algorithmic figure)"
+        achieved = numer / (avg_ms * 1e-3) / 1e9
         value = iters_all / dt
-        traffic = matching_profile("r*_hbm_traffic.json", workload)
         sq = matching_profile("r*_sq_counters.json", workload)
         line = {
             "metric": "ddp_iterations_per_sec", "value": value, "unit": "iter/s",
@@ -482,16 +564,18 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["traffic_bytes_per_launch"],
-                         "traffic_kind": None if traffic is None else "static: PMC counters of a committed profile of this "
-                                                                      "workload, not measured in this run",
+                         "traffic_kind": traffic_kind,
                          "traffic_source": None if traffic is None else traffic["_file"],
+                         "traffic_over_algorithmic": None if traffic is None else traffic["traffic_bytes_per_launch"] / bytes_per_launch,
                          "peak_measured_copy": hbm_copy, "frac_of_measured_copy": None if not hbm_copy else achieved / hbm_copy,
                          "kernel": "k_iterate_dyn (ticket-scheduled k_iterate)", "kernel_ms": avg_ms,
+                         "numerator": numer_kind,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         # the same words under the unit formula's assumption (one FULL forward trial per iteration)
+                         "algorithmic_bytes_unit_formula": bytes_unit_formula,
                          "infeasible_mode_frac": float(infeas_mask.mean()),
                          # sweep work the launch really executed (forward trials cut short by the fraction-to-boundary
-                         # rule count the knots they reached): the yardstick for the algorithmic figure above, which
-                         # assumes ONE full forward trial per iteration
+                         # rule count the knots they reached)
                          "bwd_knot_visits": launch["bwd_knot_visits"], "fwd_trial_knot_visits": launch["fwd_knot_visits"],
                          "algorithmic_knot_iterations": int(batch1.n_seg.sum()) * FIXED_ITERS,
                          "traffic_bytes_per_executed_knot_visit": None if traffic is None else

@@ -19,7 +19,7 @@ EXPORTS = ("direct_cluster_create", "direct_cluster_destroy", "direct_cluster_la
            "direct_cluster_polygon_generation_batch", "direct_cluster_convex_test", "direct_cluster_last_ms",
            "direct_cluster_set_stream", "direct_cluster_hull_planes_batch")
 CLUSTER_OK, CLUSTER_OVERFLOW, CLUSTER_BAD_SEED = 0, 1, 2
-HULL_OK, HULL_OVERFLOW, HULL_FLAT = 0, 1, 3
+HULL_OK, HULL_OVERFLOW, HULL_BAD_VOXEL, HULL_FLAT = 0, 1, 2, 3
 _BOUND = False
 
 

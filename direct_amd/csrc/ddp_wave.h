@@ -750,15 +750,8 @@ struct Wave {
   // Nothing here may WAIT on a load it has just issued (no arithmetic on the loaded words, no
   // load-dependent branch): every access is an unconditional load from a clamped, always valid index
   // and the words stay raw until commit().
-  // Feasible mode: the backward sweep hands c and s / c of the iterate to the forward trials through the idle y / ky
-  // arrays (phase R1 writes them, every trial reads them instead of re-deriving them from the old control values).
-  // That trades HBM traffic (two words per row and direction) for VALU work: right for float storage, where the kernel
-  // is issue-bound; with double storage the large configurations are HBM-bound and the trials
-  // recompute, as the reference's forward pass does (DDP:696).
-#ifndef DDP_ROWCACHE
-#define DDP_ROWCACHE 1
-#endif
-  static constexpr bool kRowCache = DDP_ROWCACHE && sizeof(St) < sizeof(double);
+  // Per row both sweeps read the slack s (and the dual y in infeasible mode) and nothing else: the slack / dual
+  // gains ks, ky, Ks, Ky of the reference (DDP:565-575, 610-614) never reach HBM on the hot path - see fwd R.
   // Float storage halves the prefetch registers: its instantiations can afford to gather the operands of all rows (and
   // the gains of phase D) in ONE batch of loads; with double storage the same batches spill inside the sweeps, and a
   // spill reload waits for every outstanding load, the HBM prefetch included
@@ -769,7 +762,7 @@ struct Wave {
   static constexpr int kRMask = (1 << kRB) - 1, kAMask = (1 << (16 - kRB)) - 1;
   static constexpr int kNPL = (4 * Lds::kPMax + 63) / 64 > 2 ? (4 * Lds::kPMax + 63) / 64 : 2;  // plane words per lane
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
-    St zh, zl, pl[kNPL], s[RPL], y[RPL], ks[RPL], ky[RPL], ku[2];
+    St zh, zl, pl[kNPL], s[RPL], y[RPL], ku[2];
   };
   DDP_DEV void prefetch(Pre& p, int* pkv, int pk_valid, int lane, int buf, int k, int P, bool fwd, int infeas) const {
     (void)buf;
@@ -781,8 +774,6 @@ struct Wave {
     for (int i = 0; i < kNPL; i++) p.pl[i] = pk[lane + 64 * i < pend ? lane + 64 * i : pend];
     GCSt* sk = SpU(sp.S[0], k);
     GCSt* yk = SpU(sp.Y[0], k);
-    GCSt* ksk = SpU(sp.KS, k);
-    GCSt* kyk = SpU(sp.KY, k);
     for (int i = 0; i < RPL; i++) {
       // the knot's row descriptors: computed once, carried to its row phases; they only depend on P,
       // so a run of knots with the same plane count (every free-space corridor) reuses them
@@ -790,11 +781,7 @@ struct Wave {
       const int r = (pkv[i] & kRMask) - 1;
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0; their results are masked
       p.s[i] = sk[rc];
-      if (infeas || (fwd && kRowCache)) p.y[i] = yk[rc];  // feasible forward pass: q = s / c of the old iterate (written by phase R1)
-      if (fwd) {
-        p.ks[i] = ksk[rc];
-        if (infeas || kRowCache) p.ky[i] = kyk[rc];  // feasible mode: c of the old iterate (written by phase R1)
-      }
+      if (infeas) p.y[i] = yk[rc];
     }
     if (fwd) {
       GCSt* ku = KUpU(k);
@@ -1189,43 +1176,6 @@ struct Wave {
     st.neg_time = neg;
   }
 
-  // The forward trials of a feasible-mode iteration read c and s / c of the nominal iterate from the y / ky arrays,
-  // where a COMPLETED backward sweep leaves them.  When the backward pass has given up (21 failures at the largest
-  // regulariser, DDP:297-310) the reference still runs its forward pass on whatever gains there are; the rows of the
-  // knots the last sweep never reached are then rebuilt here, from the iterate, as the reference's forward pass
-  // recomputes them (DDP:696).  Off the hot path: it runs only on the way to rtn = -4.
-  DDP_DEV void refresh_row_cache() {
-    if (!kRowCache) return;
-    const int buf = st.cur;
-    for (int k = 0; k < N; k++) {
-      const int P = np_(k);
-      LANES {
-        if (lane < 19) L.z[lane] = ldx(Xp(buf, k), lane);
-        for (int e = lane; e < 4 * P; e += 64) L.pl[e] = planes_(k)[e];
-      }
-      WSYNC();
-      const Real T = L.z[18];
-      LANES { if (lane < 8) L.tp[lane] = powi(T, lane); }
-      WSYNC();
-      LANES {
-        if (lane < 45) L.val[lane] = ctrl_val(L.z, L.tp, lane / 3, lane % 3);
-        else if (lane == 63) L.val[45] = T;
-      }
-      WSYNC();
-      LANES {
-        for (int i = 0; i < RPL; i++) {
-          const RowK<Real> rk = row_slot(i, lane, P);
-          if (rk.r >= 0) {
-            const Real c = row_c(L.val, rk), sv = (Real)Sp_(B.S[buf], k)[rk.r];
-            Sp_(B.KY, k)[rk.r] = (St)c;
-            Sp_(B.Y[buf], k)[rk.r] = (St)(sv * frcp(c));
-          }
-        }
-      }
-      WSYNC();
-    }
-  }
-
   // resetfilter (DDP:1636-1662) from the sums of the current iterate
   DDP_DEV void reset_filter() {
     double logcost = st.cost - st.mu * st.sumlog;
@@ -1399,7 +1349,13 @@ struct Wave {
   }
 
   // ---- backward sweep (DDP:440-644).  Returns 1 on success, 0 when the LLT failed. ---------------
-  DDP_DEV_NOINLINE int bwd_sweep() {
+  // kGains: also form the slack / dual gains ks, ky per row (DDP:568-571, 611) and store them (phases G and the row
+  // part of R2).  Only the stepwise entry point direct_ddp_backward_pass wants them (per-pass parity tests read
+  // DIRECT_FIELD_KS / KY): the forward pass eliminates them algebraically (see run_round, phase R), so the hot kernels
+  // neither compute nor store nor load them - like cx, cu, Ks and Ky they are never materialised.
+  DDP_DEV int bwd_sweep() { return bwd_sweep_t<false>(); }
+  template <bool kGains>
+  DDP_DEV_NOINLINE int bwd_sweep_t() {
     DDP_LAUNDER_S(b);
     DDP_LAUNDER_S(N);
     {  // regulariser schedule (DDP:452-474)
@@ -1595,17 +1551,13 @@ struct Wave {
             D = s * cinv;
             g = -mu * cinv;  // s - r/c
             LV(e_mu) = fmax(LV(e_mu), in ? fabs(rv) : (Real)0);
-            if (in) {  // for the forward trials of this iteration (the y / ky arrays are free in feasible mode)
-              if (kRowCache) {
-                SpU(sp.Y[0], k)[r] = (St)D;
-                SpU(sp.KY, k)[r] = (St)c;
-              }
-            }
           }
-          // for phase R2: infeasible mode needs c and rhat; feasible mode only the two quotients r / c and s / c, so
-          // that the slack gain ks = -(r + s cu ku) / c costs no second reciprocal there
-          LV(rc)[i] = infeas ? c : D;
-          LV(rr)[i] = infeas ? rv : rv * frcp_reuse;
+          if constexpr (kGains) {
+            // for phase R2: infeasible mode needs c and rhat; feasible mode only the two quotients r / c and s / c, so
+            // that the slack gain ks = -(r + s cu ku) / c costs no second reciprocal there
+            LV(rc)[i] = infeas ? c : D;
+            LV(rr)[i] = infeas ? rv : rv * frcp_reuse;
+          }
           if (in) {
             L.drow[r] = (Acc)D;
             L.grow[r] = (Acc)g;
@@ -1942,50 +1894,54 @@ struct Wave {
       }
       WSYNC();
       DDP_MARK("B_G");
-      // ---- G: cu*ku per control row; products for the V recursion
+      // ---- G: cu*ku per control row (kGains only)
       LANES {
         LV(tw_r2) = L.lt16[0][lane];
-        if (lane < 45) {
-          int cr = lane / 3, d = lane % 3;
-          Acc acc = L.dval[lane] * L.KU[9];
+        if constexpr (kGains) {
+          if (lane < 45) {
+            int cr = lane / 3, d = lane % 3;
+            Acc acc = L.dval[lane] * L.KU[9];
 #pragma unroll
-          for (int i = 3; i < 6; i++) acc += L.We[we_idx(cr, i)] * L.KU[(i - 3) * 3 + d];
-          L.G[lane] = (Real)acc;
-        } else if (lane == 45) {
-          L.G[45] = (Real)L.KU[9];  // the T_min row: A_r . ku = -ku_T
+            for (int i = 3; i < 6; i++) acc += L.We[we_idx(cr, i)] * L.KU[(i - 3) * 3 + d];
+            L.G[lane] = (Real)acc;
+          } else if (lane == 45) {
+            L.G[45] = (Real)L.KU[9];  // the T_min row: A_r . ku = -ku_T
+          }
         }
       }
-      WSYNC();
+      if constexpr (kGains) WSYNC();
       DDP_MARK("B_R2");
-      // ---- R2: slack / dual gains per row; V recursion; gains to HBM
+      // ---- R2: (kGains: slack / dual gains per row;) V recursion; gains ku, Ku to HBM
       LANES {
-        GSt* ksg = SpU(sp.KS, k);
-        GSt* kyg = SpU(sp.KY, k);
-        RowK<Real> rk2[RPL];
-        Row3 og2[RPL];
+        if constexpr (kGains) {
+          GSt* ksg = SpU(sp.KS, k);
+          GSt* kyg = SpU(sp.KY, k);
+          RowK<Real> rk2[RPL];
+          Row3 og2[RPL];
 #pragma unroll
-        for (int i = 0; i < RPL; i++) {
-          rk2[i] = row_unpack2(LV(pkc)[i]);
-          og2[i] = row_ops(L.G, LV(pkc)[i]);
-        }
-        DDP_LOADS_ISSUED();
+          for (int i = 0; i < RPL; i++) {
+            rk2[i] = row_unpack2(LV(pkc)[i]);
+            og2[i] = row_ops(L.G, LV(pkc)[i]);
+          }
+          DDP_LOADS_ISSUED();
 #pragma unroll
-        for (int i = 0; i < RPL; i++) {
-          const RowK<Real>& rk = rk2[i];
-          const int r = rk.r;
-          const Real cuku = row_dot(rk, og2[i]);
-          const Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
-          if (infeas) {  // DDP:568, 571
-            const Real y = LV(ry)[i];
-            const St ks = (St)((rv + s * cuku) * frcp(y));
-            const St ky = (St)(-(c + y) - cuku);
-            if (r >= 0) {
-              ksg[r] = ks;
-              kyg[r] = ky;
+          for (int i = 0; i < RPL; i++) {
+            const RowK<Real>& rk = rk2[i];
+            const int r = rk.r;
+            const Real cuku = row_dot(rk, og2[i]);
+            const Real s = LV(rs)[i], c = LV(rc)[i], rv = LV(rr)[i];
+            if (infeas) {  // DDP:568, 571
+              const Real y = LV(ry)[i];
+              const St ks = (St)((rv + s * cuku) * frcp(y));
+              const St ky = (St)(-(c + y) - cuku);
+              if (r >= 0) {
+                ksg[r] = ks;
+                kyg[r] = ky;
+              }
+            } else {  // DDP:611: -(r + s cu ku) / c with rv = r / c and c = s / c carried from phase R1
+              const St ks = (St)(-(rv + c * cuku));
+              if (r >= 0) ksg[r] = ks;
             }
-          } else {  // DDP:611: -(r + s cu ku) / c with rv = r / c and c = s / c carried from phase R1
-            const St ks = (St)(-(rv + c * cuku));
-            if (r >= 0) ksg[r] = ks;
           }
         }
         KUpU(k)[lane] = (St)L.KU[lane];
@@ -2248,9 +2204,9 @@ struct Wave {
   // Leaves res[t] (wave-uniform) and the trial iterates in buffers trial_buf(cur, step0 + t).  `poll` != 0 (helpers):
   // the round is abandoned when the owner cancels the search.
   template <int NT>
-  DDP_DEV void run_round(int step0, int cur, int infeas, Real omt, TrialRes* res, int poll, HelpSlot* hs) {
+  DDP_DEV void run_round(int step0, int cur, int infeas, Real omt, Real mu, TrialRes* res, int poll, HelpSlot* hs) {
     set_sweep_ptrs(cur, trial_buf(cur, step0), trial_buf(cur, step0 + NT - 1));
-    Real alpha[NT];
+    Real alpha[NT], oma[NT], amu[NT];  // step size, 1 - alpha (exact: alpha = 2^-step), alpha * mu
     TrialRes* tr = res;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -2265,6 +2221,8 @@ struct Wave {
       tr[t].stepsize = 1.0;
       for (int q = 0; q < tr[t].step; q++) tr[t].stepsize *= 0.5;  // DDP:670
       alpha[t] = DDP_UNIFORM_R((Real)tr[t].stepsize);
+      oma[t] = DDP_UNIFORM_R((Real)1 - alpha[t]);
+      amu[t] = DDP_UNIFORM_R(alpha[t] * mu);
     }
 #if !defined(DIRECT_EMULATE)
     int cancel_v = 0;  // the cancel flag as of one knot ago (the load is issued a knot ahead, like the prefetch)
@@ -2311,17 +2269,13 @@ struct Wave {
       for (int t = 0; t < NT; t++) n_visits += tr[t].alive;
       PLA(Real, rs, RPL);
       PLA(Real, ry, RPL);
-      PLA(Real, rks, RPL);
-      PLA(Real, rky, RPL);
       PLV(int, tw_ft);
       LANES {
         if (kWide) LV(tw_ft) = L.lt[7][lane];
         commit(LV(pre), lane, P, true);
         for (int i = 0; i < RPL; i++) {
           LV(rs)[i] = (Real)LV(pre).s[i];
-          LV(rks)[i] = (Real)LV(pre).ks[i];
-          LV(ry)[i] = (Real)LV(pre).y[i];    // infeasible: y, ky; feasible: s / c and c of the old iterate
-          LV(rky)[i] = (Real)LV(pre).ky[i];
+          LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
           LV(pkc)[i] = LV(pkn)[i];
         }
       }
@@ -2335,7 +2289,7 @@ struct Wave {
       }
       WSYNC();
     DDP_MARK("F_D");
-      // ---- D: dx, Ku dx, u+ (DDP:689 / 695); powers of the new T
+      // ---- D: dx, du = alpha ku + Ku dx, u+ = u + du (DDP:689 / 695); powers of the new T
       const Real To2 = DDP_UNIFORM_R(To * To), To4 = DDP_UNIFORM_R(To2 * To2);
       Real pwo[6];  // T^j, j = 0..5, of the old iterate as wave-uniform operands (same values as the tables)
 #pragma unroll
@@ -2391,10 +2345,13 @@ struct Wave {
                 constexpr int c = C;
                 ROW_FMA_V(acc, dxl, c, LV(kr)[c]);
               });
-              F.dz[9 + a] = acc;
+              // du = alpha ku + Ku dx: the whole step of the controls.  The rows of phase R multiply [dx; du], which
+              // is how the slack / dual gains are eliminated (see there)
+              const Real du = fma(alpha[t], LV(kfv), acc);
+              F.dz[9 + a] = du;
               // every new quantity is rounded to the storage type BEFORE it is used, so that the recorded
               // cost / log-barrier belong exactly to the iterate that is stored (DESIGN.md "Precision")
-              const Real un = pair_round(LV(zlv) + alpha[t] * LV(kfv) + acc);
+              const Real un = pair_round(LV(zlv) + du);
               F.zn[9 + a] = un;
               LV(unew) = un;
             }
@@ -2408,7 +2365,7 @@ struct Wave {
       }
       WSYNC();
     DDP_MARK("F_T");
-      // ---- T: control values at the new iterate, A*[dx; Ku dx], x+, jerk cost
+      // ---- T: control values at the old and at the new iterate, A * [dx; du], x+, jerk cost
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         if (tr[t].alive) {
@@ -2446,7 +2403,7 @@ struct Wave {
                 for (int jj = 0; jj < 3; jj++) {
                   const int j = 3 * half + jj;
                   const Real w = wb6[jj] * pwo[j];
-                  if (!kRowCache) vo += w * zo6[jj];  // the old control values (every alive trial writes the same ones)
+                  vo += w * zo6[jj];  // the old control values (every alive trial writes the same ones)
                   gf += w * dz6[jj];
                   dvo += wd6[jj] * pwo[j < 1 ? 0 : j - 1] * zo6[jj];
                   vn += wb6[jj] * pwn[t][j] * zn6[jj];
@@ -2454,14 +2411,14 @@ struct Wave {
               }
               const Real un = F.zn[9 + (lane < 54 ? 0 : l62 - 54)], dT = F.dz[18];
               if (lane < 45) F.G[lane] = gf + dvo * dT;
-              if (!kRowCache && lane < 45) L.val[lane] = vo;
+              if (lane < 45) L.val[lane] = vo;
               Real* dst = lane < 45 ? &F.valn[l62] : (lane < 54 ? &F.xnx[l62 - 45] : &F.qp[l62 - 54]);
               *dst = lane < 54 ? vn : vn * un;  // u_a[d] * (R u)_a[d]: the nine of them sum to u'Ru (DDP:1294-1305)
             }
             if (lane == 63) {
               F.valn[45] = F.zn[18];
               F.G[45] = F.dz[18];
-              if (!kRowCache) L.val[45] = L.z[18];
+              L.val[45] = L.z[18];
             }
           }
         }
@@ -2472,6 +2429,15 @@ struct Wave {
         if (tr[t].alive) tr[t].qsum += knot_cost(Tn[t], L.ft[t].qp);
     DDP_MARK("F_R");
       // ---- R: rows: s+, y+, c+, fraction-to-boundary tests
+      // The reference steps the slacks and duals with gains it has formed in the backward pass (DDP:565-575, 610-614,
+      // 680-703):  s+ = s + alpha ks + Ks dx,  y+ = y + alpha ky + Ky dx.  With u+ - u = du = alpha ku + Ku dx and
+      // A_r = [cx | cu]_r those are, identically,
+      //   feasible    (ks = -(r + s cu ku) / c, Ks = -(s / c)(cx + cu Ku), r = s c + mu):
+      //       s+ = (1 - alpha) s - alpha mu / c - (s / c) A_r [dx; du]
+      //   infeasible  (ks = (rhat + s cu ku) / y, Ks = (s / y)(cx + cu Ku), ky = -(c + y) - cu ku, Ky = -(cx + cu Ku)):
+      //       y+ = y - alpha (c + y) - A_r [dx; du],   s+ = s + (alpha rhat + s A_r [dx; du]) / y
+      // so a trial needs s, (y), the OLD c (re-evaluated from the old control values, as DDP:696 does) and one row
+      // product - no per-row gain ever crosses HBM, and the backward sweep has no row work after its phase R1.
       PLA(int, bad, NT);
       LANES {
 #pragma unroll
@@ -2482,39 +2448,55 @@ struct Wave {
 #pragma unroll
           for (int i = 0; i < RPL; i++) {
             rks_[i] = row_unpack2(LV(pkc)[i]);
-            if (!kRowCache && !infeas) oo[i] = row_ops(L.val, LV(pkc)[i]);
+            oo[i] = row_ops(L.val, LV(pkc)[i]);
+          }
+          DDP_LOADS_ISSUED();
+          // what belongs to the old iterate is shared by the trials of the round
+          Real co[RPL], w1[RPL], w2[RPL], bs[RPL], bc[RPL];
+#pragma unroll
+          for (int i = 0; i < RPL; i++) {
+            const Real s = LV(rs)[i];
+            co[i] = row_dot(rks_[i], oo[i]) + rks_[i].o - (Real)B.k.shift;
+            bs[i] = omt * s;
+            if (infeas) {
+              const Real y = LV(ry)[i];
+              w1[i] = frcp(y);
+              w2[i] = s * (co[i] + y) - (s * y - mu);  // rhat (DDP:536-537)
+              bc[i] = omt * y;
+            } else {
+              w1[i] = frcp(co[i]);
+              w2[i] = mu * w1[i];
+              bc[i] = omt * co[i];
+            }
           }
 #pragma unroll
           for (int t = 0; t < NT; t++) {
             if (tr[t].alive) {
-              constexpr int kG = RPL;  // rows gathered per batch of loads
               GSt* sn = SpU(sp.S[1 + t], k);
+              Row3 og[RPL], ov[RPL];  // one trial's operands at a time: both trials' would not fit the register file
 #pragma unroll
-              for (int i0 = 0; i0 < RPL; i0 += kG) {
-              Row3 og[kG], ov[kG];  // one trial's operands at a time: both trials' would not fit the register file
-#pragma unroll
-              for (int i = i0; i < i0 + kG; i++) {
-                og[i - i0] = row_ops(L.ft[t].G, LV(pkc)[i]);
-                ov[i - i0] = row_ops(L.ft[t].valn, LV(pkc)[i]);
+              for (int i = 0; i < RPL; i++) {
+                og[i] = row_ops(L.ft[t].G, LV(pkc)[i]);
+                ov[i] = row_ops(L.ft[t].valn, LV(pkc)[i]);
               }
               DDP_LOADS_ISSUED();
 #pragma unroll
-              for (int i = i0; i < i0 + kG; i++) {
+              for (int i = 0; i < RPL; i++) {
                 // branch-free rows: empty slots alias row 0, their stores / reductions are masked
                 const RowK<Real>& rk = rks_[i];
                 const int r = rk.r;
                 const bool in = r >= 0;
                 const Real s = LV(rs)[i];
-                const Real az = row_dot(rk, og[i - i0]);
-                const Real cn = row_dot(rk, ov[i - i0]) + rk.o - (Real)B.k.shift;
+                const Real az = row_dot(rk, og[i]);
+                const Real cn = row_dot(rk, ov[i]) + rk.o - (Real)B.k.shift;
                 Real snew;
                 if (infeas) {  // DDP:680-687
                   GSt* yn = SpU(sp.Y[1 + t], k);
                   const Real y = LV(ry)[i];
-                  const Real ynew = (Real)(St)(y + alpha[t] * LV(rky)[i] - az);
-                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] + (s * frcp(y)) * az);
+                  const Real ynew = (Real)(St)(fma(-alpha[t], co[i] + y, y) - az);
+                  snew = (Real)(St)fma(w1[i], fma(alpha[t], w2[i], s * az), s);
                   // bitwise, not short-circuit: the latter compiles to nested exec-masked branches per row
-                  LV(bad)[t] |= (int)(in & ((ynew < omt * y) | (snew < omt * s)));
+                  LV(bad)[t] |= (int)(in & ((ynew < bc[i]) | (snew < bs[i])));
                   LV(plog)[t].mul(in ? ynew : (Real)1);
                   LV(serr)[t] += in ? fabs(cn + ynew) : (Real)0;
                   if (in) {
@@ -2522,27 +2504,34 @@ struct Wave {
                     sn[r] = (St)snew;
                   }
                 } else {  // DDP:694-703
-                  // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
-                  // once (phase R1) instead of every trial re-deriving them from the old control values
-                  const Real co = kRowCache ? LV(rky)[i] : row_dot(rk, oo[i]) + rk.o - (Real)B.k.shift;
-                  const Real q = kRowCache ? LV(ry)[i] : s * frcp(co);
-                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - q * az);
-                  LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
+                  snew = (Real)(St)fma(s, fma(-w1[i], az, oma[t]), -(amu[t] * w1[i]));
+                  LV(bad)[t] |= (int)(in & ((cn > bc[i]) | (snew < bs[i])));
                   LV(plog)[t].mul(in ? -cn : (Real)1);
                   if (in) sn[r] = (St)snew;
                 }
                 LV(nviol)[t] += (int)(in & (cn >= (Real)2.0e-4));
               }
-              }
             }
           }
-        } else {  // double storage: row by row, both trials of a row together (the registers hold no more)
+        } else {  // double storage / many row slots: row by row, both trials of a row together (the registers hold no more)
           for (int i = 0; i < RPL; i++) {
             // branch-free rows: empty slots alias row 0, their stores / reductions are masked
             const RowK<Real> rk = row_unpack(LV(pkc)[i]);
             const int r = rk.r;
             const bool in = r >= 0;
-            const Real s = LV(rs)[i];
+            const Real s = LV(rs)[i], y = LV(ry)[i];
+            const Real co = row_c(L.val, rk);
+            const Real bs = omt * s;
+            Real w1, w2, bc;
+            if (infeas) {
+              w1 = frcp(y);
+              w2 = s * (co + y) - (s * y - mu);  // rhat (DDP:536-537)
+              bc = omt * y;
+            } else {
+              w1 = frcp(co);
+              w2 = mu * w1;
+              bc = omt * co;
+            }
 #pragma unroll
             for (int t = 0; t < NT; t++) {
               if (tr[t].alive) {
@@ -2553,11 +2542,10 @@ struct Wave {
                 Real snew;
                 if (infeas) {  // DDP:680-687
                   GSt* yn = SpU(sp.Y[1 + t], k);
-                  const Real y = LV(ry)[i];
-                  const Real ynew = (Real)(St)(y + alpha[t] * LV(rky)[i] - az);
-                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] + (s * frcp(y)) * az);
+                  const Real ynew = (Real)(St)(fma(-alpha[t], co + y, y) - az);
+                  snew = (Real)(St)fma(w1, fma(alpha[t], w2, s * az), s);
                   // bitwise, not short-circuit: the latter compiles to nested exec-masked branches per row
-                  LV(bad)[t] |= (int)(in & ((ynew < omt * y) | (snew < omt * s)));
+                  LV(bad)[t] |= (int)(in & ((ynew < bc) | (snew < bs)));
                   LV(plog)[t].mul(in ? ynew : (Real)1);
                   LV(serr)[t] += in ? fabs(cn + ynew) : (Real)0;
                   if (in) {
@@ -2565,12 +2553,8 @@ struct Wave {
                     sn[r] = (St)snew;
                   }
                 } else {  // DDP:694-703
-                  // c and s / c of the OLD iterate do not depend on the step size: the backward sweep wrote them
-                  // once (phase R1) instead of every trial re-deriving them from the old control values
-                  const Real co = kRowCache ? LV(rky)[i] : row_c(L.val, rk);
-                  const Real q = kRowCache ? LV(ry)[i] : s * frcp(co);
-                  snew = (Real)(St)(s + alpha[t] * LV(rks)[i] - q * az);
-                  LV(bad)[t] |= (int)(in & ((cn > omt * co) | (snew < omt * s)));
+                  snew = (Real)(St)fma(s, fma(-w1, az, oma[t]), -(amu[t] * w1));
+                  LV(bad)[t] |= (int)(in & ((cn > bc) | (snew < bs)));
                   LV(plog)[t].mul(in ? -cn : (Real)1);
                   if (in) sn[r] = (St)snew;
                 }
@@ -2670,6 +2654,7 @@ struct Wave {
     }
     const double tau_d = fmax(0.99, 1.0 - mu_d);
     const Real omt = DDP_UNIFORM_R((Real)(1.0 - tau_d));
+    const Real mu_r = DDP_UNIFORM_R((Real)mu_d);
     const int nfilter = helper ? 0 : DDP_UNIFORM_I(st.nfilter);
     double* filt = B.filt + (size_t)b * B.fcap * 2;
     // rounds: {0}, then the pairs (2r-1, 2r), r = 1..5, or the single steps r = 1..10 (few trajectories on many waves:
@@ -2702,8 +2687,8 @@ struct Wave {
       res[1].alive = 0;
       const int nt = (pair && mine > 0) ? 2 : 1, step0 = (pair && mine > 0) ? 2 * mine - 1 : mine;
       if (mine >= 0) {
-        if (nt == 2) run_round<2>(step0, cur, infeas, omt, res, helper, hs);
-        else run_round<1>(step0, cur, infeas, omt, res, helper, hs);
+        if (nt == 2) run_round<2>(step0, cur, infeas, omt, mu_r, res, helper, hs);
+        else run_round<1>(step0, cur, infeas, omt, mu_r, res, helper, hs);
       }
       if (helper) {
         post_results(hs, mine, step0, nt, res, tag);
@@ -2767,7 +2752,6 @@ struct Wave {
         else st.bp_no_upd = 0;
         if (st.bp_no_upd > 20) break;
       }
-      if (st.bp_failed && !st.infeas) refresh_row_cache();
     }
     fwd_pass(helper);
     if (helper) return;

@@ -767,7 +767,9 @@ __global__ __launch_bounds__(64) void k_resolve_fast(Dev D) {
   }
   if (lane == 0) {
     E->pad0 = n_clu;  // where this round's voxels go (k_apply)
-    if (n_clu + count > D.ccap) { E->rtn = DIRECT_CLUSTER_OVERFLOW; E->live = 0; E->n_cluster = D.ccap; E->n_active = 0; }
+    // overflow: k_apply skips a dead element, so only the n_clu voxels of the earlier rounds are in the cluster array -
+    // that valid prefix is what stays (slots beyond it were never written)
+    if (n_clu + count > D.ccap) { E->rtn = DIRECT_CLUSTER_OVERFLOW; E->live = 0; E->n_cluster = n_clu; E->n_active = 0; }
     else {
       E->n_cluster = n_clu + count;
       E->n_active = count;
@@ -850,6 +852,7 @@ struct direct_cluster_handle_s {
   std::vector<void*> allocs;
   HullDev H = {};          // scratch of hull_planes_batch, allocated by its first call
   bool have_hull = false;
+  int resident_batch = 0;    // seeds of the last polygon_generation_batch whose clusters are still in D.cluster / D.el (0: none)
   void* hull_out = nullptr;  // device staging of its host outputs
   size_t hull_out_bytes = 0;
 };
@@ -960,6 +963,7 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
   if (!h->have_map) return cfail(DIRECT_ERR_INVALID, "direct_cluster_set_map has not been called");
   CHIP_TRY(hipSetDevice(h->cfg.device));
   Dev& D = h->D;
+  h->resident_batch = 0;
   CHIP_TRY(hipMemcpyAsync(h->seeds, seeds, (size_t)batch * 3 * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CHIP_TRY(hipEventRecord(h->ev0, h->stream));
   const int gblocks = std::min((D.G + 255) / 256, 4096);
@@ -1031,6 +1035,7 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
   cleanup();
   if (e != hipSuccess || e2 != hipSuccess)
     return cfail(DIRECT_ERR_DEVICE, std::string("polygon_generation_batch: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  h->resident_batch = batch;
   return DIRECT_OK;
 }
 
@@ -1092,6 +1097,10 @@ direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int3
   if (batch <= 0 || batch > h->cfg.max_batch) return cfail(DIRECT_ERR_INVALID, "batch exceeds the handle's max_batch");
   if (cluster_xyz && !cluster_num) return cfail(DIRECT_ERR_INVALID, "cluster_xyz without cluster_num");
   if (plane_capacity <= 0 || vertex_capacity <= 0 || !(resolution > 0)) return cfail(DIRECT_ERR_INVALID, "bad capacity / resolution");
+  if (!cluster_xyz && batch > h->resident_batch)
+    return cfail(DIRECT_ERR_INVALID, "no resident clusters for this batch: call direct_cluster_polygon_generation_batch with at least "
+                                     "`batch` seeds first (caller-provided voxels replace the resident clusters)");
+  if (cluster_xyz) h->resident_batch = 0;  // the voxels are packed into the handle's cluster storage: the generation's clusters are gone
   CHIP_TRY(hipSetDevice(h->cfg.device));
   Dev& D = h->D;
   HullDev& H = h->H;
@@ -1100,22 +1109,31 @@ direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int3
     H.QX = 2 * D.max_x + 1; H.QY = 2 * D.max_y + 1; H.QZ = 2 * D.max_z + 1;
     H.half_words = (size_t)H.QY * H.QZ + (size_t)H.QX * H.QZ + (size_t)H.QX * H.QY;
     H.line_words = 2 * H.half_words;
-    auto A = [&](auto pp, size_t bytes) -> hipError_t {
+    // all or nothing: a failed allocation frees what this call has allocated, so that a retry starts clean
+    std::vector<void*> mine;
+    hipError_t ae = hipSuccess;
+    auto A = [&](auto pp, size_t bytes) {
+      if (ae != hipSuccess) return;
       void* q = nullptr;
-      hipError_t e = hipMalloc(&q, bytes);
-      if (e != hipSuccess) return e;
-      h->allocs.push_back(q);
+      ae = hipMalloc(&q, bytes);
+      if (ae != hipSuccess) return;
+      mine.push_back(q);
       *pp = (typename std::remove_pointer<decltype(pp)>::type)q;
-      return hipSuccess;
     };
-    CHIP_TRY(A(&H.he, B * sizeof(HullElem)));
-    CHIP_TRY(A(&H.lines, B * H.line_words * sizeof(int)));
-    CHIP_TRY(A(&H.cand, B * 3 * hull::kCandCap * sizeof(int)));
-    CHIP_TRY(A(&H.first, B * hull::kCandCap * sizeof(int)));
-    CHIP_TRY(A(&H.isv, B * hull::kCandCap * sizeof(int)));
-    CHIP_TRY(A(&H.raw, B * hull::kRawCap * 4 * sizeof(hull::i64)));
-    CHIP_TRY(A(&H.sorted, B * hull::kRawCap * 4 * sizeof(hull::i64)));
-    CHIP_TRY(A(&H.vq, B * hull::kCandCap * 3 * sizeof(int)));
+    A(&H.he, B * sizeof(HullElem));
+    A(&H.lines, B * H.line_words * sizeof(int));
+    A(&H.cand, B * 3 * hull::kCandCap * sizeof(int));
+    A(&H.first, B * hull::kCandCap * sizeof(int));
+    A(&H.isv, B * hull::kCandCap * sizeof(int));
+    A(&H.raw, B * hull::kRawCap * 4 * sizeof(hull::i64));
+    A(&H.sorted, B * hull::kRawCap * 4 * sizeof(hull::i64));
+    A(&H.vq, B * hull::kCandCap * 3 * sizeof(int));
+    if (ae != hipSuccess) {
+      for (void* q : mine) (void)hipFree(q);
+      H = HullDev{};
+      return cfail(DIRECT_ERR_DEVICE, std::string("hull_planes_batch: scratch allocation: ") + hipGetErrorString(ae));
+    }
+    h->allocs.insert(h->allocs.end(), mine.begin(), mine.end());
     h->have_hull = true;
   }
   // device views of the outputs: the caller's pointers, or one staging block for host outputs
@@ -1156,6 +1174,7 @@ direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int3
   CHIP_TRY(hipEventRecord(h->ev0, h->stream));
   CHIP_TRY(hipMemset2DAsync(H.lines, H.line_words * sizeof(int), 0x7f, H.half_words * sizeof(int), nb, h->stream));
   CHIP_TRY(hipMemset2DAsync(H.lines + H.half_words, H.line_words * sizeof(int), 0x80, H.half_words * sizeof(int), nb, h->stream));
+  CHIP_TRY(hipMemsetAsync(H.he, 0, nb * sizeof(HullElem), h->stream));
   hipLaunchKernelGGL(k_hull_src, dim3(32, batch), dim3(256), 0, h->stream, D, H, batch, sx, sn);
   hipLaunchKernelGGL(k_hull_lines, dim3(batch), dim3(256), 0, h->stream, D, H);
   hipLaunchKernelGGL(k_hull_cand, dim3(batch), dim3(256), 0, h->stream, D, H);

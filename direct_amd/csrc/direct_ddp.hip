@@ -196,13 +196,8 @@ __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
   if (mode == 1) {
-    W.bwd_sweep();
+    W.template bwd_sweep_t<true>();  // with the slack / dual gains ks, ky (DIRECT_FIELD_KS / KY): the hot kernels never form them
   } else {
-    // The trials read c and s / c of the nominal iterate from the row cache, which only a COMPLETED backward sweep
-    // fills (ddp_wave.h, refresh_row_cache): after a backward pass that gave up part-way the rows of the knots it
-    // never reached are rebuilt from the iterate, as iterate_once() does and as the reference's forwardpass
-    // recomputes them (ddp_optimizer.cpp:696).  direct_ddp_set_field refreshes the cache itself.
-    if (__builtin_amdgcn_readfirstlane(lds.st.bp_failed) && !__builtin_amdgcn_readfirstlane(lds.st.infeas)) W.refresh_row_cache();
     W.fwd_pass();
   }
   W.store_state();
@@ -227,12 +222,6 @@ __global__ __launch_bounds__(64) void k_field(Batch<St> B, int field, St* buf, i
   W.init_tables();
   if (set) {
     set_field_wave(W, field, (const St*)buf);
-    // an overwritten iterate invalidates the row cache of the feasible-mode forward trials (c, s / c of the iterate)
-    if (field <= 2 && !__builtin_amdgcn_readfirstlane(lds.st.infeas)) {
-      __threadfence();  // the refresh reads the new iterate on other lanes than the ones that stored it
-      __syncthreads();
-      W.refresh_row_cache();
-    }
   } else {
     get_field_wave(W, field, buf);
   }

@@ -41,29 +41,37 @@ __device__ __forceinline__ hull::Lines hull_lines_of(const HullDev& H, int e) {
 
 __global__ void k_hull_src(Dev D, HullDev H, int batch, const int32_t* xyz /* or null */, const int32_t* num) {
   const int e = blockIdx.y;
-  int n;
+  int n, bad = 0;
   if (xyz) {
     n = num[e];
     n = n < 0 ? 0 : (n > D.ccap ? D.ccap : n);
+    // caller-provided voxels are validated like direct_cluster_convex_test validates its own: an index outside the map
+    // would address lattice lines outside the per-cluster line arrays (and one above 1023 would alias another axis in
+    // pack3).  One bad voxel disqualifies the cluster: rtn = DIRECT_HULL_BAD_VOXEL, nothing is computed for it.
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
       const int32_t* p = xyz + ((size_t)e * D.ccap + t) * 3;
-      D.cluster[(size_t)e * D.ccap + t] = pack3(p[0], p[1], p[2]);
+      const int x = p[0], y = p[1], z = p[2];
+      const bool ok = x >= 0 && x < D.max_x && y >= 0 && y < D.max_y && z >= 0 && z < D.max_z;
+      bad |= ok ? 0 : 1;
+      D.cluster[(size_t)e * D.ccap + t] = ok ? pack3(x, y, z) : 0;
     }
+    if (bad) atomicOr(&H.he[e].pad0, 1);  // pad0 / overflow were zeroed by the host before this launch
   } else {
-    n = D.el[e].rtn == DIRECT_CLUSTER_BAD_SEED ? 0 : D.el[e].n_cluster;
+    // resident clusters: only a generation that ended well left a usable cluster (an overflowed one is a truncated
+    // prefix, DIRECT_CLUSTER_OVERFLOW: "not usable"); the count is clamped to the storage whatever the element says
+    const int rt = D.el[e].rtn;
+    n = rt == DIRECT_CLUSTER_OK ? D.el[e].n_cluster : 0;
+    n = n < 0 ? 0 : (n > D.ccap ? D.ccap : n);
+    if (rt == DIRECT_CLUSTER_OVERFLOW && blockIdx.x == 0 && threadIdx.x == 0) H.he[e].overflow = 1;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    HullElem he = {};
-    he.n = n;
-    H.he[e] = he;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) H.he[e].n = n;
   (void)batch;
 }
 
 __global__ __launch_bounds__(256) void k_hull_lines(Dev D, HullDev H) {
   const int e = blockIdx.x, tid = threadIdx.x;
   const int n = H.he[e].n;
-  if (n <= 0) return;
+  if (n <= 0 || H.he[e].pad0) return;  // pad0: a caller-provided voxel outside the map (k_hull_src)
   const int* cl = D.cluster + (size_t)e * D.ccap;
   // checkDegeneratePoly (poly_utils.cpp:236-273): all voxels share x, or y, or z
   const int p0 = cl[0];
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void k_hull_cand(Dev D, HullDev H) {
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   HullElem* E = &H.he[e];
   const int n = E->n;
-  if (n <= 0) return;
+  if (n <= 0 || E->pad0) return;
   const int deg = E->degenerate;
   const int* cl = D.cluster + (size_t)e * D.ccap;
   const hull::Lines L = hull_lines_of(H, e);
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(256) void k_hull_finish(HullDev H, double res, doub
   int code = DIRECT_HULL_OK;
   if (E.n <= 0 || E.flat || E.n_raw == 0) code = DIRECT_HULL_FLAT;
   if (E.overflow) code = DIRECT_HULL_OVERFLOW;
+  if (E.pad0) code = DIRECT_HULL_BAD_VOXEL;
   if (degenerate && tid == 0) degenerate[e] = E.degenerate;
   if (code != DIRECT_HULL_OK) {
     if (tid == 0) {
@@ -297,7 +306,8 @@ __global__ __launch_bounds__(256) void k_hull_finish(HullDev H, double res, doub
     if (n_planes) n_planes[e] = np;
     if (n_vertices) n_vertices[e] = nv;
     // a capacity only counts for an output the caller asked for
-    const bool over = ((planes || plane_int) && np > plane_cap) || (vertices && nv > vert_cap);
+    const bool over = ((planes || plane_int) && np > plane_cap) || (vertices && nv > vert_cap) ||
+                      (center && np > hull::kRawCap / 4);  // the centre needs one scratch index per plane (2048)
     if (rtn) rtn[e] = over ? DIRECT_HULL_OVERFLOW : DIRECT_HULL_OK;
   }
 }

@@ -8,6 +8,9 @@
 // and polyHrep2Utils do per seed (:127-206, 282-389: voxel clustering, quickhull, cdd) by ONE device call for all the
 // seeds that are due:
 //   * corridorGeneration(gridPath, corridor)       the reference's single-path walk (one seed per device call)
+//   * corridorInsertGeneration(coordSet, corridor) the walk the LIVE caller uses (teach_repeat_planner.cpp:172, 228;
+//     poly_utils.cpp:391-449): continues the corridor it is given (isOutsideLatestPolytope against the last existing
+//     polytope), never pops, works on a copy and returns 0 / 1 - on 0 (no map, cdd error) the corridor is untouched
 //   * corridorGenerationBatch(gridPaths, corridors) many paths in lock step: every round collects the seed each
 //     unfinished walk is waiting for and runs them as one batch - the form the device wants.  A walk's result does not
 //     depend on the other walks (getConvexPoly is a function of the seed voxel and the map), so both give the same
@@ -65,6 +68,46 @@ class polyhedronGenerator {
     return false;
   }
 
+  template <class Corridor>
+  static bool isOutsideLatestPolytope(const std::array<double, 3>& c, const Corridor& cor) {  // :59-62
+    return isOutsidePolytope(c, cor.polyhedrons.back());
+  }
+  template <class Corridor>
+  static bool isInsideLastSecondPolytope(const std::array<double, 3>& c, const Corridor& cor) {  // :64-70
+    const size_t n = cor.polyhedrons.size();
+    return n > 1 ? !isOutsidePolytope(c, cor.polyhedrons[n - 2]) : false;
+  }
+
+  // corridorInsertGeneration (:391-449), the walk of the live caller (teach_repeat_planner.cpp:172, 228): new polytopes
+  // are appended behind the ones `corridor` already holds; a point inside the latest polytope adds nothing; there is no
+  // pop.  Returns 1 and replaces `corridor` when the whole path went through, 0 (corridor untouched) without a map or
+  // where the reference's cdd call fails (:437-439).  The reference's second argument, the visualisation message, has
+  // no counterpart here (RViz is out of scope).
+  template <class Corridor>
+  int corridorInsertGeneration(const std::vector<std::array<double, 3>>& coordSet, Corridor& corridor) {
+    if (!has_map_) return 0;  // :394
+    std::vector<Corridor*> cs{&corridor};
+    return corridorInsertGenerationBatch(std::vector<std::vector<std::array<double, 3>>>{coordSet}, cs)[0];
+  }
+  // the same for many (path, corridor) pairs in lock step (one device batch per round of due seeds)
+  template <class Corridor>
+  std::vector<int> corridorInsertGenerationBatch(const std::vector<std::vector<std::array<double, 3>>>& coordSets,
+                                                 const std::vector<Corridor*>& corridors) {
+    std::vector<int> rc(coordSets.size(), 0);
+    if (!has_map_) return rc;
+    std::vector<Corridor> beg;  // beg_corridor (:399-403): the copy the walk extends
+    for (Corridor* c : corridors) beg.push_back(*c);
+    std::vector<Corridor*> ptr;
+    for (Corridor& c : beg) ptr.push_back(&c);
+    const std::vector<bool> ok = walk(coordSets, ptr, false);
+    for (size_t p = 0; p < coordSets.size(); p++)
+      if (ok[p]) {
+        *corridors[p] = beg[p];  // :447
+        rc[p] = 1;
+      }
+    return rc;
+  }
+
   // corridorGeneration (:508-557) for one path.  Returns false where the reference prints "corridor generation broke".
   template <class Corridor>
   bool corridorGeneration(const std::vector<std::array<double, 3>>& gridPath, Corridor& corridor) {
@@ -77,6 +120,15 @@ class polyhedronGenerator {
   std::vector<bool> corridorGenerationBatch(const std::vector<std::vector<std::array<double, 3>>>& gridPaths,
                                             const std::vector<Corridor*>& corridors) {
     if (!has_map_) throw std::runtime_error("polyhedronGenerator: no map");
+    return walk(gridPaths, corridors, true);
+  }
+
+ private:
+  // The walk all entry points share.  pop_back: corridorGeneration's return into the last but one polytope (:524-528);
+  // corridorInsertGeneration has none.
+  template <class Corridor>
+  std::vector<bool> walk(const std::vector<std::vector<std::array<double, 3>>>& gridPaths, const std::vector<Corridor*>& corridors,
+                         bool pop_back) {
     const size_t np = gridPaths.size();
     struct Walk { size_t next = 0; std::array<double, 3> lst{{-INFINITY, -INFINITY, -INFINITY}}; bool done = false, ok = true; };
     std::vector<Walk> w(np);
@@ -94,9 +146,8 @@ class polyhedronGenerator {
           const std::array<int, 3> idx = coord2Index(gridPaths[p][s.next]);
           const std::array<double, 3> cur = index2Coord(idx);
           if (cur == s.lst) { s.next++; continue; }
-          const size_t n = cor.polyhedrons.size();
-          if (n > 1 && !isOutsidePolytope(cur, cor.polyhedrons[n - 2])) cor.polyhedrons.pop_back();  // :526-530
-          if (cor.polyhedrons.empty() || isOutsidePolytope(cur, cor.polyhedrons.back())) {
+          if (pop_back && isInsideLastSecondPolytope(cur, cor)) cor.polyhedrons.pop_back();  // :524-528
+          if (cor.polyhedrons.empty() || isOutsideLatestPolytope(cur, cor)) {  // :413, :530
             due.push_back(p);
             seeds.insert(seeds.end(), idx.begin(), idx.end());
             due_coord.push_back(cur);
@@ -139,6 +190,8 @@ class polyhedronGenerator {
     for (size_t p = 0; p < np; p++) ok[p] = w[p].ok;
     return ok;
   }
+
+ public:
 
   // getConvexPoly + hrep + polyHrep2Utils for `batch` seed voxels: clusters and planes never leave the device in between
   void getConvexPolyBatch(int batch, const int32_t* seed_idx, std::vector<PlainPolytope>& out, std::vector<int32_t>& rtn) {

@@ -153,16 +153,22 @@ def make_config1(seed=1, n_seg=50, dtype=np.float64):
                          seeds=seeds, dtype=dtype)
 
 
-def algorithmic_words(n_planes, n_seg, infeasible=False):
+def algorithmic_words(n_planes, n_seg, infeasible=False, split=False):
     """Algorithmic words moved per DDP iteration of a batch:
     per knot 257 + 5 nc + 8 P (feasible) or 257 + 10 nc + 8 P (infeasible), nc = 6 P + 55.
-    `infeasible`: one flag for the batch or one per trajectory (the mode its iterations run in)."""
+    `infeasible`: one flag for the batch or one per trajectory (the mode its iterations run in).
+    `split`: return (backward words, forward words) instead of their sum - SURVEY's own split of the figure:
+    backward R(nx + nu + nc + 4 P) W(nu + nu nx + nc) = 119 + 2 nc + 4 P, forward (ONE trial)
+    R(nx + nu + nc + 4 P + nu + nu nx + nc) W(nx + nu + nc) = 138 + 3 nc + 4 P; the nc terms double in infeasible mode."""
     n_planes = np.asarray(n_planes)
     k = np.arange(n_planes.shape[1])[None, :] < np.asarray(n_seg)[:, None]
     nc = 6 * n_planes + 55
-    per_row = np.where(np.broadcast_to(np.asarray(infeasible, bool).reshape(-1, 1), n_planes.shape), 10, 5)
-    w = 257 + per_row * nc + 8 * n_planes
-    return int(np.where(k, w, 0).sum())
+    dbl = np.where(np.broadcast_to(np.asarray(infeasible, bool).reshape(-1, 1), n_planes.shape), 2, 1)
+    wb = 119 + 2 * dbl * nc + 4 * n_planes
+    wf = 138 + 3 * dbl * nc + 4 * n_planes
+    if split:
+        return int(np.where(k, wb, 0).sum()), int(np.where(k, wf, 0).sum())
+    return int(np.where(k, wb + wf, 0).sum())
 
 
 def make_voxel_map(dims=(120, 120, 24), seed=7, n_pillars=60, n_boxes=25, n_rings=6):

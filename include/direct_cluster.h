@@ -94,13 +94,16 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
  * are not corners; cdd's H-rep does not depend on them).
  *
  * cluster_xyz == NULL: the clusters of the last polygon_generation_batch, still resident on the device (no copy of
- * the voxels in either direction).  Otherwise cluster_xyz[batch][cluster_capacity][3] / cluster_num[batch] in memory
- * kind mem_in replace them.  Outputs in memory kind `mem`, any may be NULL:
+ * the voxels in either direction; `batch` may not exceed that call's, and a seed whose generation did not end with
+ * DIRECT_CLUSTER_OK has no usable cluster: DIRECT_HULL_OVERFLOW / DIRECT_HULL_FLAT).  Otherwise
+ * cluster_xyz[batch][cluster_capacity][3] / cluster_num[batch] in memory kind mem_in REPLACE them in the handle's storage
+ * (a later call with cluster_xyz == NULL needs a new generation first); every voxel must lie inside the map.  Outputs in memory kind `mem`, any may be NULL:
  *   planes[batch][plane_capacity][4] (double), plane_int[batch][plane_capacity][4] (int64: primitive normal and
  *   offset on the lattice, n . q + K <= 0), n_planes[batch], vertices[batch][vertex_capacity][3], n_vertices[batch],
  *   center[batch][3], degenerate[batch] (checkDegeneratePoly), rtn[batch] (codes below). */
 #define DIRECT_HULL_OK 0
-#define DIRECT_HULL_OVERFLOW 1 /* more planes / vertices than the capacity of an output that was asked for, more than 2048 line-extreme points or 8192 plane reports of hull edges */
+#define DIRECT_HULL_OVERFLOW 1 /* more planes / vertices than the capacity of an output that was asked for, more than 2048 line-extreme points or 8192 plane reports of hull edges, more than 2048 planes with `center` asked for, or a resident cluster whose generation overflowed */
+#define DIRECT_HULL_BAD_VOXEL 2 /* a caller-provided voxel lies outside the map [0, max_x) x [0, max_y) x [0, max_z): nothing is computed for the cluster */
 #define DIRECT_HULL_FLAT 3     /* empty cluster, or the points do not span three dimensions (the reference's cdd call fails) */
 direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int32_t batch, int32_t mem_in,
                                                  const int32_t* cluster_xyz, const int32_t* cluster_num, double resolution,
@@ -109,10 +112,10 @@ direct_status_t direct_cluster_hull_planes_batch(direct_cluster_handle_t h, int3
                                                  double* vertices, int32_t* n_vertices, double* center, int32_t* degenerate,
                                                  int32_t* rtn);
 
-/* HIP-event time [ms] of the kernels of the last polygon_generation_batch / convex_test / hull_planes_batch call */
 /* The HIP stream (hipStream_t) the handle enqueues its copies, kernels and timing events on; NULL (the default) is
  * the legacy default stream.  Mirrors direct_ddp_set_stream. */
 direct_status_t direct_cluster_set_stream(direct_cluster_handle_t h, void* hip_stream);
+/* HIP-event time [ms] of the kernels of the last polygon_generation_batch / convex_test / hull_planes_batch call */
 direct_status_t direct_cluster_last_ms(direct_cluster_handle_t h, float* ms);
 
 #ifdef __cplusplus

@@ -3,7 +3,9 @@
 // paths in lock step, and writes the corridors for tests/test_gpu_hull.py to compare with the CPU restatement.
 //   usage: test_corridor_gen <in.bin> <out.bin> [seeds per device call, default 16]
 //   in : int32 X Y Z, double res, double lower[3], int32 n_paths, {int32 len, double pts[len][3]}*, uint8 map[X*Y*Z]
-//   out: per mode (0 = one by one, 1 = batch): per path: int32 ok, int32 n_poly, {int32 n_planes, double planes[n][4], center[3], seed[3]}*
+//   out: per mode (0 = corridorGeneration one by one, 1 = all paths in lock step, 2 = corridorInsertGeneration: the first half of
+//        every path into an empty corridor, then the second half into that corridor - the live caller's pattern,
+//        teach_repeat_planner.cpp:172 / 228 -, 3 = the same two calls for all paths in lock step): per path: int32 ok, int32 n_poly, {int32 n_planes, double planes[n][4], center[3], seed[3]}*
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -38,17 +40,33 @@ int main(int argc, char** argv) {
   direct::polyhedronGenerator gen(res, lower, dims[0], dims[1], dims[2], 1000, 50, max_batch);
   gen.setMap(map.data());
   FILE* o = std::fopen(argv[2], "wb");
-  for (int mode = 0; mode < 2; mode++) {
+  for (int mode = 0; mode < 4; mode++) {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<direct::PlainCorridor> cors(np);
     std::vector<bool> ok(np);
     if (mode == 0) {
       for (int p = 0; p < np; p++) ok[p] = gen.corridorGeneration(paths[p], cors[p]);
-    } else {
+    } else if (mode == 1) {
       std::vector<direct::PlainCorridor*> ptr;
       for (auto& c : cors) ptr.push_back(&c);
       ok = gen.corridorGenerationBatch(paths, ptr);
       std::printf("batch: %d device rounds for %d polytopes on %d paths\n", gen.lastRounds(), gen.lastPolytopes(), np);
+    } else {
+      std::vector<std::vector<std::array<double, 3>>> first(np), second(np);
+      for (int p = 0; p < np; p++) {
+        const size_t h = paths[p].size() / 2;
+        first[p].assign(paths[p].begin(), paths[p].begin() + h);
+        second[p].assign(paths[p].begin() + h, paths[p].end());
+      }
+      if (mode == 2) {
+        for (int p = 0; p < np; p++)
+          ok[p] = gen.corridorInsertGeneration(first[p], cors[p]) == 1 && gen.corridorInsertGeneration(second[p], cors[p]) == 1;
+      } else {
+        std::vector<direct::PlainCorridor*> ptr;
+        for (auto& c : cors) ptr.push_back(&c);
+        const std::vector<int> r1 = gen.corridorInsertGenerationBatch(first, ptr), r2 = gen.corridorInsertGenerationBatch(second, ptr);
+        for (int p = 0; p < np; p++) ok[p] = r1[p] == 1 && r2[p] == 1;
+      }
     }
     std::printf("mode %d: %.3f ms\n", mode, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     for (int p = 0; p < np; p++) {

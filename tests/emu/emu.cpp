@@ -134,7 +134,7 @@ void* emu_begin(int dtype, const direct_ddp_params_t* p, const direct_ddp_batch_
   if (h->dtype == DIRECT_F64) { auto& E = *(Emu<double>*)h->p; typedef double Real; (void)sizeof(Real); body; } \
   else { auto& E = *(Emu<float>*)h->p; typedef float Real; (void)sizeof(Real); body; }
 
-void emu_backward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.bwd_sweep(); })) }
+void emu_backward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.template bwd_sweep_t<true>(); })) }
 void emu_forward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.fwd_pass(); })) }
 void emu_iterate(void* hv, int n) { EMU_CALL(with_state(E, [n](auto& W) { W.iterate(n); })) }
 void emu_get_field(void* hv, int field, void* dst) {

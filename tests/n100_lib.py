@@ -60,14 +60,22 @@ def two_phase(solve, p0, p1, batch0, handoff):
 def sample_report(kind, B, N, idx, dev64, dev32, seed=1000, first=0, control_seeds=(11, 12)):
     """dev64 / dev32: solve(params, HostBatch) -> HostResult on the device (double / float storage), or None.
     Returns the comparison records of one BASELINE batch sample (both phases)."""
-    p0, p1 = abi.phase0_params(), abi.phase1_params()
     full = problems.make_batch(kind, B, N, seed=seed, first=first)
-    sb = full.select(idx)
+    out = batch_report(full.select(idx), dev64, dev32, control_seeds)
+    out.update(kind=kind, batch=B, n_seg=N, first=int(first))
+    return out
+
+
+def batch_report(sb, dev64, dev32, control_seeds=(11, 12)):
+    """The comparison records of the problems `sb` (any HostBatch): device (double / float storage) against the oracle,
+    both phases, phase 1 of every implementation from the ORACLE's phase-0 result, with the oracle-against-itself
+    controls (inputs moved by one ulp of a double / of a float) next to them."""
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
     ora = lambda p, b: refapi.solve_batch(p, b)[0]
     r0 = ora(p0, sb)
     b1 = soak_lib.phase1_inputs(sb, r0)             # the reference's own hand-off: time-scaled Bezier points
     r1 = ora(p1, b1)
-    out = dict(kind=kind, batch=B, n_seg=N, sample=int(len(idx)), first=int(first),
+    out = dict(sample=int(sb.batch),
                oracle=dict(phase0_rtn={str(int(v)): int(c) for v, c in zip(*np.unique(r0.rtn, return_counts=True))},
                            phase1_rtn={str(int(v)): int(c) for v, c in zip(*np.unique(r1.rtn, return_counts=True))},
                            phase0_iters_mean=float(r0.fwd_passes.mean()), phase1_iters_mean=float(r1.fwd_passes.mean())))

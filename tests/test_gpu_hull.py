@@ -89,7 +89,8 @@ def grid_path(grid, start, goal):
 
 
 def test_corridor_generation_walk_and_ddp(built, tmp_path):
-    """corridorGeneration (poly_utils.cpp:508-557) through the C++ host class (direct_amd/host/poly_utils.hpp): grid
+    """corridorGeneration (poly_utils.cpp:508-557) and corridorInsertGeneration (:391-449, the live caller's walk,
+    teach_repeat_planner.cpp:172 / 228) through the C++ host class (direct_amd/host/poly_utils.hpp): grid
     paths -> corridors, path by path and all paths in lock step, against the walk restated over the CPU checkers
     (planes bit for bit); then the corridor is what the DDP path consumes: the replay batch of one of them is solved."""
     import struct
@@ -131,7 +132,12 @@ def test_corridor_generation_walk_and_ddp(built, tmp_path):
         return v
     cache, modes = {}, []
     want = [corridor_walk.corridor_generation(grid, RES, LOWER, p, cache=cache) for p in paths]
-    for mode in range(2):
+    want_ins = []  # corridorInsertGeneration (poly_utils.cpp:391-449): first half into an empty corridor, second half into that
+    for p in paths:
+        c1, r1 = corridor_walk.corridor_insert_generation(grid, RES, LOWER, p[:len(p) // 2], [], cache=cache)
+        c2, r2 = corridor_walk.corridor_insert_generation(grid, RES, LOWER, p[len(p) // 2:], c1, cache=cache)
+        want_ins.append((c2, r1 == 1 and r2 == 1))
+    for mode in range(4):
         got = []
         for p in range(len(paths)):
             ok, n = take("<2i")
@@ -144,8 +150,10 @@ def test_corridor_generation_walk_and_ddp(built, tmp_path):
         modes.append(got)
     assert off == len(raw)
     n_poly = 0
-    for got in modes:
-        for (gc, gok), (wc, wok) in zip(got, want):
+    # the insert walk never pops: on these paths it keeps polytopes the plain walk drops again
+    assert sum(len(c) for c, _ in want_ins) >= sum(len(c) for c, _ in want)
+    for mi, got in enumerate(modes):
+        for (gc, gok), (wc, wok) in zip(got, want if mi < 2 else want_ins):
             assert gok == wok and len(gc) == len(wc) and len(gc) >= 2
             for a, b in zip(gc, wc):
                 assert np.array_equal(a["planes"], b["planes"]) and np.array_equal(a["center"], b["center"])
