@@ -11,7 +11,7 @@ import numpy as np
 
 NX = 9
 NU = 10
-P_LIMIT = 76
+P_LIMIT = 128
 
 DIRECT_OK = 0
 DIRECT_ERR_INVALID = 1

@@ -185,7 +185,7 @@ DDP_DEV void static_for_down(F&& f) {  // B, B-1, ..., E
   }
 }
 
-constexpr int kPLim = 76;  // DIRECT_P_LIMIT: (64 * 8 - 55) / 6, eight row slots per lane
+constexpr int kPLim = 128;  // DIRECT_P_LIMIT: what polyhedronGenerator can emit (128 planes); fourteen row slots per lane hold (64 * 14 - 55) / 6 = 140
 
 #if !defined(DIRECT_EMULATE)
 #if defined(DDP_TIMING)
@@ -389,7 +389,11 @@ constexpr int kMaxBuf = 12;  // iterate buffers: `cur` + one per concurrently ev
 // ---- device-resident batch (all pointers are device memory) -----------------------------------
 template <typename Real>
 struct Batch {
-  int B, nmax, pmax, ncs;  // ncs = row stride of S/Y/KS/KY (>= 6*pmax+55)
+  int B, nmax, pmax, ncs;  // B: trajectories of THIS launch; ncs = row stride of S/Y/KS/KY (>= 6*pmax+55)
+  // Row-slot classes (direct_ddp.hip): a launch covers the trajectories idx[0 .. B) of the handle's batch, the ones whose
+  // widest polytope fits this instantiation's row slots; null: trajectories 0 .. B - 1 themselves.  Every per-trajectory
+  // array stays indexed by the trajectory's own number.
+  const int32_t* idx;
   int fcap, nbuf, help_early, tail_thresh;  // nbuf: iterate buffers in use (3, or kMaxBuf with the shared line search);
                                      // help_early: single-step searches are open to helpers from step 0 on
   const int32_t* n_seg;
@@ -757,8 +761,14 @@ struct Wave {
   // spill reload waits for every outstanding load, the HBM prefetch included
   static constexpr bool kWide = sizeof(St) < sizeof(double) && RPL <= 2;
   // Field widths of the packed row descriptor: rows fit eight bits up to four row slots per lane (6 P + 55 <= 255);
-  // the kernels with five to eight slots (polytopes of 34 .. 76 planes: 6 P + 55 <= 511) take a ninth bit from a0 (< 64).
-  static constexpr int kRB = RPL > 4 ? 9 : 8;
+  // the kernels with five to eight slots (polytopes of 34 .. 76 planes: 6 P + 55 <= 511) take a ninth bit from a0 (< 64),
+  // those with ten to fourteen (up to 128 planes: 6 P + 55 <= 823) a tenth.
+  static constexpr int kRB = RPL > 8 ? 10 : (RPL > 4 ? 9 : 8);
+  // Row slots a knot with P planes really uses: position rows fill slots 0 .. ceil(6 P / 64) - 1, the last slot always
+  // holds the 55 velocity / acceleration / T_min rows.  The kernels with many slots skip the others (a wave-uniform
+  // branch per slot): a corridor whose widest polytope has 60 planes mostly consists of polytopes with 15 - 20
+  // (DESIGN.md section 7d), and every slot costs its loads and ~40 instructions per row phase.
+  static DDP_DEV bool slot_on(int slot, int P) { return RPL <= 2 || slot == RPL - 1 || 64 * slot < 6 * P; }
   static constexpr int kRMask = (1 << kRB) - 1, kAMask = (1 << (16 - kRB)) - 1;
   static constexpr int kNPL = (4 * Lds::kPMax + 63) / 64 > 2 ? (4 * Lds::kPMax + 63) / 64 : 2;  // plane words per lane
   struct Pre {  // held in the storage type: half the registers in DIRECT_F32
@@ -778,6 +788,7 @@ struct Wave {
       // the knot's row descriptors: computed once, carried to its row phases; they only depend on P,
       // so a run of knots with the same plane count (every free-space corridor) reuses them
       if (!pk_valid) pkv[i] = row_pack(i, lane, P);
+      if (!slot_on(i, P)) continue;
       const int r = (pkv[i] & kRMask) - 1;
       const int rc = r >= 0 ? r : 0;  // rows that do not exist read row 0; their results are masked
       p.s[i] = sk[rc];
@@ -956,7 +967,7 @@ struct Wave {
     const int rp = last ? 64 * (RPL - 1) + lane - 55 : lane + 64 * slot;
     const bool pv = rp >= 0 && rp < 6 * P;
     const int rq = pv ? rp : 0;
-    const int j = (int)(DDP_UMUL24((unsigned)rq, kInvP[P]) >> 16);  // rq / P: the control point
+    const int j = (int)(DDP_UMUL24((unsigned)rq, kInvP[P]) >> kInvPShift);  // rq / P: the control point
     const int q = rq - (int)DDP_UMUL24((unsigned)j, (unsigned)P);   // the plane
     int pk = (pv ? rp + 1 : 0) | ((3 * j) << kRB) | (q << 16);
     if (last) {  // lanes 0..54: velocity (30), acceleration (24), T_min (1) rows  (DDP:1236-1238, 1274-1279)
@@ -1112,6 +1123,7 @@ struct Wave {
         if (infeas) {
           const St* yk = Sp_(B.Y[buf], k);
           for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
             const int r = (row_pack(i, lane, P) & kRMask) - 1;
             LV(yv)[i] = (Real)yk[r >= 0 ? r : 0];
           }
@@ -1140,6 +1152,7 @@ struct Wave {
       qsum += knot_cost(T, L.ft[0].qp);
       LANES {
         for (int i = 0; i < RPL; i++) {
+          if (!slot_on(i, P)) continue;
           const RowK<Real> rk = row_slot(i, lane, P);
           const int r = rk.r;
           if (r >= 0) {
@@ -1233,6 +1246,7 @@ struct Wave {
         LANES {
           LV(bad) = 0;
           for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
             const RowK<Real> rk = row_slot(i, lane, P);
             if (rk.r >= 0 && !(row_c(L.val, rk) < (Real)0)) LV(bad) = 1;
           }
@@ -1450,9 +1464,10 @@ struct Wave {
         LV(tw_t2) = L.lt[7][lane];
         commit(LV(pre), lane, P, false);
         for (int i = 0; i < RPL; i++) {
+          LV(pkc)[i] = LV(pkn)[i];
+          if (!slot_on(i, P)) continue;
           LV(rs)[i] = (Real)LV(pre).s[i];
           LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
-          LV(pkc)[i] = LV(pkn)[i];
         }
       }
       // the segment time straight from lane 18's prefetch registers (hi + lo with float storage, see ldx()):
@@ -1524,12 +1539,14 @@ struct Wave {
         Row3 ov1[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; i++) {
+          if (!slot_on(i, P)) continue;
           rk1[i] = row_unpack2(LV(pkc)[i]);
           ov1[i] = row_ops(L.val, LV(pkc)[i]);
         }
         DDP_LOADS_ISSUED();
 #pragma unroll
         for (int i = 0; i < RPL; i++) {
+          if (!slot_on(i, P)) continue;
           // every lane runs the row arithmetic (empty slots alias row 0); only the stores and the
           // running maxima are masked
           const RowK<Real>& rk = rk1[i];
@@ -1920,12 +1937,14 @@ struct Wave {
           Row3 og2[RPL];
 #pragma unroll
           for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
             rk2[i] = row_unpack2(LV(pkc)[i]);
             og2[i] = row_ops(L.G, LV(pkc)[i]);
           }
           DDP_LOADS_ISSUED();
 #pragma unroll
           for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
             const RowK<Real>& rk = rk2[i];
             const int r = rk.r;
             const Real cuku = row_dot(rk, og2[i]);
@@ -2274,9 +2293,10 @@ struct Wave {
         if (kWide) LV(tw_ft) = L.lt[7][lane];
         commit(LV(pre), lane, P, true);
         for (int i = 0; i < RPL; i++) {
+          LV(pkc)[i] = LV(pkn)[i];
+          if (!slot_on(i, P)) continue;
           LV(rs)[i] = (Real)LV(pre).s[i];
           LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
-          LV(pkc)[i] = LV(pkn)[i];
         }
       }
       // the old T straight from lane 18's prefetch register (no LDS round trip)
@@ -2515,6 +2535,7 @@ struct Wave {
           }
         } else {  // double storage / many row slots: row by row, both trials of a row together (the registers hold no more)
           for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
             // branch-free rows: empty slots alias row 0, their stores / reductions are masked
             const RowK<Real> rk = row_unpack(LV(pkc)[i]);
             const int r = rk.r;
@@ -2961,6 +2982,7 @@ DDP_DEV void get_field_wave(Wave<Real, St, RPL>& W, int field, St* dst) {
       WSYNC();
       LANES {
         for (int i = 0; i < RPL; i++) {
+          if (!W.slot_on(i, P)) continue;
           const RowK<Real> rk = W.row_slot(i, lane, P);
           if (rk.r >= 0) dst[rowbase + rk.r] = (St)W.row_c(W.L.val, rk);
         }

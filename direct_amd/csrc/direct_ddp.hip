@@ -39,10 +39,16 @@ struct MinWaves { static constexpr int v = DDP_WAVES_F32; };
 template <>
 struct MinWaves<double> { static constexpr int v = DDP_WAVES_F64; };
 
+// trajectory of the i-th workgroup / ticket of a launch (Batch::idx: the launch's row-slot class)
+template <typename St>
+__device__ __forceinline__ int traj_of(const Batch<St>& B, int i) {
+  return B.idx ? __builtin_amdgcn_readfirstlane(B.idx[i]) : i;
+}
+
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_begin(Batch<St> B) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
-  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
+  Wave<Cmp, St, RPL> W(B, lds, traj_of(B, blockIdx.x));
   W.init_tables();
   W.begin();
   W.store_state();
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(64) void k_begin(Batch<St> B) {
 template <typename St, int RPL>
 __global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate(Batch<St> B, int n_iters) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
-  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
+  Wave<Cmp, St, RPL> W(B, lds, traj_of(B, blockIdx.x));
   W.load_state();
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
@@ -84,7 +90,7 @@ struct Sched {
 // wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early
 // exits on purpose: inlined into the (huge) iterate loop the structuriser turned the nested uniform loops into
 // exec-masked ones.
-__device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, unsigned nb, unsigned total, int held,
+__device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, const int32_t* idx, unsigned nb, unsigned total, int held,
                                                    int* waited, int* help) {
   unsigned t = (unsigned)held;
   if (held < 0) {
@@ -95,7 +101,8 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, uns
   }
   *help = 0;
   if (t >= total) return -1;
-  const int e = (int)(t / nb), b = (int)(t - (unsigned)e * nb);
+  const int e = (int)(t / nb), bi = (int)(t - (unsigned)e * nb);
+  const int b = idx ? __builtin_amdgcn_readfirstlane(idx[bi]) : bi;  // done_epoch / slots are indexed by the trajectory's own number
   int ready = (e == 0) ? 1 : 0, have = 0, wanted = 0;
   int spins = 0;
   for (; !ready && !wanted && spins < (1 << 22); spins++) {
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate
   for (;;) {
     int help_v = 0;
     DDP_MARK("X_T");
-    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, nb, total, held, &waited, &help_v));
+    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, B.idx, nb, total, held, &waited, &help_v));
     const int help = __builtin_amdgcn_readfirstlane(help_v);
     DDP_MARK("X_G");
     held = -1;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate
       continue;
     }
     const int e = __builtin_amdgcn_readfirstlane((int)((unsigned)t / nb));
-    const int b = __builtin_amdgcn_readfirstlane(t - e * (int)nb);
+    const int b = traj_of(B, __builtin_amdgcn_readfirstlane(t - e * (int)nb));
     W.b = b;
     // A chunk whose predecessor was still running when its ticket was drawn belongs to a trajectory that lags the
     // batch, i.e. to the critical chain of the launch: it gets the SIMD's issue priority over the co-resident waves
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
-  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
+  Wave<Cmp, St, RPL> W(B, lds, traj_of(B, blockIdx.x));
   W.load_state();
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_finish(Batch<St> B, OutPtrs<St> O, const int* sched_err) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
-  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
+  Wave<Cmp, St, RPL> W(B, lds, traj_of(B, blockIdx.x));
   W.load_state();
   W.init_tables();
   // a scheduler error makes the whole launch's results suspect: every row says so (direct_ddp.h)
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(64) void k_finish(Batch<St> B, OutPtrs<St> O, const
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_field(Batch<St> B, int field, St* buf, int set) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
-  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
+  Wave<Cmp, St, RPL> W(B, lds, traj_of(B, blockIdx.x));
   W.load_state();
   W.init_tables();
   if (set) {
@@ -288,6 +295,19 @@ static direct_status_t fail(direct_status_t st, const std::string& msg) {
 
 struct direct_ddp_handle_s {
   int dtype = 0, device = 0, max_batch = 0, nmax = 0, pmax = 0, ncs = 0, rpl = 2, fcap = 0;
+  // Row-slot classes of the current batch (stage_inputs -> classify_batch): a trajectory runs on the kernels instantiated
+  // for ITS widest polytope, not for the handle's p_max - one 59-plane polytope in one corridor used to put the whole
+  // batch on the one-wave-per-SIMD kernels.  `order` lists the trajectories class by class; `classes` the non-empty
+  // classes (empty: every trajectory runs on the handle's own class `rpl`, identity order - always so for p_max <= 12).
+  struct Cls { int rpl, off, cnt; };
+  std::vector<Cls> classes;
+  int32_t* order = nullptr;     // device [max_batch]
+  int32_t* cls_dev = nullptr;   // device [max_batch]: row slots per trajectory (scratch of the classification)
+  int* tickets = nullptr;       // device [16]: one ticket counter per class launch
+  int slots_of[16] = {};        // resident one-wave workgroups of k_iterate_dyn per row-slot class (0: not asked yet)
+  int n_cu = 0;
+  hipStream_t cstream[12] = {};  // the class launches of one iterate call run side by side (created on first use)
+  hipEvent_t cev[12] = {}, fork_ev = nullptr;
   size_t rsz = 4;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -328,7 +348,8 @@ struct direct_ddp_handle_s {
   int* live = nullptr;                   // [1] unfinished trajectories of the running launch (Batch::live)
   unsigned long long* visits = nullptr;  // [2] sweep-work counters of the last hot-kernel launch (direct_ddp_last_launch_info)
   direct_ddp_launch_info_t last_info = {};
-  int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device
+  int sched_slots = 0;   // resident one-wave workgroups of k_iterate_dyn on this device (the handle's own class)
+  int slots_cap = 0;     // DIRECT_DDP_SLOTS: fewer persistent waves than fit (experiments)
   int sched_chunk = 1;   // outer-loop trips per ticket (DIRECT_DDP_CHUNK at create time; experiments)
   int pair_trials = -1;  // two line-search steps per forward sweep from the second attempt on: -1 auto, DIRECT_DDP_PAIR=0|1 forces
   int sched_prio = 1;    // chunks that had to wait for their predecessor run at raised wave priority (DIRECT_DDP_PRIO=0: off)
@@ -356,11 +377,21 @@ static direct_status_t dalloc(direct_ddp_handle_t h, T** p, size_t bytes) {
     if (s_ != DIRECT_OK) return s_;          \
   } while (0)
 
+// the classes of the current batch: the recorded ones, or the whole batch on the handle's own class
+static std::vector<direct_ddp_handle_s::Cls> batch_classes(direct_ddp_handle_t h) {
+  if (!h->classes.empty()) return h->classes;
+  return {direct_ddp_handle_s::Cls{h->rpl, 0, h->B}};
+}
 template <typename Real>
-static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t& in, const direct_ddp_params_t& p) {
+static int resident_slots(direct_ddp_handle_t h, int rpl);
+
+template <typename Real>
+static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t& in, const direct_ddp_params_t& p,
+                              const direct_ddp_handle_s::Cls& c) {
   Batch<Real> B;
   memset(&B, 0, sizeof(B));
-  B.B = in.batch; B.nmax = h->nmax; B.pmax = h->pmax; B.ncs = h->ncs; B.fcap = h->fcap;
+  B.B = c.cnt; B.idx = h->classes.empty() ? nullptr : h->order + c.off;
+  B.nmax = h->nmax; B.pmax = h->pmax; B.ncs = h->ncs; B.fcap = h->fcap;
   B.n_seg = in.n_seg; B.x0 = (const Real*)in.x0; B.xd = (const Real*)in.xd; B.T0 = (const Real*)in.T0;
   B.n_planes = in.n_planes; B.planes = (const Real*)in.planes; B.init_bez = (const Real*)in.init_bez;
   B.init_poly = (const Real*)in.init_poly;
@@ -385,95 +416,172 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   k.line_init = p.line_init; k.minvo = p.minvo; k.fixed_iters = p.fixed_iters; k.exact_dt = p.exact_dt;
   // two trials per sweep pay off where the launch is bound by its slowest chain (batch up to twice the resident
   // waves: +4 % at B = 4096) and cost ~1 % where it is throughput-bound; results are identical either way
-  k.pair_trials = h->pair_trials >= 0 ? h->pair_trials : ((h->sched_slots > 0 && in.batch <= 2 * h->sched_slots) ? 1 : 0);
+  const int slots = resident_slots<Real>(h, c.rpl);
+  k.pair_trials = h->pair_trials >= 0 ? h->pair_trials : ((slots > 0 && c.cnt <= 2 * slots) ? 1 : 0);
   // few trajectories on many waves and a shared line search: single steps, one wave each, beat pairs
-  if (h->pair_trials < 0 && h->help && h->help_mode != 0 && h->dynamic && h->nmax >= 80 && (long long)in.batch * h->single_ratio <= (long long)h->sched_slots)
+  if (h->pair_trials < 0 && h->help && h->help_mode != 0 && h->dynamic && h->nmax >= 80 && (long long)c.cnt * h->single_ratio <= (long long)slots)
     k.pair_trials = 0;
   return B;
 }
 
-#define RPL_LAUNCH(h, KERNEL, Real, grid, ...)                                                          \
-  do {                                                                                                   \
-    if ((h)->rpl <= 2) hipLaunchKernelGGL((KERNEL<Real, 2>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else if ((h)->rpl == 3) hipLaunchKernelGGL((KERNEL<Real, 3>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else if ((h)->rpl == 4) hipLaunchKernelGGL((KERNEL<Real, 4>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else if ((h)->rpl == 5) hipLaunchKernelGGL((KERNEL<Real, 5>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else if ((h)->rpl == 6) hipLaunchKernelGGL((KERNEL<Real, 6>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else if ((h)->rpl == 7) hipLaunchKernelGGL((KERNEL<Real, 7>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<Real, 8>), dim3(grid), dim3(64), 0, (h)->stream, __VA_ARGS__);       \
+// Row-slot classes the kernels are instantiated for: 2 .. 8 slots per lane (polytopes of up to 12, 22, 33, 44, 54, 65, 76
+// planes) and 10, 12, 14 (97, 118, 128 = DIRECT_P_LIMIT).  Class numbers passed to RPL_LAUNCH are always one of them.
+#if defined(DDP_DEV_RPL2)  // development builds (tools/fastbuild.sh): only the two-slot kernels are instantiated, 7 x faster to compile
+#define RPL_LAUNCH(rpl, stream, KERNEL, Real, grid, ...) \
+  hipLaunchKernelGGL((KERNEL<Real, 2>), dim3(grid), dim3(64), 0, stream, __VA_ARGS__)
+#else
+#define RPL_CASE(stream, KERNEL, Real, grid, R, ...) \
+  case R: hipLaunchKernelGGL((KERNEL<Real, R>), dim3(grid), dim3(64), 0, stream, __VA_ARGS__); break;
+#define RPL_LAUNCH(rpl, stream, KERNEL, Real, grid, ...)            \
+  do {                                                              \
+    switch (rpl) {                                                  \
+      RPL_CASE(stream, KERNEL, Real, grid, 2, __VA_ARGS__)          \
+      RPL_CASE(stream, KERNEL, Real, grid, 3, __VA_ARGS__)          \
+      RPL_CASE(stream, KERNEL, Real, grid, 4, __VA_ARGS__)          \
+      RPL_CASE(stream, KERNEL, Real, grid, 5, __VA_ARGS__)          \
+      RPL_CASE(stream, KERNEL, Real, grid, 6, __VA_ARGS__)          \
+      RPL_CASE(stream, KERNEL, Real, grid, 7, __VA_ARGS__)          \
+      RPL_CASE(stream, KERNEL, Real, grid, 8, __VA_ARGS__)          \
+      RPL_CASE(stream, KERNEL, Real, grid, 10, __VA_ARGS__)         \
+      RPL_CASE(stream, KERNEL, Real, grid, 12, __VA_ARGS__)         \
+      default: hipLaunchKernelGGL((KERNEL<Real, 14>), dim3(grid), dim3(64), 0, stream, __VA_ARGS__); \
+    }                                                               \
   } while (0)
+#endif
+
+// smallest instantiated row-slot class that holds `slots` row slots per lane
+static int rpl_class(int slots) {
+#if defined(DDP_DEV_RPL2)
+  (void)slots;
+  return 2;
+#else
+  return slots <= 2 ? 2 : (slots <= 8 ? slots : (slots <= 10 ? 10 : (slots <= 12 ? 12 : 14)));
+#endif
+}
+// resident one-wave workgroups of k_iterate_dyn of one class on this device (asked once per class)
+template <typename Real>
+static int resident_slots(direct_ddp_handle_t h, int rpl) {
+  if (rpl < 0 || rpl > 15) return 0;
+  if (h->slots_of[rpl] != 0) return h->slots_of[rpl] < 0 ? 0 : h->slots_of[rpl];
+  int per_cu = 0;
+  hipError_t e;
+#if defined(DDP_DEV_RPL2)
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 2>, 64, 0);
+#else
+  switch (rpl) {
+#define OCC_CASE(R) case R: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, R>, 64, 0); break;
+    OCC_CASE(2) OCC_CASE(3) OCC_CASE(4) OCC_CASE(5) OCC_CASE(6) OCC_CASE(7) OCC_CASE(8) OCC_CASE(10) OCC_CASE(12)
+#undef OCC_CASE
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 14>, 64, 0);
+  }
+#endif
+  int v = (e == hipSuccess && per_cu > 0) ? per_cu * h->n_cu : 0;
+  if (h->slots_cap > 0 && v > h->slots_cap) v = h->slots_cap;  // DIRECT_DDP_SLOTS (experiments)
+  h->slots_of[rpl] = v > 0 ? v : -1;
+  return v;
+}
 
 template <typename Real>
 static void launch_begin_t(direct_ddp_handle_t h) {
-  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
-  RPL_LAUNCH(h, k_begin, Real, h->B, Bt);
+  for (const auto& c : batch_classes(h)) {
+    auto Bt = make_batch<Real>(h, h->cur_in, h->params, c);
+    RPL_LAUNCH(c.rpl, h->stream, k_begin, Real, c.cnt, Bt);
+  }
 }
-template <typename Real>
-static int resident_slots(direct_ddp_handle_t h, int n_cu) {
-  int per_cu = 0;
-  hipError_t e;
-  if (h->rpl <= 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 2>, 64, 0);
-  else if (h->rpl == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 3>, 64, 0);
-  else if (h->rpl == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 4>, 64, 0);
-  else if (h->rpl == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 5>, 64, 0);
-  else if (h->rpl == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 6>, 64, 0);
-  else if (h->rpl == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 7>, 64, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_iterate_dyn<Real, 8>, 64, 0);
-  return (e == hipSuccess && per_cu > 0) ? per_cu * n_cu : 0;
+// The classes of one iterate call run SIDE BY SIDE, each on a stream of its own forked from the handle's: a small
+// batch is bound by its longest chain of iterations, and one class after the other would add those chains up.
+static hipStream_t class_stream(direct_ddp_handle_t h, size_t ci, size_t n_classes) {
+  if (n_classes <= 1 || ci >= 12) return h->stream;
+  if (!h->fork_ev && hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) return h->stream;
+  if (!h->cstream[ci]) {
+    if (hipStreamCreateWithFlags(&h->cstream[ci], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->cev[ci], hipEventDisableTiming) != hipSuccess) {
+      h->cstream[ci] = nullptr;
+      return h->stream;
+    }
+  }
+  return h->cstream[ci];
 }
 template <typename Real>
 static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
-  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
-  Bt.visits = h->visits;
+  const auto classes = batch_classes(h);
   (void)hipMemsetAsync(h->visits, 0, 2 * sizeof(unsigned long long), h->stream);
   direct_ddp_launch_info_t& li = h->last_info;
   li = direct_ddp_launch_info_t{};
-  li.pair_trials = Bt.k.pair_trials; li.n_buffers = h->nbuf; li.batch = h->B;
+  li.n_buffers = h->nbuf; li.batch = h->B;
   if (mode == 0) {
+    (void)hipMemsetAsync(h->tickets, 0, 16 * sizeof(int), h->stream);
+    (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);  // done_epoch; the error flag [1] is sticky: cleared in stage_inputs
+    if (h->help) (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
+  }
+  bool forked = false;
+  if (mode == 0 && classes.size() > 1 && class_stream(h, 0, classes.size()) != h->stream) {
+    (void)hipEventRecord(h->fork_ev, h->stream);
+    forked = true;
+  }
+  int biggest = -1;
+  for (size_t ci = 0; ci < classes.size(); ci++) {
+    const auto& c = classes[ci];
+    auto Bt = make_batch<Real>(h, h->cur_in, h->params, c);
+    Bt.visits = h->visits;
+    hipStream_t st = h->stream;
+    if (forked) {
+      st = class_stream(h, ci, classes.size());
+      if (st != h->stream) (void)hipStreamWaitEvent(st, h->fork_ev, 0);
+    }
+    if (mode != 0) {
+      RPL_LAUNCH(c.rpl, st, k_pass, Real, c.cnt, Bt, mode);
+      continue;
+    }
+    const int slots = resident_slots<Real>(h, c.rpl);
     // shared line search: where the launch is bound by its slowest chain and a round is long enough to pay for the
     // protocol's fences (agent-scope release = L2 write-back).  Measured at N = 100: +5 .. +13 % for batches up to 4/3 of
     // the resident waves, -1.4 % at twice the resident waves, +15 .. +20 % below them; at N = 60: -1 .. -5 %; at
     // N = 30: up to -35 %.  Unless forced either way.
-    const bool help = h->help && (h->help_mode >= 0 ? h->help_mode != 0 : (2 * h->B <= 3 * h->sched_slots && h->nmax >= 80));
+    const bool help = h->help && (h->help_mode >= 0 ? h->help_mode != 0 : (2 * c.cnt <= 3 * slots && h->nmax >= 80));
+    const bool is_big = biggest < 0 || c.cnt > classes[biggest].cnt;
+    if (is_big) {
+      biggest = (int)ci;
+      li.pair_trials = Bt.k.pair_trials; li.resident_waves = slots; li.dynamic = 0; li.shared_search = 0; li.single_steps = 0;
+    }
     // The static launch is tail-free when every trajectory is resident at once - but then the waves that are left
     // over have nothing to do, while the ticket scheduler turns them into helpers: with help it is used for small
     // batches too (DIRECT_DDP_SMALL=0: not below the resident waves).
-    if (h->dynamic && h->sched_slots > 0 && (h->B > h->sched_slots || (help && h->small_dyn))) {
+    if (h->dynamic && slots > 0 && (c.cnt > slots || (help && h->small_dyn))) {
       Sched S;
-      S.ticket = (unsigned*)h->sched;
+      S.ticket = (unsigned*)(h->tickets + (ci < 16 ? ci : 15));
       S.err = h->sched + 1;
       S.done_epoch = h->sched + 2;
       S.chunk = h->sched_chunk;
       S.prio = h->sched_prio;
-      (void)hipMemsetAsync(h->sched, 0, sizeof(int), h->stream);  // the error flag [1] is sticky: cleared in stage_inputs
-      (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);
       if (help) {
-        (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
         Bt.help = h->help;
         Bt.help_early = h->help_early;
-        // the launch's tail: when at most sched_slots / single_ratio trajectories are left (natural exits), their line
+        // the launch's tail: when at most slots / single_ratio trajectories are left (natural exits), their line
         // searches go to single steps open from step 0, as a batch that small would from the start
-        (void)hipMemsetD32Async((hipDeviceptr_t)h->live, h->B, 1, h->stream);
-        Bt.live = h->live;
-        Bt.tail_thresh = h->single_ratio > 0 ? h->sched_slots / h->single_ratio : 0;
-        li.shared_search = 1;
-        li.single_steps = Bt.k.pair_trials ? 0 : 1;
+        int* live = h->live + (ci < 16 ? ci : 15);
+        (void)hipMemsetD32Async((hipDeviceptr_t)live, c.cnt, 1, st);
+        Bt.live = live;
+        Bt.tail_thresh = h->single_ratio > 0 ? slots / h->single_ratio : 0;
+        if (is_big) { li.shared_search = 1; li.single_steps = Bt.k.pair_trials ? 0 : 1; }
       }
-      li.dynamic = 1;
-      li.resident_waves = h->sched_slots;
-      RPL_LAUNCH(h, k_iterate_dyn, Real, h->sched_slots, Bt, n, S);
+      if (is_big) li.dynamic = 1;
+      RPL_LAUNCH(c.rpl, st, k_iterate_dyn, Real, slots, Bt, n, S);
     } else {
-      li.resident_waves = h->sched_slots;
-      RPL_LAUNCH(h, k_iterate, Real, h->B, Bt, n);
+      RPL_LAUNCH(c.rpl, st, k_iterate, Real, c.cnt, Bt, n);
     }
-  } else {
-    RPL_LAUNCH(h, k_pass, Real, h->B, Bt, mode);
+    if (forked && st != h->stream) {
+      (void)hipEventRecord(h->cev[ci], st);
+      (void)hipStreamWaitEvent(h->stream, h->cev[ci], 0);
+    }
   }
 }
 template <typename Real>
 static void launch_field_t(direct_ddp_handle_t h, int field, int set) {
-  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
-  RPL_LAUNCH(h, k_field, Real, h->B, Bt, field, (Real*)h->fieldbuf, set);
+  for (const auto& c : batch_classes(h)) {
+    auto Bt = make_batch<Real>(h, h->cur_in, h->params, c);
+    RPL_LAUNCH(c.rpl, h->stream, k_field, Real, c.cnt, Bt, field, (Real*)h->fieldbuf, set);
+  }
 }
 template <typename Real>
 static OutPtrs<Real> out_ptrs(direct_ddp_handle_t h, const direct_ddp_batch_out_t* out) {
@@ -491,9 +599,11 @@ static OutPtrs<Real> out_ptrs(direct_ddp_handle_t h, const direct_ddp_batch_out_
 }
 template <typename Real>
 static void launch_finish_t(direct_ddp_handle_t h, const direct_ddp_batch_out_t* out) {
-  auto Bt = make_batch<Real>(h, h->cur_in, h->params);
   auto O = out_ptrs<Real>(h, out);
-  RPL_LAUNCH(h, k_finish, Real, h->B, Bt, O, (const int*)(h->sched + 1));
+  for (const auto& c : batch_classes(h)) {
+    auto Bt = make_batch<Real>(h, h->cur_in, h->params, c);
+    RPL_LAUNCH(c.rpl, h->stream, k_finish, Real, c.cnt, Bt, O, (const int*)(h->sched + 1));
+  }
 }
 
 // direct_traj_sample_batch for one storage type: host arrays are staged through temporary device buffers
@@ -598,7 +708,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   h->rsz = cfg->dtype == DIRECT_F64 ? 8 : 4;
   const int ncm = 6 * cfg->p_max + 55;
   h->ncs = (ncm + 3) / 4 * 4;
-  h->rpl = (ncm + 63) / 64;
+  h->rpl = rpl_class((ncm + 63) / 64);
   h->fcap = 0;
   const size_t B = cfg->max_batch, nm = cfg->n_seg_max, r = h->rsz;
   const size_t xs = cfg->dtype == DIRECT_F64 ? x_stride<double>() : x_stride<float>();  // knot record of the iterate
@@ -610,8 +720,9 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B); A(&h->infeas_next, B);
   h->dynamic = !(cfg->reserved & DIRECT_FLAG_STATIC_SCHEDULE);
   if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
-  h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, prop.multiProcessorCount)
-                                            : resident_slots<float>(h, prop.multiProcessorCount);
+  h->n_cu = prop.multiProcessorCount;
+  if (const char* ev = getenv("DIRECT_DDP_SLOTS")) h->slots_cap = atoi(ev) > 0 ? atoi(ev) : 0;  // experiments: fewer persistent waves than fit
+  h->sched_slots = cfg->dtype == DIRECT_F64 ? resident_slots<double>(h, h->rpl) : resident_slots<float>(h, h->rpl);
   if (const char* ev = getenv("DIRECT_DDP_HELP")) h->help_mode = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_SINGLE")) h->single_ratio = atoi(ev) > 0 ? atoi(ev) : (1 << 30);
   if (const char* ev = getenv("DIRECT_DDP_SMALL")) h->small_dyn = atoi(ev) != 0;
@@ -641,14 +752,12 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->best_idx, 16); A(&h->best_cost, 16);
   A(&h->sched, (B + 2) * sizeof(int));
   A(&h->visits, 2 * sizeof(unsigned long long));
-  A(&h->live, 16);
+  A(&h->live, 16 * sizeof(int));
+  A(&h->tickets, 16 * sizeof(int));
+  A(&h->order, B * sizeof(int32_t)); A(&h->cls_dev, B * sizeof(int32_t));
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
   if (const char* ev = getenv("DIRECT_DDP_PRIO")) h->sched_prio = atoi(ev);
   if (const char* ev = getenv("DIRECT_DDP_PAIR")) h->pair_trials = atoi(ev);
-  if (const char* ev = getenv("DIRECT_DDP_SLOTS")) {  // experiments: fewer persistent waves than fit
-    const int v = atoi(ev);
-    if (v > 0 && v < h->sched_slots) h->sched_slots = v;
-  }
   h->fieldbuf_bytes = B * nm * (size_t)std::max(ncm, 100) * r + B * 16 * r + B * 9 * r;
   A(&h->fieldbuf, h->fieldbuf_bytes);
   if (st == DIRECT_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
@@ -672,6 +781,11 @@ direct_status_t direct_ddp_destroy(direct_ddp_handle_t h) {
   if (h->filt) (void)hipFree(h->filt);
   for (void* q : {h->g_recs, h->g_blocks, h->g_win, h->g_in})
     if (q) (void)hipFree(q);
+  for (int i = 0; i < 12; i++) {
+    if (h->cstream[i]) { (void)hipStreamSynchronize(h->cstream[i]); (void)hipStreamDestroy(h->cstream[i]); }
+    if (h->cev[i]) (void)hipEventDestroy(h->cev[i]);
+  }
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -691,6 +805,71 @@ static direct_status_t check_params(const direct_ddp_params_t* p) {
   if (p->time_power != 1 && p->time_power != 2)
     return fail(DIRECT_ERR_INVALID, "time_power must be 1 or 2 (computeq has no other branch, ddp_optimizer.cpp:1294-1305)");
   if (p->iter_max < 0) return fail(DIRECT_ERR_INVALID, "iter_max < 0");
+  return DIRECT_OK;
+}
+
+// Row slots per lane the widest polytope of every trajectory needs (device-resident inputs: the host never sees them).
+// Sizes outside the handle's configuration are clamped: begin() turns such rows into DIRECT_RTN_INVALID whatever
+// kernels they are sent to.
+__global__ void k_classify(int B, int nmax, int pmax, const int32_t* n_seg, const int32_t* n_planes, int32_t* slots) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int N = n_seg[b];
+  N = N < 0 ? 0 : (N > nmax ? nmax : N);
+  int pm = 1;
+  for (int k = 0; k < N; k++) {
+    const int p = n_planes[(size_t)b * nmax + k];
+    pm = p > pm ? p : pm;
+  }
+  pm = pm > pmax ? pmax : pm;
+  slots[b] = (6 * pm + 55 + 63) / 64;
+}
+// Sorts the trajectories of the current batch into row-slot classes (direct_ddp_handle_s::classes).  Handles whose
+// p_max fits the two-slot kernels have one class by construction and skip all of this.  n_seg / n_planes: host arrays
+// (host-memory inputs) or device arrays (one small read-back).
+static direct_status_t classify_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t* in, bool on_host) {
+  h->classes.clear();
+  // Classes buy OCCUPANCY (three waves per SIMD instead of one for the trajectories whose polytopes allow it), which only
+  // matters when the batch does not fit the resident waves of the handle's own class anyway.  A batch that does is bound
+  // by the chain of its longest solve, and a lone wave runs FASTER on the wide kernels (one wave per SIMD: up to 512
+  // registers, no spills; the row slots a knot does not need are skipped at run time): 710 real-corridor plans, 36 ms on
+  // the one class of their widest polytope against 65 ms spread over six classes (profiles/r04_real_corridors.json).
+  // DIRECT_DDP_CLASSES=0 | 1 forces either way.
+  const char* force = getenv("DIRECT_DDP_CLASSES");
+  if (h->rpl <= 2 || getenv("DIRECT_DDP_ONE_CLASS") || (force && atoi(force) == 0)) return DIRECT_OK;
+  if (!(force && atoi(force) != 0) && in->batch <= h->sched_slots) return DIRECT_OK;
+  const int B = in->batch, nm = h->nmax;
+  std::vector<int32_t> sl(B);
+  if (on_host) {
+    for (int b = 0; b < B; b++) {
+      int pm = 1;
+      for (int k = 0; k < in->n_seg[b]; k++) pm = std::max(pm, (int)in->n_planes[(size_t)b * nm + k]);
+      sl[b] = (6 * std::min(pm, h->pmax) + 55 + 63) / 64;
+    }
+  } else {
+    hipLaunchKernelGGL(k_classify, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, nm, h->pmax, in->n_seg, in->n_planes, h->cls_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sl.data(), h->cls_dev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  int cnt[16] = {0};
+  for (int b = 0; b < B; b++) {
+    sl[b] = rpl_class(sl[b]);
+    cnt[sl[b]]++;
+  }
+  int n_cls = 0;
+  for (int r = 0; r < 16; r++) n_cls += cnt[r] > 0;
+  if (n_cls == 1 && cnt[h->rpl] == B) return DIRECT_OK;  // everything on the handle's own class: identity order
+  std::vector<int32_t> order(B);
+  int off[16];
+  for (int r = 0, o = 0; r < 16; r++) {
+    off[r] = o;
+    if (cnt[r] > 0) h->classes.push_back(direct_ddp_handle_s::Cls{r, o, cnt[r]});
+    o += cnt[r];
+  }
+  for (int b = 0; b < B; b++) order[off[sl[b]]++] = b;  // stable: ascending trajectory numbers inside a class
+  HIP_TRY(hipMemcpyAsync(h->order, order.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));  // `order` is a local
   return DIRECT_OK;
 }
 
@@ -735,6 +914,10 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
   if (!in->infeas_in) {
     HIP_TRY(hipMemsetAsync(h->infeas_in, p->infeas ? 1 : 0, B, h->stream));
     d.infeas_in = h->infeas_in;
+  }
+  if (fresh) {  // (phase 1 of a plan keeps phase 0's classes: the same polytopes)
+    h->B = in->batch;
+    TRY(classify_batch(h, in->mem == DIRECT_MEM_HOST ? in : &d, in->mem == DIRECT_MEM_HOST));
   }
   // the scheduler-error flag is sticky within one API call (both phases of a plan) and cleared between calls
   if (fresh) HIP_TRY(hipMemsetAsync(h->sched + 1, 0, sizeof(int), h->stream));

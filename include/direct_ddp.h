@@ -41,7 +41,7 @@ extern "C" {
 
 #define DIRECT_NX 9   /* dim*sys_order, ddp_optimizer.cpp:37-39 */
 #define DIRECT_NU 10  /* dim*sys_order+1 (c3,c4,c5 per axis + T), ddp_optimizer.cpp:126 */
-#define DIRECT_P_LIMIT 76 /* largest planes-per-polytope the kernels are built for (6 P + 55 rows in eight row slots per lane) */
+#define DIRECT_P_LIMIT 128 /* largest planes-per-polytope the kernels are built for: what polyhedronGenerator can emit (poly_utils.hpp: 128-plane capacity); 6 P + 55 rows in up to fourteen row slots per lane */
 
 typedef enum {
   DIRECT_OK = 0,

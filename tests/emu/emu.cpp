@@ -42,7 +42,10 @@ static void dispatch_c(Emu<Real>& E, F f) {
   else if (E.rpl == 5) for_each_wave<Cmp, Real, 5>(E, f);
   else if (E.rpl == 6) for_each_wave<Cmp, Real, 6>(E, f);
   else if (E.rpl == 7) for_each_wave<Cmp, Real, 7>(E, f);
-  else for_each_wave<Cmp, Real, 8>(E, f);
+  else if (E.rpl == 8) for_each_wave<Cmp, Real, 8>(E, f);
+  else if (E.rpl <= 10) for_each_wave<Cmp, Real, 10>(E, f);
+  else if (E.rpl <= 12) for_each_wave<Cmp, Real, 12>(E, f);
+  else for_each_wave<Cmp, Real, 14>(E, f);
 }
 template <typename Real, typename F>
 static void dispatch(Emu<Real>& E, F f) {

@@ -131,9 +131,9 @@ def test_row_dealing_reciprocal_table_is_exact():
     """kInvP of csrc/ddp_tables.h replaces r / P in the row -> (control point, plane) dealing."""
     import re
     txt = open(os.path.join(ROOT, "direct_amd", "csrc", "ddp_tables.h")).read()
-    body = re.search(r"kInvP\[77\]\s*=\s*\{([^}]*)\}", txt).group(1)
+    body = re.search(r"kInvP\[141\]\s*=\s*\{([^}]*)\}", txt).group(1)
     tab = [int(t) for t in body.replace("\n", " ").split(",")]
-    assert len(tab) == 77
-    for P in range(1, 77):
-        for r in range(860):
-            assert (r * tab[P]) >> 16 == r // P
+    assert len(tab) == 141 and "kInvPShift = 20" in txt
+    for P in range(1, 141):
+        for r in range(900):
+            assert (r * tab[P]) >> 20 == r // P and r * tab[P] < 2 ** 32

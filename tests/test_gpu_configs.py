@@ -3,18 +3,22 @@ arrays: on-device validation of n_seg / n_planes, the sticky scheduler-error fla
 through the library's C entry points (direct_ddp_gather_best over RCCL, world size 1 on this box).
 
 Config 4: B = 16384, N = 300, double storage, config-3 generator.
-Config 5: 131072 corridors over 8 GPUs = 16384 per GPU, N = 100, float storage; one shard is solved here.
+Config 5: 131072 corridors over 8 GPUs = 16384 per GPU, N = 100, float storage; one shard through the device-resident
+interface and the C gather, then ALL EIGHT shards one after another on this one device.
 The oracle cannot solve these batches in seconds: parity is exact agreement on a sample plus the
 size-independent properties of tests/test_gpu_fullsize.py on the whole batch."""
+import os
+
 import numpy as np
 import pytest
 
 from direct_amd import abi, devmem, distributed, problems, solver
 from oracle import refapi
-from tests import helpers
+from tests import helpers, n100_lib
 from tests.test_gpu_fullsize import check_properties
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _torch():
@@ -33,13 +37,23 @@ def test_config4_long_horizon_fp64(built, monkeypatch):
     assert s.sched_error() == 0
     check_properties(batch, g1, 1e-9)
     assert set(np.unique(g1.rtn)) <= {0, 1, -3, -4}
-    # exact agreement with the oracle on a sample (both phases, every discrete decision)
-    idx = np.array([5, 8191, 16383])
-    r0, r1 = refapi.plan_batch(p0, p1, batch.select(idx))
-    assert (g0.rtn[idx] == r0.rtn).all() and (g0.iter_used[idx] == r0.iter_used).all()
-    assert (g1.rtn[idx] == r1.rtn).all() and (g1.iter_used[idx] == r1.iter_used).all()
-    assert np.abs(g1.cost[idx] / r1.cost - 1).max() < 1e-5   # Bezier vs monomial hand-off between the phases
-    assert helpers.rel(g1.T[idx], r1.T) < 1e-3
+    # agreement with the oracle on 16 problems spread over the batch (both phases, every discrete decision), next to
+    # the oracle against ITSELF with its inputs moved by one ulp (N = 300: three times the knots to amplify a bit)
+    idx = np.arange(5, B, B // 16)[:16]
+    sb = batch.select(idx)
+    r0, r1 = refapi.plan_batch(p0, p1, sb)
+    from tests import soak_lib
+    c0, c1 = refapi.plan_batch(p0, p1, soak_lib.perturb_ulp(sb, 4))
+    same0 = (g0.rtn[idx] == r0.rtn) & (g0.iter_used[idx] == r0.iter_used)
+    same1 = (g1.rtn[idx] == r1.rtn) & (g1.iter_used[idx] == r1.iter_used)
+    ctl0 = (c0.rtn == r0.rtn) & (c0.iter_used == r0.iter_used)
+    ctl1 = (c1.rtn == r1.rtn) & (c1.iter_used == r1.iter_used)
+    assert same0.sum() >= ctl0.sum() - 1 and same0.sum() >= 14, (same0, ctl0)
+    assert same1.sum() >= ctl1.sum() - 1 and same1.sum() >= 13, (same1, ctl1)
+    ok = same0 & same1 & (r1.rtn >= 0)
+    assert ok.sum() >= 8
+    assert np.abs(g1.cost[idx][ok] / r1.cost[ok] - 1).max() < 1e-5   # Bezier vs monomial hand-off between the phases
+    assert helpers.rel(g1.T[idx][ok], r1.T[ok]) < 1e-3
     s.close()
     # the ticket scheduler at N = 300 (3x longer chunks against the spin limit): bitwise equal to the static launch
     sub = batch.select(np.arange(4096))
@@ -96,6 +110,118 @@ def test_config5_shard_fp32_and_c_abi_gather(built):
     assert ni == -1 and nown == -1 and np.isinf(nc_) and not nb.any()
     s.rccl_comm_destroy(comm)
     s.close()
+
+
+def test_config5_whole_workload_on_one_gpu(built):
+    """BASELINE config 5 in full: all eight 16384-corridor shards of the 131072-corridor stream, generated and solved one
+    after another on this one device (what ranks 0 .. 7 of an 8-GPU node would each do with theirs), reduced with the
+    tie rule of the collective.  (a) the size-independent properties on all 131072 results; (b) the winner is the argmin
+    over ALL costs (ties: smaller global index), and direct_ddp_gather_best fed the eight local bests - the records the
+    eight ranks would contribute - picks that same winner; (c) a sample of every shard against the oracle."""
+    B, N, G = 16384, 100, 8
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    s = solver.DdpSolver(B, N, 12, np.float32)
+    loc = []           # per shard: (local index, cost) of its best, its block
+    all_cost, all_rtn = [], []
+    n_same, n_checked, devs, cdevs = 0, 0, [], []
+    for g in range(G):
+        first = g * B
+        batch = problems.make_batch("corridor", B, N, seed=1000, first=first, dtype=np.float32)
+        g0, g1 = s.plan(p0, p1, batch)
+        assert s.sched_error() == 0
+        check_properties(batch, g1, 5e-4)                       # (a)
+        li, lc = distributed.local_best(g1.cost, g1.rtn)
+        assert li >= 0
+        loc.append((first + li, lc, g1.bez[li].copy(), g1.T[li].copy()))
+        all_cost.append(g1.cost.astype(np.float64))
+        all_rtn.append(g1.rtn.copy())
+        # (c) three problems of the shard against the oracle on the same float-rounded inputs, fused two-phase plan of
+        # both (float storage: SURVEY.md 8(c)'s fp32 tolerances; the N = 100 samples with their controls: test_gpu_n100.py)
+        idx = np.array([17, B // 2 + 5, B - 3])
+        sb = batch.select(idx).astype(np.float64)
+        r0, r1 = refapi.plan_batch(p0, p1, sb)
+        assert ((g0.rtn[idx] >= 0) == (r0.rtn >= 0)).all()
+        same = (g1.rtn[idx] == r1.rtn) & (r1.rtn >= 0)
+        n_same += int(same.sum())
+        n_checked += 3
+        devs += list(np.abs(g1.cost[idx][same] / r1.cost[same] - 1))
+        # the control: the oracle against itself, every input moved by -1 / 0 / +1 ulp of a float
+        _, q1 = refapi.plan_batch(p0, p1, n100_lib.perturb_float_ulp(sb, 100 + g))
+        cs = (q1.rtn == r1.rtn) & (r1.rtn >= 0)
+        cdevs += list(np.abs(q1.cost[cs] / r1.cost[cs] - 1))
+    devs, cdevs = np.array(devs), np.array(cdevs)
+    # float storage at N = 100: SURVEY.md 8(c)'s 1e-3 for the bulk; the tail is the problems the 100 iterations do not
+    # converge, and how far those may end apart is what the control measures on these very problems
+    assert n_same >= n_checked - 2 and np.median(devs) < 1e-5, (n_same, n_checked, np.sort(devs)[::-1][:5])
+    assert (devs < 1e-3).mean() >= (cdevs < 1e-3).mean() - 0.1 and devs.max() <= max(1e-3, 5 * cdevs.max()), (np.sort(devs)[::-1][:5], np.sort(cdevs)[::-1][:5])
+    cost, rtn = np.concatenate(all_cost), np.concatenate(all_rtn)
+    wi, wc = distributed.local_best(cost, rtn)                  # argmin over all 131072, ties to the smaller index
+    key = [(c, i) for i, c, _, _ in loc]
+    wg = int(np.lexsort(([k[1] for k in key], [k[0] for k in key]))[0])   # the reduction the ranks perform on their records
+    assert loc[wg][0] == wi and loc[wg][1] == wc
+    # (b) the same reduction through the library's C entry point: the eight records as a batch of eight
+    comm = s.rccl_comm_create(s.rccl_unique_id(), 1, 0)
+    lc8 = np.array([c for _, c, _, _ in loc], np.float32)
+    bez8 = np.stack([b for _, _, b, _ in loc]).astype(np.float32)
+    T8 = np.stack([t for _, _, _, t in loc]).astype(np.float32)
+    gi, gc, owner, gb, gT = s.gather_best(comm, 1, 0, lc8, np.zeros(G, np.int32), bez8, T8, 0)
+    s.rccl_comm_destroy(comm)
+    s.close()
+    assert gi == wg and gc == float(np.float32(wc))
+    assert np.array_equal(gb, loc[wg][2]) and np.array_equal(gT, loc[wg][3])
+
+
+def _two_rank_worker(rank, world, port, total, n_seg, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.is_available()   # torch's HIP runtime first (see conftest.py)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from direct_amd import abi as abi_, distributed as distributed_, problems as problems_, solver as solver_
+    first, count = distributed_.shard_range(total, rank, world)
+    batch = problems_.make_batch("corridor", count, n_seg, seed=77, first=first)
+    s = solver_.DdpSolver(count, n_seg, batch.p_max, np.float64, device=0)   # both ranks on the one device of this box
+    g0, g1 = s.plan(abi_.phase0_params(), abi_.phase1_params(), batch)
+    s.close()
+    i, c = distributed_.local_best(g1.cost, g1.rtn)
+    block = torch.from_numpy(np.concatenate([g1.bez[i].ravel(), g1.T[i].ravel()]))
+    cost, gidx, owner, blk = distributed_.gather_best(c, first + i, block)
+    q.put((rank, cost, gidx, owner, blk.numpy().copy(), first, count, g1.cost.copy(), g1.rtn.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_solve_gather_through_the_product_library(built):
+    """World size 2 through libdirect_ddp.so: two processes (both on this box's one device; RCCL refuses two ranks on
+    one GPU, so the exchange runs over gloo) shard the stream, solve their shard on the device and run the config-5
+    gather; both learn the winner a single process finds on the whole batch.  tests/test_dist_gloo.py does the same
+    without a GPU (the oracle in the device's place)."""
+    _torch()
+    import torch.multiprocessing as mp
+    total, n_seg, world = 2 * problems.CHUNK, 12, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, total, n_seg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    full = problems.make_batch("corridor", total, n_seg, seed=77)
+    s = solver.DdpSolver(total, n_seg, full.p_max, np.float64)
+    g0, g1 = s.plan(abi.phase0_params(), abi.phase1_params(), full)
+    s.close()
+    i, c = distributed.local_best(g1.cost, g1.rtn)
+    want = np.concatenate([g1.bez[i].ravel(), g1.T[i].ravel()])
+    for rank, cost, gidx, owner, blk, first, count, rc, rr in outs:
+        assert np.array_equal(rc, g1.cost[first:first + count]) and np.array_equal(rr, g1.rtn[first:first + count])   # sharding invariance, bit for bit
+        assert gidx == i and cost == c and owner == i // (total // world)
+        assert np.array_equal(blk, want)
 
 
 def test_device_resident_sizes_are_validated_on_the_device(built):
