@@ -216,10 +216,18 @@ def label_model_line(torch, dev, B, with_cpu):
     return out
 
 
-def corridor_clusters_line(dev):
+L1_PEAK_GBS = 39300.0  # vector L1: 64 B per clock and CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md: 32 KiB L1 per CU, 2.4 GHz)
+
+
+def corridor_clusters_line(dev, with_cpu):
     """SURVEY.md 8(f-4), reported SEPARATELY: seed voxels -> voxel clusters -> polytope planes on the device
     (include/direct_cluster.h; polyhedron_generator + poly_utils.cpp:127-206, 282-389), 64 seeds on a synthetic
-    200 x 200 x 40 map, clusters left on the device, planes back to the host.  Not part of `value`."""
+    200 x 200 x 40 map, clusters left on the device, planes back to the host.  Not part of `value`.
+    roofline: the dominant kernel (k_convex, ray-cast convexity tests: byte gathers from the map and the summed-area
+    table) is bound by the vector L1, not by HBM - its cache-line accesses (TCP_TOTAL_CACHE_ACCESSES x 64 B, newest
+    committed profiles/r*_cluster_pmc.json: static) over its share of this run's kernel time.
+    cpu_baseline: the REFERENCE's own serialConvexTest (oracle/_ref, compiled from cluster_engine_cpu.cpp) inside the
+    restated loops of cluster_server_cpu.cpp, one thread, on a bounded sample of the same seeds."""
     from direct_amd import cluster, problems
     dims = (200, 200, 40)
     grid, seeds = problems.make_voxel_map(dims, seed=7, n_pillars=170, n_boxes=70, n_rings=12)
@@ -227,17 +235,62 @@ def corridor_clusters_line(dev):
     gen = cluster.ClusterGenerator(dims, max_batch=64, cluster_capacity=50000, candidate_capacity=10000, device=dev.index or 0)
     gen.set_map(grid)
     gen.polygon_generation(seeds[:2], fetch_clusters=False)
-    ts, hp, r = [], None, None
+    ts, hp, r, kms = [], None, None, None
     for _ in range(3):
         t = time.perf_counter()
         r = gen.polygon_generation(seeds, 1000, 50, fetch_clusters=False)
+        kms = gen.last_ms()
         hp = gen.hull_planes(0.2, np.array([-20.0, -20.0, 0.0]), batch=len(seeds), plane_capacity=128, vertex_capacity=512)
         ts.append(time.perf_counter() - t)
     gen.close()
-    return {"workload": "64 seeds, 200x200x40 voxel map (1.6 % obstacles)", "ms_per_seed": min(ts) * 1e3 / len(seeds),
-            "wall_ms": min(ts) * 1e3, "cluster_voxels_mean": float(r["cluster_num"].mean()), "planes_mean": float(hp["n_planes"].mean()),
-            "planes_max": int(hp["n_planes"].max()), "seeds_ok": int(((r["rtn"] == 0) & (hp["rtn"] == 0)).sum()),
-            "note": "bit-identical to the reference's CPU path (clusters) / exact facet planes pinned against its quickhull: tests/test_gpu_cluster.py, tests/test_gpu_hull.py"}
+    out = {"workload": "64 seeds, 200x200x40 voxel map (1.6 % obstacles)", "ms_per_seed": min(ts) * 1e3 / len(seeds),
+           "wall_ms": min(ts) * 1e3, "generation_kernels_ms": kms, "cluster_voxels_mean": float(r["cluster_num"].mean()),
+           "planes_mean": float(hp["n_planes"].mean()),
+           "planes_max": int(hp["n_planes"].max()), "seeds_ok": int(((r["rtn"] == 0) & (hp["rtn"] == 0)).sum()),
+           "note": "bit-identical to the reference's CPU path (clusters) / exact facet planes pinned against its quickhull: tests/test_gpu_cluster.py, tests/test_gpu_hull.py"}
+    pmc = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cluster_pmc.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+            pmc["_file"] = os.path.relpath(f, ROOT)
+            break
+        except (OSError, ValueError):
+            continue
+    if pmc is not None and "k_convex" in pmc and "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc["k_convex"] and kms:
+        calls = pmc.get("generation_calls_of_64_seeds", 6)   # tests/soak/cluster_bench.py 64: 6 full calls + a 2-seed warm-up
+        share = 0.72   # k_convex's share of the generation's kernel time: from the newest committed rocprofv3 --stats summary
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cluster_kernel_stats.csv")), reverse=True):
+            try:
+                import csv
+                rows = list(csv.DictReader(open(f)))
+                gen_k = ("k_convex", "k_resolve", "k_compact", "k_inflate", "k_mark", "k_apply", "k_chunk_box", "k_flags_init", "k_sat_scan", "k_emit")
+                tot = sum(float(q["TotalDurationNs"]) for q in rows if any(n in q["Name"] for n in gen_k))
+                cv = sum(float(q["TotalDurationNs"]) for q in rows if "k_convex" in q["Name"])
+                if tot > 0:
+                    share = cv / tot
+                break
+            except (OSError, ValueError, KeyError):
+                continue
+        byts = pmc["k_convex"]["TCP_TOTAL_CACHE_ACCESSES_sum"] * 64.0 / calls
+        ach = byts / (kms * share * 1e-3) / 1e9
+        out["roofline"] = {"bound": "l1", "kernel": "k_convex", "achieved": ach, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": ach / L1_PEAK_GBS,
+                           "traffic": pmc["k_convex"].get("FETCH_SIZE", 0) * 1024.0 * 2 / calls if "FETCH_SIZE" in pmc["k_convex"] else None,
+                           "traffic_kind": "static: committed PMC profile of tests/soak/cluster_bench.py 64 (L1 accesses and HBM fetch per call), "
+                                           "this run's kernel time", "source": pmc["_file"]}
+    if with_cpu:
+        from oracle import clusterapi as ca
+        ca.use_reference_convex_test(ca.ref_lib() is not None)
+        m = 4
+        t = time.perf_counter()
+        for sd in seeds[:m]:
+            ca.polygon_generation(grid, sd, 1000, 50)
+        cpu_ms = (time.perf_counter() - t) * 1e3 / m
+        kind = "reference" if ca.ref_lib() is not None else "port"
+        ca.use_reference_convex_test(False)
+        out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/seed", "cores": 1, "kind": kind,
+                               "sample": "%d of the 64 seeds: serialConvexTest of polyhedron_generator/src/cluster_engine_cpu.cpp (oracle/_ref) "
+                                         "inside the restated loops of cluster_server_cpu.cpp:257-528, one thread" % m}
+    return out
 
 
 def free_port():
@@ -505,7 +558,7 @@ def main():
     if not args.no_secondary and rank == 0:
         label = label_model_line(torch, dev, B, not args.no_cpu_baseline and world == 1)
         try:
-            clusters = corridor_clusters_line(dev)
+            clusters = corridor_clusters_line(dev, not args.no_cpu_baseline and world == 1)
         except Exception as ex:  # a secondary block never takes the line down
             clusters = {"error": str(ex)[:200]}
 

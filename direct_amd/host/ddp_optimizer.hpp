@@ -114,7 +114,7 @@ class DdpDevice {
 
  private:
   static std::unique_ptr<DdpDevice>& shared_slot() { static std::unique_ptr<DdpDevice> s; return s; }
-  static std::array<int, 5>& shared_cfg() { static std::array<int, 5> c{{1, 128, 32, (int)DIRECT_F64, 0}}  /* up to 32 planes: the four-slot kernels; DIRECT_P_LIMIT (54) takes the six-slot ones */; return c; }
+  static std::array<int, 5>& shared_cfg() { static std::array<int, 5> c{{1, 128, DIRECT_P_LIMIT, (int)DIRECT_F64, 0}}  /* every polytope polyhedronGenerator can emit (128 planes); a knot only pays for the row slots its own polytope fills */; return c; }
   direct_ddp_handle_t h_ = nullptr;
   int max_batch_, n_seg_max_, p_max_;
   direct_dtype_t dtype_;
