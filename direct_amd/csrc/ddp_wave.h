@@ -457,7 +457,7 @@ struct WaveLds {
   // not hoisted into a hundred live registers - which made every knot re-derive them with ~40 integer
   // instructions per phase.  One ds_read_b32 and a few bit-field extracts replace that.
   int lt[8][64];                  // rows 0..3: phase H; 4..6: the three VZ passes of phase R1; 7: phase T2
-  unsigned short lt16[6][64];     // 0: value recursion of phase R2; 1: phase S; 2..4: phase H (operand offsets); 5: phase T1
+  unsigned short lt16[5][64];     // 0: value recursion of phase R2; 1: phase S; 2..4: phase H (operand offsets)
   Real ones[5];           // 1.0: the neutral second factor of phase S's g rows (addressed like a plane component)
   // per knot, both sweeps
   Real tp[8];             // powers of T
@@ -467,7 +467,7 @@ struct WaveLds {
   union {
     struct {  // ---- backward sweep only
       // We = WbE o T-powers for rows 0..17; rows 15..17 are Z = [F|G] itself
-      alignas(16) Real We[108];  // layout we_idx(): [i][row]
+      alignas(16) Real We[112];  // layout we_idx(): [i][row]; [108..111]: dump slot of phase T2's masked stores
       Real dval[48];
       // The condensed 19x19 system, its Cholesky and the value-function recursion are kept in double
       // (Acc) whatever Real is: cu'Dcu with D = s/c and the Vxx update cancel catastrophically in
@@ -925,19 +925,15 @@ struct Wave {
         }
         if (lane < 5) L.ones[lane] = (Real)1;
         if (lane < 5) L.z[19 + lane] = (Real)0;  // read (against zero weights) by phase T2's clamp-free term loop
-        {  // lt16[5]: phase T1 - the exponents of entries e = lane and min(lane + 64, 107) of We, as offsets into tp
-          int ex[2];
-          for (int pass = 0; pass < 2; pass++) {
-            const int e = (lane + 64 * pass < 108) ? lane + 64 * pass : 107;
-            const int x = e % 6 - ctrl_off(e / 6);
-            ex[pass] = x < 0 ? 0 : x;
-          }
-          L.lt16[5][lane] = (unsigned short)((ex[0] * (int)sizeof(Real)) | ((ex[1] * (int)sizeof(Real)) << 6));
-        }
         {  // lt[7]: phase T2 (lane 63 redoes lane 62)
           const int l62 = lane < 63 ? lane : 62;
           const int cr = l62 / 3, d = l62 % 3, o = ctrl_off(cr);
-          L.lt[7][lane] = ((cr * 6 + o) * (int)sizeof(Real)) | (((3 * o + d) * (int)sizeof(Real)) << 10) | (o << 17);
+          // bits 19..28: byte offset of We[cr][o], the first of the 6 - o entries of We this lane ALSO produces (the
+          // products weight x power of T of rows 0..17: phase T2 stores them, there is no separate table phase); bits
+          // 29..31: how many of them the lane stores (axis 0 of rows 0..17 only)
+          const int nst = (d == 0 && cr < 18) ? 6 - o : 0;
+          L.lt[7][lane] = ((cr * 6 + o) * (int)sizeof(Real)) | (((3 * o + d) * (int)sizeof(Real)) << 10) | (o << 17) |
+                          ((we_idx(cr < 18 ? cr : 17, o) * (int)sizeof(Real)) << 19) | (nst << 29);
         }
         for (int pass = 0; pass < 3; pass++) {  // lt[4..6]: the VZ passes of phase R1
           const int e = (lane + 64 * pass < 162) ? lane + 64 * pass : 161;
@@ -1413,28 +1409,15 @@ struct Wave {
     PLA(int, pkn, RPL);  // row descriptors of the prefetched knot / of the knot being processed
     PLA(int, pkc, RPL);
     LANES { prefetch(LV(pre), LV(pkn), 0, lane, buf, N - 1, Pn, false, infeas); }
-    // Phase T1 of a knot with segment time Tx: the powers of T (read by phase H) and We = WbE o T-powers (rows 0..14:
-    // control points, rows 15..17: Z = [F | G]; read by phases R1, H, G).  Neither is read after phase G, and the next
-    // knot's T has been in the prefetch registers for a whole trip by then: the tables of knot k - 1 are built at the
-    // end of knot k's trip, where their two LDS round trips overlap phase R2 instead of opening the next trip.
-    PLV(int, tw_t1);
-    auto t1_tables = [&](Real Tx) {
-      const Real Tx2 = DDP_UNIFORM_R(Tx * Tx), Tx4 = DDP_UNIFORM_R(Tx2 * Tx2);
-      LANES { L.tp[lane & 7] = pow3(Tx, Tx2, Tx4, lane & 7); }
-      WSYNC();  // one wave: the LDS unit executes its instructions in order, the powers are there for the reads below
-      LANES {
-        // We[e] = WbE[e] * T^ex(e): the power comes from the eight-entry table just written (per-lane byte offsets
-        // from lt16[5]) instead of a select chain per entry
-        const int wt = LV(tw_t1);
-        const int e1 = lane + 64 < 108 ? lane + 64 : 107;
-        const Real w0 = L.WbE[lane], w1 = L.WbE[e1];
-        const Real p0 = *byte_at(L.tp, wt & 63), p1 = *byte_at(L.tp, wt >> 6);
-        DDP_LOADS_ISSUED();
-        const int r0 = (lane * 43) >> 8, r1 = (e1 * 43) >> 8;  // row = e / 6 (e < 108)
-        L.We[we_idx(r0, lane - 6 * r0)] = w0 * p0;  // WbE is 0 where the exponent would be negative
-        L.We[we_idx(r1, e1 - 6 * r1)] = w1 * p1;
-      }
-    };
+    // We = WbE o T-powers (rows 0..14: control points, rows 15..17: Z = [F | G]; read by phases R1, H, G) is a by-product
+    // of phase T2, which forms exactly these products on its way to the control values; the entries with a zero weight
+    // (coefficient index below the row's exponent offset) never change: cleared once per sweep (the forward pass uses
+    // the same LDS).
+    LANES {
+      L.We[lane] = (Real)0;
+      if (lane + 64 < 112) L.We[lane + 64] = (Real)0;
+    }
+    WSYNC();
 #pragma unroll 1
     for (int k_ = N - 1; k_ >= 0; k_--) {
       // the knot index is re-materialised every trip: as a visible induction variable it makes loop
@@ -1460,7 +1443,6 @@ struct Wave {
       DDP_MARK("B_L");
       // ---- L: this knot's data from the prefetch registers; issue the loads of the next knot
       LANES {
-        LV(tw_t1) = L.lt16[5][lane];
         LV(tw_t2) = L.lt[7][lane];
         commit(LV(pre), lane, P, false);
         for (int i = 0; i < RPL; i++) {
@@ -1479,10 +1461,6 @@ struct Wave {
         const int same = (Pn == P) ? 1 : 0;
         LANES { prefetch(LV(pre), LV(pkn), same, lane, buf, k - 1, Pn, false, infeas); }
       }
-      DDP_MARK("B_T1");
-      // ---- T1: powers of T, scaled value table, dynamics tables - done at the END of the previous knot's trip
-      // (t1_tables below phase R2), on the critical path of the sweep's first knot only
-      if (k_ == N - 1) t1_tables(T);
       WSYNC();
       DDP_MARK("B_T2");
       // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u (all lanes run all roles, clamped)
@@ -1511,9 +1489,16 @@ struct Wave {
           z6[j] = zb[3 * j];
         }
         DDP_LOADS_ISSUED();
+        // the lane's products weight x power of T ARE entries of We (rows 0..17, axis-0 lanes): stored on the way, the
+        // others go to the dump slot behind the table; the powers of T themselves go to L.tp (read by phase H)
+        Real* const wst = byte_at(L.We, ((unsigned)w2 >> 19) & 1023);
+        const int nst = (int)((unsigned)w2 >> 29);
+        L.tp[lane & 7] = pow3(T, T2, T4, lane & 7);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-          v += (wb6[j] * pw[j]) * z6[j];  // We[cr][i] = WbE * T^j, exactly as phase T1 forms it
+          const Real pj = wb6[j] * pw[j];  // We[cr][o + j]
+          *(j < nst ? wst + 18 * j : &L.We[108]) = pj;
+          v += pj * z6[j];
           dv += wd6[j] * pw[j < 1 ? 0 : j - 1] * z6[j];
           if (j >= 2) ddv += (wd6[j] * (Real)(j - 1)) * pw[j - 2] * z6[j];  // only read for rows 18..20
         }
@@ -2017,10 +2002,6 @@ struct Wave {
             L.Vx[aa] = vnew;
           }
         }
-      }
-      if (k > 0) {  // phase T1 of the next knot (its record arrived a trip ago)
-        const Real Tnx = (sizeof(St) < sizeof(double)) ? (Real)RDLANE_M(pre, zh, 18) + (Real)RDLANE_M(pre, zl, 18) : (Real)RDLANE_M(pre, zh, 18);
-        t1_tables(Tnx);
       }
       WSYNC();
     }

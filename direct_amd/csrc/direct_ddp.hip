@@ -414,10 +414,11 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   k.tol = 1.0e-7;                        // ddp_optimizer.cpp:43
   k.iter_max = p.iter_max; k.time_power = p.time_power; k.zero_init = p.zero_init;
   k.line_init = p.line_init; k.minvo = p.minvo; k.fixed_iters = p.fixed_iters; k.exact_dt = p.exact_dt;
-  // two trials per sweep pay off where the launch is bound by its slowest chain (batch up to twice the resident
-  // waves: +4 % at B = 4096) and cost ~1 % where it is throughput-bound; results are identical either way
+  // two trials per sweep: +8 % where the launch is bound by its slowest chain (B = 4096) and, since the trials share
+  // the old iterate's row values (c, 1 / c: run_round, phase R), +0.7 % where it is throughput-bound (B = 16384; r03: -1 %);
+  // results are identical either way
   const int slots = resident_slots<Real>(h, c.rpl);
-  k.pair_trials = h->pair_trials >= 0 ? h->pair_trials : ((slots > 0 && c.cnt <= 2 * slots) ? 1 : 0);
+  k.pair_trials = h->pair_trials >= 0 ? h->pair_trials : 1;
   // few trajectories on many waves and a shared line search: single steps, one wave each, beat pairs
   if (h->pair_trials < 0 && h->help && h->help_mode != 0 && h->dynamic && h->nmax >= 80 && (long long)c.cnt * h->single_ratio <= (long long)slots)
     k.pair_trials = 0;
