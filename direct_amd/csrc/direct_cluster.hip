@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -46,6 +47,7 @@ struct Elem {  // per-seed counters, device resident
   int vertex[24];
 };
 
+constexpr int kCompactBlocks = 64;  // workgroups per seed of the candidate compaction
 struct Dev {
   int max_x, max_y, max_z, max_yz, G;
   int ccap, kcap, kwords;  // cluster / candidate capacity, 64-bit words per candidate row
@@ -64,6 +66,8 @@ struct Dev {
   unsigned long long* accbits;      // [batch][kwords] accepted candidates of the round (k_resolve_fast -> k_apply)
   int* accpre;                      // [batch][kwords] accepted candidates before word w
   Elem* el;                // [batch]
+  int* ccnt;               // [batch][kCompactBlocks] first-discoverer counts of k_compact_count's ranges
+  int* csnap;              // [batch][2] (live, n_active * 26) as the round's candidate generation saw them
 };
 
 // ---- flags <- map ---------------------------------------------------------------------------------------
@@ -257,17 +261,59 @@ __global__ void k_mark(Dev D) {
     if (id >= 0 && D.flags[(size_t)e * D.G + id] == 0) atomicMin(&D.key[(size_t)e * D.G + id], t);
   }
 }
-__global__ __launch_bounds__(256) void k_compact(Dev D) {
+// Ordered compaction of the first discoverers into the candidate list, kCompactBlocks workgroups per seed (one
+// workgroup walking all n_active x 26 neighbours was 84 us per round, 8 % of the generation): every workgroup owns a
+// contiguous range of the discovery order; k_compact_count counts its first discoverers, k_compact_write places them
+// behind those of the ranges before it.  The Elem is only written by k_compact_write's workgroup 0, and nobody in that
+// kernel reads it (csnap carries what the round started from).
+__device__ __forceinline__ void compact_range(int total, int b, int* lo, int* hi) {
+  const int per = (((total + kCompactBlocks - 1) / kCompactBlocks) + 255) & ~255;
+  *lo = b * per;
+  *hi = *lo + per < total ? *lo + per : total;
+}
+__global__ __launch_bounds__(256) void k_compact_count(Dev D) {
   __shared__ int wsum[4];
-  const int e = blockIdx.x, tid = threadIdx.x;
-  Elem* E = &D.el[e];
-  if (!E->live) return;
-  const int total = E->n_active * 26;
-  int n_out = 0, overflow = 0;
-  for (int base = 0; base < total; base += 256) {
+  const int e = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+  const Elem* E = &D.el[e];
+  const int live = E->live, total = live ? E->n_active * 26 : 0;
+  if (b == 0 && tid == 0) { D.csnap[2 * e] = live; D.csnap[2 * e + 1] = total; }
+  int lo, hi, n = 0;
+  compact_range(total, b, &lo, &hi);
+  for (int base = lo; base < hi; base += 256) {
+    const int t = base + tid;
+    int first = 0, p = 0;
+    if (t < hi) {
+      const int id = neighbour_id(D, D.active[(size_t)e * D.ccap + t / 26], t % 26, &p);
+      first = id >= 0 && D.key[(size_t)e * D.G + id] == t;
+    }
+    n += __popcll(__ballot(first));
+  }
+  if ((tid & 63) == 0) wsum[tid >> 6] = n;
+  __syncthreads();
+  if (tid == 0) D.ccnt[e * kCompactBlocks + b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void k_compact_write(Dev D) {
+  __shared__ int wsum[4];
+  __shared__ int s_off, s_all;
+  const int e = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+  if (!D.csnap[2 * e]) return;
+  const int total = D.csnap[2 * e + 1];
+  if (tid < 64) {  // kCompactBlocks == 64: one count per lane
+    const int c = D.ccnt[e * kCompactBlocks + tid];
+    int before = tid < b ? c : 0, all = c;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+    if (tid == 0) { s_off = before; s_all = all; }
+  }
+  __syncthreads();
+  int n_out = s_off;
+  const int all = s_all;
+  int lo, hi;
+  compact_range(total, b, &lo, &hi);
+  for (int base = lo; base < hi; base += 256) {
     const int t = base + tid;
     int first = 0, p = 0, id = -1;
-    if (t < total) {
+    if (t < hi) {
       id = neighbour_id(D, D.active[(size_t)e * D.ccap + t / 26], t % 26, &p);
       first = id >= 0 && D.key[(size_t)e * D.G + id] == t;
     }
@@ -277,16 +323,16 @@ __global__ __launch_bounds__(256) void k_compact(Dev D) {
       D.key[(size_t)e * D.G + id] = KEY_NONE;
       D.flags[(size_t)e * D.G + id] |= F_USE;  // CS:347
       if (n_out + pos < D.kcap) D.cand[(size_t)e * D.kcap + n_out + pos] = p;
-      else overflow = 1;
     }
     n_out += tot;
     __syncthreads();
   }
-  overflow = __syncthreads_or(overflow);
-  if (tid == 0) {
-    E->n_cand = overflow ? 0 : n_out;
+  if (b == 0 && tid == 0) {
+    Elem* E = &D.el[e];
+    const int overflow = all > D.kcap;
+    E->n_cand = overflow ? 0 : all;
     if (overflow) { E->rtn = DIRECT_CLUSTER_OVERFLOW; E->live = 0; }
-    else if (n_out == 0) E->live = 0;  // CS:356-357
+    else if (all == 0) E->live = 0;  // CS:356-357
   }
 }
 
@@ -423,10 +469,23 @@ __global__ __launch_bounds__(256) void k_chunk_box(Dev D) {
 }
 
 // one workgroup per candidate.  full = 1 (kernel-level parity entry point): no early exit, every row is complete
+__device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, int i, int full);
+// A workgroup takes the candidates blockIdx.x, blockIdx.x + gridDim.x, ... of its seed: the grid is sized for the
+// typical shell (a few thousand candidates), not for the candidate CAPACITY - one workgroup per capacity slot meant
+// 640 k workgroups per round for 64 seeds, nine in ten of which only looked at n_cand and left (44 M wave launches per
+// call, ~10 % of the kernel's time).
 __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
-  const int e = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  const int e = blockIdx.y;
   const Elem* E = &D.el[e];
-  if (!E->live || i >= E->n_cand) return;
+  if (!E->live) return;
+  const int n_cand = E->n_cand;
+  for (int i = blockIdx.x; i < n_cand; i += gridDim.x) {
+    convex_one(D, E, e, i, full);
+    __syncthreads();  // the next candidate reuses the workgroup's LDS
+  }
+}
+__device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, int i, int full) {
+  const int tid = threadIdx.x;
   const uint8_t* fl = D.flags + (size_t)e * D.G;
   const int* cl = D.cluster + (size_t)e * D.ccap;
   const int* cd = D.cand + (size_t)e * D.kcap;
@@ -526,7 +585,16 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
     if (jq >= 0 && ray_walk_lin(D, fl, inv, cx, cy, cz, cd[jq])) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
   }
   __syncthreads();
-  for (int w = tid; w < nw; w += 256) row[w] = srow[w];
+  int nz = 0;
+  for (int w = tid; w < nw; w += 256) {
+    row[w] = srow[w];
+    nz |= srow[w] != 0ull;
+  }
+  // A candidate that sees the cluster AND every earlier candidate joins whatever the accept loop decides about the
+  // others (CS:360-384: it is only ever compared with candidates it cannot see): marked 2, and k_resolve_fast takes it
+  // without a place in its sequential chain - which then only holds the few candidates with a blocked ray
+  nz = __syncthreads_or(nz);
+  if (!full && !nz && tid == 0) D.can_clu[(size_t)e * D.kcap + i] = 2;
 }
 
 // the sequential accept loop (CS:360-384) for one seed: one wave.  dry = 1: only accept[] is written.
@@ -544,7 +612,7 @@ __global__ __launch_bounds__(64) void k_resolve(Dev D, int dry) {
   int* ac = D.active + (size_t)e * D.ccap;
   uint8_t* fl = D.flags + (size_t)e * D.G;
   for (int i = 0; i < n_cand; i++) {
-    int ok = D.can_clu[(size_t)e * D.kcap + i];
+    int ok = D.can_clu[(size_t)e * D.kcap + i] != 0;
     if (ok) {
       const unsigned long long* row = D.blocked + ((size_t)e * D.kcap + i) * D.kwords;
       int hit = 0;
@@ -597,7 +665,7 @@ __global__ __launch_bounds__(64) void k_resolve_pipe(Dev D) {
   uint8_t* fl = D.flags + (size_t)e * D.G;
   constexpr int kW = 4;  // row words per lane held in registers: candidates up to 64 * 64 * kW
   auto load_row = [&](int i, unsigned long long* r, int& okc, int& pc) {
-    okc = cc[i];
+    okc = cc[i] != 0;
     pc = cd[i];
     const unsigned long long* row = D.blocked + ((size_t)e * D.kcap + i) * D.kwords;
     const int nw = (i + 63) / 64;
@@ -735,11 +803,13 @@ __global__ __launch_bounds__(64) void k_resolve_fast(Dev D) {
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const unsigned long long m = __ballot(v[u]);
+      // 1: joins unless an earlier accepted candidate is hidden from it (the sequential chain below); 2: sees everything
+      // before it (k_convex): accepted at once - its bit can stand in acc from the start, rows only hold EARLIER candidates
+      const unsigned long long m = __ballot(v[u] == 1), m2 = __ballot(v[u] == 2);
       const int w = w0 + u;
 #pragma unroll
       for (int q = 0; q < kW; q++)
-        if (q == (w >> 6) && lane == (w & 63)) ccm[q] = m;
+        if (q == (w >> 6) && lane == (w & 63)) { ccm[q] = m; acc[q] = m2; }
     }
   }
   // candidates below 4096 only meet row words below 64 (one per lane), below 8192 two per lane, ...: the narrower the
@@ -852,6 +922,7 @@ struct direct_cluster_handle_s {
   std::vector<void*> allocs;
   HullDev H = {};          // scratch of hull_planes_batch, allocated by its first call
   bool have_hull = false;
+  int convex_grid = 2048;    // workgroups per seed of k_convex (DIRECT_CLUSTER_CONVEX_GRID: experiments)
   int resident_batch = 0;    // seeds of the last polygon_generation_batch whose clusters are still in D.cluster / D.el (0: none)
   void* hull_out = nullptr;  // device staging of its host outputs
   size_t hull_out_bytes = 0;
@@ -880,6 +951,7 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
     return cfail(DIRECT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
   direct_cluster_handle_t h = new direct_cluster_handle_s();
   h->cfg = *cfg;
+  if (const char* ev = getenv("DIRECT_CLUSTER_CONVEX_GRID")) h->convex_grid = atoi(ev) > 0 ? atoi(ev) : h->convex_grid;
   Dev& D = h->D;
   D.max_x = cfg->max_x; D.max_y = cfg->max_y; D.max_z = cfg->max_z; D.max_yz = cfg->max_y * cfg->max_z;
   D.G = cfg->max_x * cfg->max_y * cfg->max_z;
@@ -908,6 +980,7 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
   A(&D.blocked, B * D.kcap * (size_t)D.kwords * sizeof(unsigned long long));
   A(&D.accbits, B * (size_t)D.kwords * sizeof(unsigned long long)); A(&D.accpre, B * (size_t)D.kwords * sizeof(int));
   A(&D.el, B * sizeof(Elem));
+  A(&D.ccnt, B * kCompactBlocks * sizeof(int)); A(&D.csnap, B * 2 * sizeof(int));
   A(&h->st_vertex, B * 24 * 4); A(&h->st_xyz, B * (size_t)D.ccap * 12); A(&h->st_num, B * 4); A(&h->st_iters, B * 4); A(&h->st_rtn, B * 4);
   D.map = h->map;
   if (st == DIRECT_OK) {
@@ -989,13 +1062,14 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
     const int n = std::min(kRoundsPerCheck, itr_cluster_max - round);
     for (int r = 0; r < n; r++) {
       hipLaunchKernelGGL(k_mark, dim3(128, batch), dim3(256), 0, h->stream, D);
-      hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, h->stream, D);
+      hipLaunchKernelGGL(k_compact_count, dim3(kCompactBlocks, batch), dim3(256), 0, h->stream, D);
+      hipLaunchKernelGGL(k_compact_write, dim3(kCompactBlocks, batch), dim3(256), 0, h->stream, D);
       // one workgroup per candidate SLOT: the slots beyond a seed's candidate count return at once (640 k empty
       // workgroups cost ~0.1 ms; a persistent ticket kernel with the rays' voxels staged in LDS was built and measured
       // 1.6 - 2 x slower: thousands of short workgroups balance the seeds' very different loads better, and the flag
       // bytes of a round's rays live in L2 anyway)
       hipLaunchKernelGGL(k_chunk_box, dim3(D.nchunk, batch), dim3(256), 0, h->stream, D);
-      hipLaunchKernelGGL(k_convex, dim3(D.kcap, batch), dim3(256), 0, h->stream, D, 0);
+      hipLaunchKernelGGL(k_convex, dim3(std::min(D.kcap, h->convex_grid), batch), dim3(256), 0, h->stream, D, 0);
       if (D.kwords <= 256) {
         hipLaunchKernelGGL(k_resolve_fast, dim3(batch), dim3(64), 0, h->stream, D);
         hipLaunchKernelGGL(k_apply, dim3((D.kcap + 255) / 256, batch), dim3(256), 0, h->stream, D);
