@@ -26,7 +26,7 @@ for n, c in out.items():
     d = dict(c)
     if 'TCC_HIT_sum' in d: d['l2_hit_rate'] = d['TCC_HIT_sum'] / max(d['TCC_HIT_sum'] + d.get('TCC_MISS_sum', 0), 1)
     res[n] = d
-res['note'] = 'sums over the 7 polygon_generation / hull calls of tests/soak/cluster_bench.py 64 (1 warm-up of 2 seeds + 6 of 64 seeds); FETCH_SIZE / WRITE_SIZE in kB as reported (see profiles/r03_hbm_calib.json for the factors)'
+res['note'] = 'sums over the 7 polygon_generation / hull calls of tests/soak/cluster_bench.py 64 (1 warm-up of 2 seeds + 6 of 64 seeds); FETCH_SIZE / WRITE_SIZE in kB as reported (see the newest profiles/r*_hbm_calib.json for the factors)'
 json.dump(res, open('$ROOT/gpurun_out/${R}_cluster_pmc.json', 'w'), indent=1)
 print(json.dumps(res)[:1500])
 PY

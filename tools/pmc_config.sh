@@ -15,5 +15,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_cfg/p$i -o pmc -- python $ROOT/tools/prof_one.py "$@" > $OUT/${TAG}_pmc_run$i.log 2>&1
 done
-cp $ROOT/profiles/r02_hbm_calib.json $OUT/${TAG}_hbm_calib.json 2>/dev/null
+cp $(ls $ROOT/profiles/r*_hbm_calib.json | sort | tail -1) $OUT/${TAG}_hbm_calib.json 2>/dev/null
 python $ROOT/tools/pmc_collect.py /tmp/pmc_cfg $OUT/${TAG} "$@"
