@@ -108,7 +108,7 @@ def test_create_rejects_bad_configs(built):
     h = C.c_void_p()
     for cfg, want in ((abi.Config(5, 0, 4, 4, 6, 0), abi.DIRECT_ERR_INVALID),
                       (abi.Config(abi.F32, 0, 0, 4, 6, 0), abi.DIRECT_ERR_INVALID),
-                      (abi.Config(abi.F32, 0, 4, 4, 99, 0), abi.DIRECT_ERR_UNSUPPORTED)):
+                      (abi.Config(abi.F32, 0, 4, 4, abi.P_LIMIT + 1, 0), abi.DIRECT_ERR_UNSUPPORTED)):
         assert lib.direct_ddp_create(C.addressof(cfg), C.addressof(h)) == want
         assert len(lib.direct_ddp_last_error()) > 0
 
