@@ -1407,3 +1407,26 @@ direct_status_t direct_traj_sample_last_ms(direct_ddp_handle_t h, float* ms) {
 }
 
 }  // extern "C"
+
+#if defined(DDP_SPLIT_PROBE)  // register-budget probe (tools only): the two sweeps as kernels of their own at four waves per SIMD
+template <typename St, int RPL>
+__global__ __launch_bounds__(64, 4) void k_probe_bwd(Batch<St> B) {
+  __shared__ WaveLds<Cmp, St, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
+  W.load_state();
+  W.init_tables();
+  W.bwd_sweep();
+  W.store_state();
+}
+template <typename St, int RPL>
+__global__ __launch_bounds__(64, 4) void k_probe_fwd(Batch<St> B) {
+  __shared__ WaveLds<Cmp, St, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, blockIdx.x);
+  W.load_state();
+  W.init_tables();
+  W.fwd_pass();
+  W.store_state();
+}
+template __global__ void k_probe_bwd<float, 2>(Batch<float>);
+template __global__ void k_probe_fwd<float, 2>(Batch<float>);
+#endif
