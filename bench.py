@@ -103,7 +103,7 @@ def matching_profile(pattern, workload):
     return None
 
 
-def live_hbm_traffic(workload, timeout_s=240):
+def live_hbm_traffic(workload, timeout_s=150):
     """HBM bytes of ONE timed launch from the PMC counters, measured NOW on this box: two separate rocprofv3 passes
     (FETCH_SIZE and WRITE_SIZE cannot share one) over tools/prof_one.py, which runs this very workload (phase 0, then the
     fixed-iteration phase-1 launch: the LAST k_iterate* dispatch of the process, checked against the HIP-event time the

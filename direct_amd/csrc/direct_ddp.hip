@@ -830,15 +830,17 @@ __global__ void k_classify(int B, int nmax, int pmax, const int32_t* n_seg, cons
 // (host-memory inputs) or device arrays (one small read-back).
 static direct_status_t classify_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t* in, bool on_host) {
   h->classes.clear();
-  // Classes buy OCCUPANCY (three waves per SIMD instead of one for the trajectories whose polytopes allow it), which only
-  // matters when the batch does not fit the resident waves of the handle's own class anyway.  A batch that does is bound
-  // by the chain of its longest solve, and a lone wave runs FASTER on the wide kernels (one wave per SIMD: up to 512
-  // registers, no spills; the row slots a knot does not need are skipped at run time): 710 real-corridor plans, 36 ms on
-  // the one class of their widest polytope against 65 ms spread over six classes (profiles/r04_real_corridors.json).
-  // DIRECT_DDP_CLASSES=0 | 1 forces either way.
+  // Classes would buy OCCUPANCY (three waves per SIMD instead of one for the trajectories whose polytopes allow it) - but
+  // every class launch is bound by the chain of ITS longest solve, and the class launches, each a grid of persistent
+  // waves sized for the whole device, end up one after the other.  Measured on real-corridor replay plans (N <= 21, widest
+  // polytope per plan 12 .. 59 planes, six classes; profiles/r04_real_corridors.json): 710 plans 36 ms on the
+  // one class of the widest polytope against 65 ms in classes; 5680 plans (5.5 x the resident waves of that class)
+  // 38.5 against 68.7 ms.  What pays is skipping, per knot, the row slots its polytope does not fill (ddp_wave.h,
+  // slot_on) on the wide kernels.  So ONE class is the default; DIRECT_DDP_CLASSES=1 sorts the batch into classes
+  // (bit-identical results: tests/test_gpu_real_corridors.py), for workloads of long trajectories far beyond the
+  // resident waves, which none of the measured ones is.
   const char* force = getenv("DIRECT_DDP_CLASSES");
-  if (h->rpl <= 2 || getenv("DIRECT_DDP_ONE_CLASS") || (force && atoi(force) == 0)) return DIRECT_OK;
-  if (!(force && atoi(force) != 0) && in->batch <= h->sched_slots) return DIRECT_OK;
+  if (h->rpl <= 2 || !(force && atoi(force) != 0)) return DIRECT_OK;
   const int B = in->batch, nm = h->nmax;
   std::vector<int32_t> sl(B);
   if (on_host) {

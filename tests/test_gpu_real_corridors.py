@@ -3,7 +3,7 @@
 (teach_repeat_planner.cpp:316-320: the first n polytopes, n = 2 ..) -> ONE ragged batch of ~700 two-phase plans with
 N <= 21 segments and 6 .. 60 planes per polytope, run by the kernels of the widest polytope with the row slots a knot
 does not need skipped at run time (ddp_wave.h, slot_on); the row-slot CLASSES (direct_ddp.hip, classify_batch: a plan on
-the kernels of its OWN widest polytope, what a batch beyond the resident waves gets) are forced on for the comparison.
+the kernels of its OWN widest polytope; opt-in) are forced on for the comparison.
 
 Checked: both phases of 96 plans spread over the batch against the oracle (identical return codes and iteration
 counts, cost 1e-6), both storage types; the class dispatch against the single-class dispatch bit for bit; containment
