@@ -176,3 +176,49 @@ def test_corridor_generation_walk_and_ddp(built, tmp_path):
     s.close()
     assert (g1.rtn >= 0).any()
     assert (d["cmax"][g1.rtn >= 0] < 1e-6).all()       # solved trajectories stay inside their polytopes
+
+
+def test_hull_input_guards(built):
+    """(a) a caller-provided voxel outside the map disqualifies ITS cluster (DIRECT_HULL_BAD_VOXEL) instead of
+    addressing lattice lines outside the per-cluster arrays, the other clusters of the call are unaffected; (b) the
+    resident-cluster form needs a generation of at least `batch` seeds, and caller-provided voxels - which are packed
+    into the handle's cluster storage - retire the resident clusters; (c) a generation that overflowed the cluster
+    capacity in a clustering round keeps the valid PREFIX of the cluster (every returned voxel is a map voxel of the
+    oracle's cluster, in its order) and its hull is refused (DIRECT_HULL_OVERFLOW) rather than computed on slots that
+    were never written."""
+    from direct_amd.solver import DirectError
+    grid, seeds = problems.make_voxel_map()
+    gen = cluster.ClusterGenerator(grid.shape, max_batch=8, cluster_capacity=20000, candidate_capacity=4000)
+    gen.set_map(grid)
+    r = gen.polygon_generation(seeds[:3])
+    assert (r["rtn"] == cluster.CLUSTER_OK).all()
+    good = gen.hull_planes(RES, LOWER, batch=3)
+    assert (good["rtn"] == cluster.HULL_OK).all()
+    # (b) more clusters than the last generation produced
+    with pytest.raises(DirectError) as e:
+        gen.hull_planes(RES, LOWER, batch=4)
+    assert e.value.status == abi.DIRECT_ERR_INVALID
+    # (a) one voxel of cluster 1 outside the map, in every direction the packing could alias
+    for badv in ([-1, 3, 3], [grid.shape[0], 2, 2], [3, 3, 1024 + 5], [2, grid.shape[1] + 7, 1]):
+        cl = [c.copy() for c in r["clusters"]]
+        cl[1][len(cl[1]) // 2] = badv
+        h = gen.hull_planes(RES, LOWER, clusters=cl)
+        assert h["rtn"][1] == cluster.HULL_BAD_VOXEL and h["n_planes"][1] == 0
+        for b in (0, 2):
+            assert h["rtn"][b] == cluster.HULL_OK and np.array_equal(h["planes"][b], good["planes"][b])
+    # (b) the caller's voxels replaced the resident clusters: a resident call needs a new generation
+    with pytest.raises(DirectError):
+        gen.hull_planes(RES, LOWER, batch=3)
+    gen.close()
+    # (c) overflow in a clustering round: capacity just above the inflated cube's surface
+    _, cl_full, _, _ = clusterapi.polygon_generation(grid, tuple(int(v) for v in seeds[0]))
+    gen = cluster.ClusterGenerator(grid.shape, max_batch=2, cluster_capacity=len(cl_full) - 5, candidate_capacity=4000)
+    gen.set_map(grid)
+    ro = gen.polygon_generation(seeds[:1])
+    assert ro["rtn"][0] == cluster.CLUSTER_OVERFLOW
+    n = int(ro["cluster_num"][0])
+    assert 0 < n <= len(cl_full) - 5
+    assert np.array_equal(ro["clusters"][0], cl_full[:n])          # a valid prefix, never stale storage
+    ho = gen.hull_planes(RES, LOWER, batch=1)
+    assert ho["rtn"][0] == cluster.HULL_OVERFLOW and ho["n_planes"][0] == 0
+    gen.close()
