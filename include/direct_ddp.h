@@ -286,8 +286,10 @@ typedef enum {
   DIRECT_FIELD_C = 4,      /* [b][n_seg_max][nc_max] (recomputed from x,u on read) */
   DIRECT_FIELD_KU = 5,     /* [b][n_seg_max][10] */
   DIRECT_FIELD_KUU = 6,    /* [b][n_seg_max][10][9] */
-  DIRECT_FIELD_KS = 7,     /* [b][n_seg_max][nc_max] */
-  DIRECT_FIELD_KY = 8,     /* [b][n_seg_max][nc_max]; infeasible mode only (feasible mode: scratch, c of the iterate) */
+  DIRECT_FIELD_KS = 7,     /* [b][n_seg_max][nc_max]; the slack / dual gains ks, ky (ddp_optimizer.cpp:568-571, 611) are formed ONLY by
+                              direct_ddp_backward_pass: valid after that call, not after direct_ddp_iterate / solve_batch / plan_batch,
+                              whose forward passes step s and y without them */
+  DIRECT_FIELD_KY = 8,     /* [b][n_seg_max][nc_max]; infeasible mode only; see DIRECT_FIELD_KS */
   DIRECT_FIELD_SCALARS = 9 /* [b][16]: cost,costq,logcost,err,mu,reg,opterr,stepsize,
                               step,fp_failed,bp_failed,rtn,iter,done,filter_n,infeas */
 } direct_field_t;

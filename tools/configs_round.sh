@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench lines of the other single-GPU configurations + the cluster bench of a round (run through gpurun from the repo root):
 #   gpurun_out/rNN_configs.json, rNN_cluster_bench.json, rNN_cluster_kernel_stats.csv   usage: tools/configs_round.sh r03
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd $ROOT; export PYTHONPATH=$ROOT
