@@ -14,7 +14,8 @@
 // rounded recurrence, not by ceil(1/step).  The recurrence drifts from k*step by at most k ulp, so when
 // no k*step lies within that margin of 1.0 the count follows from a multiplication (fast path, sample
 // times k*step); otherwise the segment replays the exact recurrence (lane l performs the l sequential
-// additions).  The kernel streams (bez, T) in and 9 words per sample out: it is HBM-write bound.
+// additions).  The kernel streams (bez, T) in and 9 words per sample out: it is HBM-write bound by design;
+// the evaluation itself is 36 fused multiply-adds per sample (monomial form, see below).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -109,6 +110,31 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
       nfast = 1;
     }
     const double invT = 1.0 / Ti;
+    // The segment's three Bernstein polynomials in the monomial basis, once per segment: with D_i the i-th forward
+    // difference of the control points at 0, the degree-5 position polynomial is sum_i C(5,i) D_i t^i, the reference's
+    // velocity polynomial (control points 5 (c_j+1 - c_j), degree 4) is sum_i 5 C(4,i) D_i+1 t^i and its acceleration
+    // polynomial (control points 20 (c_j+2 - 2 c_j+1 + c_j), degree 3) is sum_i 20 C(3,i) D_i+2 t^i - ONE difference
+    // table (15 subtractions per axis) serves all three, and a sample is 5 + 4 + 3 fused multiply-adds per axis (Horner on
+    // t in [0, 1]) plus twelve products of t instead of 15 basis products and ~100 multiply-adds.  The kernel was bound by exactly that arithmetic
+    // (480 VALU instructions per chunk of 64 samples, 39 % of the HBM roofline).  Against the reference's Bernstein
+    // sums this differs at rounding level (measured < 1e-13 of the largest value; the parity tests ask for 1e-12).
+    // Only the difference table is kept per segment (18 doubles): the binomial factors ride on the sample's t
+    // (s_k = D_k + (C_k+1 / C_k) t s_k+1, value = C_0 s_0), so the kernel stays below 128 VGPRs (four waves per SIMD).
+    double D[3][6];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      double w[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) w[j] = cf[d * 6 + j];
+      D[d][0] = w[0];
+#pragma unroll
+      for (int lvl = 1; lvl < 6; lvl++) {
+#pragma unroll
+        for (int j = 0; j + lvl < 6; j++) w[j] = w[j + 1] - w[j];
+        D[d][lvl] = w[0];
+      }
+    }
+    const double vs = 5.0, as = 20.0 * invT;
     double t_carry = 0.0;
     int kbase = 0;
     while (true) {
@@ -124,31 +150,28 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
         valid = t < 1.0;
       }
       const int n = __popcll(__ballot(valid));
-      const double u = 1.0 - t;
-      double tp[6], up[6];
-      tp[0] = 1.0; up[0] = 1.0;
-#pragma unroll
-      for (int j = 1; j < 6; j++) { tp[j] = tp[j - 1] * t; up[j] = up[j - 1] * u; }
-      const double C5[6] = {1, 5, 10, 10, 5, 1}, C4[5] = {1, 4, 6, 4, 1}, C3[4] = {1, 3, 3, 1};
+      // t times the ratios of consecutive binomials: C(5,.) = 1 5 10 10 5 1, C(4,.) = 1 4 6 4 1, C(3,.) = 1 3 3 1
+      const double p5[5] = {5.0 * t, 2.0 * t, t, 0.5 * t, 0.2 * t};
+      const double p4[4] = {4.0 * t, 1.5 * t, (2.0 / 3.0) * t, 0.25 * t};
+      const double p3[3] = {3.0 * t, t, (1.0 / 3.0) * t};
       double p[3], v[3] = {0, 0, 0}, a[3] = {0, 0, 0};
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-        double r = 0.0;
+        double r = D[d][5];
 #pragma unroll
-        for (int j = 0; j < 6; j++) r += C5[j] * cf[d * 6 + j] * tp[j] * up[5 - j];
+        for (int q = 4; q >= 0; q--) r = fma(r, p5[q], D[d][q]);
         p[d] = Ti * r;
         if (A.derivs >= 1) {
-          double rv = 0.0;
+          double rv = D[d][5];
 #pragma unroll
-          for (int j = 0; j < 5; j++) rv += C4[j] * 5.0 * (cf[d * 6 + j + 1] - cf[d * 6 + j]) * tp[j] * up[4 - j];
-          v[d] = rv;
+          for (int q = 3; q >= 0; q--) rv = fma(rv, p4[q], D[d][q + 1]);
+          v[d] = vs * rv;
         }
         if (A.derivs >= 2) {
-          double ra = 0.0;
+          double ra = D[d][5];
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            ra += C3[j] * 5.0 * 4.0 * (cf[d * 6 + j + 2] - 2.0 * cf[d * 6 + j + 1] + cf[d * 6 + j]) * tp[j] * up[3 - j];
-          a[d] = ra * invT;
+          for (int q = 2; q >= 0; q--) ra = fma(ra, p3[q], D[d][q + 2]);
+          a[d] = as * ra;
         }
       }
       // distance to the previous sample (lane - 1, or the carried point for lane 0)
@@ -157,8 +180,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
       const double dx = qx - p[0], dy = qy - p[1], dz = qz - p[2];
       double dist = sqrt(dx * dx + dy * dy + dz * dz);
       if (!valid || (base == 0 && lane == 0)) dist = 0.0;  // the first point of the trajectory has no predecessor
-      for (int o = 32; o > 0; o >>= 1) dist += __shfl_xor(dist, o, 64);
-      len += dist;
+      len += wave_sum_d(dist);  // DPP reduction on the VALU (ddp_wave.h): six shuffles through the LDS pipe otherwise
       const int idx = base + lane;
       if (audit && valid) {  // the planes of a segment are the same for every lane: broadcast loads
         const int np = min(max(A.n_planes[(size_t)b * A.nmax + i], 0), A.pmax);
