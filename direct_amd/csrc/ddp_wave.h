@@ -47,7 +47,12 @@ inline T emu_uniform(T x, int line) {
 }
 #define DDP_DEV inline
 #define DDP_DEV_NOINLINE inline
+#if defined(DDP_EMU_TRACE)  // tools/lds_trace: the tracer is told the lane by a call the optimiser cannot move
+extern "C" int ddp_emu_set_lane(int);
+#define LANES for (int lane = (direct::emu_lane() = 0, ddp_emu_set_lane(0)); lane < 64; direct::emu_lane() = ++lane, ddp_emu_set_lane(lane))
+#else
 #define LANES for (int lane = (direct::emu_lane() = 0); lane < 64; direct::emu_lane() = ++lane)
+#endif
 // LANES_AGAIN(l): a further per-lane block of a phase whose lane index l was declared with DDP_LANE_DECL
 #define LANES_AGAIN(l) LANES
 #define DDP_LANE_DECL(l) const int l = 0; (void)l
@@ -77,7 +82,13 @@ inline T emu_uniform(T x, int line) {
 #define DDP_OPAQUE_S(x) ((void)0)
 #define DDP_UMUL24(a, b) ((a) * (b))
 #define DDP_GLOBAL
+#if defined(DDP_EMU_TRACE)  // tools/lds_trace: LDS bank-conflict attribution on the emulator (phase marks, 16-byte loads)
+extern "C" void ddp_emu_mark(const char*);
+extern "C" void ddp_emu_ld2(const void*, int);
+#define DDP_MARK(name) ddp_emu_mark(name)
+#else
 #define DDP_MARK(name)
+#endif
 #else
 #include <hip/hip_runtime.h>
 #define DDP_DEV __device__ __forceinline__
@@ -478,34 +489,39 @@ struct WaveLds {
       union {
         alignas(16) Acc V[81];
         struct {
-          alignas(16) Acc Sd[48];  // layout ch_idx(): [axis][control row]
+          alignas(16) Acc Sd[54];  // layout ch_idx(): [axis][control row]
           alignas(16) Acc dl[30];  // layout dl_idx(): [axis][velocity / acceleration control point]
         };
       };
       Acc Vx[12];
-      // Hxu[a][c] (9x10), Huu 10x10, both triangles stored.  Hxx | Hxu | Huu must stay consecutive
-      // (phase H stores through one base pointer).  Phase C reads Huu into registers and never again, so
-      // the gains it produces share that storage.
+      // The condensed system.  Hxx (9x9): the upper triangle is what the value recursion reads.  HR: rows 9..18 of the
+      // 19x19 matrix WITH the right-hand side as a twentieth column - HR[a] = [Hux[a][0..8] | Huu[a][0..9] | Hu[a]], row
+      // stride kHRS = 21: phase C's read `a` of all twenty column lanes is then one run of twenty consecutive doubles
+      // (conflict-free; the 9x10 + 10x10 + separate Hz layout of r04 put three address families on the same banks), and
+      // phase H's scattered stores see two-way bank conflicts at worst instead of three-way (tools/lds_trace; the
+      // offset of HR behind Hxx is part of that tuning).  Hzx = Hx; hdump: the slot of phase H's masked stores.
+      // Everything is addressed from Hxx[0] (phase H stores through one base pointer).  Phase C reads HR into registers
+      // and never again, so the gains it produces share that storage.
       // The per-row weights D = s/c and g of phase R1 are consumed by phase S, before phase H writes the
       // condensed system, and the system (and the gains) of a knot are dead when the next knot's R1 runs:
       // the two share storage.
       union {
         struct {
-          Acc Hxx[81], Hxu[90];
+          Acc Hxx[81], hpad[7];
           union {
-            Acc Huu[100];
+            Acc HR[10 * 21];
             Acc KU[100];
           };
+          Acc Hzx[9], hdump[1];
         };
         struct {
           Acc drow[64 * RPL], grow[64 * RPL];
         };
       };
-      Acc Hz[20];
       union {
         struct {  // operands of the assembly: dead once phase H is done
           alignas(16) Acc Sp[36];  // layout sp_idx(): [entry of the symmetric 3x3][control point]
-          alignas(16) Acc hh[48];  // layout ch_idx()
+          alignas(16) Acc hh[54];  // layout ch_idx()
           Acc last[4];
           Acc VZ[176];  // Vxx * Z
         };
@@ -601,6 +617,9 @@ DDP_DEV Real powi(Real T, int e) {  // T^e for 0 <= e <= 7 without a register-ar
 #if defined(DIRECT_EMULATE)
 template <typename T>
 DDP_DEV void ld2(const T* p, T& a, T& b) {
+#if defined(DDP_EMU_TRACE)
+  ddp_emu_ld2(p, (int)(2 * sizeof(T)));
+#endif
   a = p[0];
   b = p[1];
 }
@@ -669,10 +688,11 @@ struct Wave {
 
   // LDS layouts of the assembly operands of the backward sweep.  The index a consumer's inner loop runs over is the
   // fastest one, so that two neighbours come with one 16-byte load (ld2).
+  static constexpr int kHRS = 21, kHR0 = 88, kHzx = kHR0 + 10 * kHRS, kHdump = kHzx + 9;  // WaveLds: HR, Hzx, hdump in doubles from Hxx[0]
   static constexpr int we_idx(int row, int i) { return i * 18 + row; }   // We: 15 control rows + 3 rows of Z, 6 coefficients
   static constexpr int sp_idx(int cp, int e) { return e * 6 + cp; }      // Sp: 6 position control points, 6 entries of the symmetric 3x3
   static constexpr int dl_idx(int cp9, int d) { return d * 10 + cp9; }   // dl: 9 velocity / acceleration control points, 3 axes
-  static constexpr int ch_idx(int row, int d) { return d * 16 + row; }   // Sd, hh: 15 control rows, 3 axes
+  static constexpr int ch_idx(int row, int d) { return d * 18 + row; }   // Sd, hh: 15 control rows, 3 axes; stride 18: the 16-byte row loads of the three axes (phase H) fall on disjoint banks
 
   // Knot (b, k) of the [B][nmax(+1)] arrays; k may differ between lanes.
   DDP_DEV St* Xp(int buf, int k) const { return B.X[buf] + ((size_t)b * (B.nmax + 1) + k) * x_stride<St>(); }
@@ -896,12 +916,13 @@ struct Wave {
           const int lo = d < d2 ? d : d2, hi = d < d2 ? d2 : d;
           const int sidx = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);  // xx,xy,xz,yy,yz,zz
           const int q = 3 * i2 + d2;
-          // [Hxu; Huu] is one 19x10 block behind Hxx: entry (p, q >= 9) sits at 81 + 10 p + (q - 9)
-          int o1 = q < 9 ? p * 9 + q : p * 10 + q + 72;
-          int o2 = q < 9 ? q * 9 + p : (p < 9 ? o1 : q * 10 + p + 72);
+          // entry (p, q), p <= q < 18: Hxx keeps its upper triangle only; rows >= 9 live in HR, both triangles (phase C
+          // reads whole rows), and the Hxu block as its transpose inside those rows (see WaveLds)
+          int o1 = q < 9 ? p * 9 + q : (p < 9 ? kHR0 + (q - 9) * kHRS + p : kHR0 + (p - 9) * kHRS + q);
+          int o2 = (q < 9 || p < 9) ? o1 : kHR0 + (q - 9) * kHRS + p;
           // i == i2: the lower triangle of the diagonal block belongs to the lane of the other axis - this lane's copy
-          // goes to a slot nobody reads (Hz[19], behind Hxx | Hxu | Huu | Hz[0..18])
-          if (p > q) o1 = o2 = 81 + 90 + 100 + 19;
+          // goes to a slot nobody reads
+          if (p > q) o1 = o2 = kHdump;
           // bits 12..14 (t == 0): the power of T of the jerk Gram term; bits 28..31: Sp[.][sidx] in units of 16 bytes
           L.lt[1 + t][lane] = (o1 * a8) | ((t == 0 && hasq ? i + i2 - 5 : 0) << 12) | ((o2 * a8) << 16) |
                               ((sp_idx(0, sidx) * a8 / 16) << 28);
@@ -917,8 +938,10 @@ struct Wave {
         {  // lt[5]: phase S roles (lanes >= 54 redo lane 53)
           const int l54 = lane < 54 ? lane : 53;
           const bool isS = l54 < 36;
-          const int e = l54 % 6, j = isS ? l54 / 6 : (l54 - 36) / 3;
-          const int d0 = isS ? ((e < 3) ? 0 : (e < 5 ? 1 : 2)) : (l54 - 36) % 3;
+          // consecutive lanes take consecutive control points: their stores fall on consecutive LDS words (entry- / axis-
+          // fastest roles stored with a stride of 6 / 16 doubles, a three-way bank conflict on the store path)
+          const int e = l54 / 6, j = isS ? l54 % 6 : (l54 - 36) % 6;
+          const int d0 = isS ? ((e < 3) ? 0 : (e < 5 ? 1 : 2)) : (l54 - 36) / 6;
           const int d1 = isS ? ((e < 3) ? e : (e < 5 ? e - 2 : 2)) : 0;
           const int dst = isS ? sp_idx(j, e) : (int)(&L.hh[0] - &L.Sp[0]) + ch_idx(j, d0);  // hh follows Sp in the same struct
           L.lt16[1][lane] = (unsigned short)(d0 | (d1 << 2) | ((isS ? 1 : 0) << 4) | (j << 5) | (dst << 8));
@@ -974,7 +997,11 @@ struct Wave {
       const int a0 = isv ? a0v : (isa ? a0a : 43);
       const int pp = isv ? (lane < 15 ? 0 : 1) : (isa ? (l2 < 12 ? 2 : 3) : 4);
       const int po = (6 * P + lane + 1) | (a0 << kRB) | ((Lds::kPMax + pp) << 16);
-      pk = lane < 55 ? po : pk;
+      // lanes 55..63 without a position row of their own alias the T_min row (lane 54's operands: the same LDS addresses,
+      // i.e. a broadcast) instead of position row 0, whose val[0..2] and plane 0 sit one bank period away from this slot's
+      // val[32..34] and pseudo-plane 4 - a bank conflict in every row-operand load of the slot (tools/lds_trace)
+      const int pal = (43 << kRB) | ((Lds::kPMax + 4) << 16);
+      pk = lane < 55 ? po : (pv ? pk : pal);
     }
     return pk;
   }
@@ -1632,10 +1659,11 @@ struct Wave {
           (&L.Sp[0])[(ws >> 8) & 255] = acc;
         }
         {  // velocity / acceleration rows: +/- pairs
-          const int l27 = lane < 27 ? lane : 26;
+          const int lq = lane < 27 ? lane : 26;
+          const int d9 = lq / 9, cp9 = lq - 9 * d9;  // lq = 9 axis + control point: consecutive lanes store consecutive words
+          const int l27 = 3 * cp9 + d9;                     // the row's number among the 27: 3 (control point) + axis
           const int rp = 6 * P + (l27 < 15 ? l27 : 15 + l27);  // 6P + l | 6P + 30 + (l - 15)
           const int rm = rp + (l27 < 15 ? 15 : 12);
-          const int cp9 = (l27 * 11) >> 5, d9 = l27 - 3 * cp9;  // l27 = 3 cp9 + axis
           L.dl[dl_idx(cp9, d9)] = L.drow[rp] + L.drow[rm];
           L.hh[ch_idx(6 + cp9, d9)] = L.grow[rp] - L.grow[rm];
         }
@@ -1652,8 +1680,9 @@ struct Wave {
           LV(tw_ho)[t] = L.lt[1 + t][lane];
           LV(tw_hv)[t] = L.lt16[2 + t][lane];
         }
-        const int l45 = lane < 45 ? lane : 44;
-        const int cr = l45 / 3, d = l45 % 3;
+        const int lq = lane < 45 ? lane : 44;
+        const int d = lq / 15, cr = lq - 15 * d;  // row-fastest roles: consecutive lanes store consecutive words of Sd
+        const int l45 = 3 * cr + d;
         const int crp = cr < 6 ? cr : 5;
         const Acc* S = &L.Sp[sp_idx(crp, 0)];  // entries xx,xy,xz,yy,yz,zz of control point crp, six apart
         const Real* dv = &L.dval[crp * 3];
@@ -1715,7 +1744,7 @@ struct Wave {
           DDP_PIN(adv);  // or the FMAs sink below the later batches' loads and all operands stay live
         }
         adv *= sig;
-        Acc* Hb = L.Hxx;  // Hxx | Hxu | Huu | Hz are consecutive members: byte offsets from Hxx[0] (see init_tables)
+        Acc* Hb = L.Hxx;  // Hxx | HR | Hzx | hdump are consecutive members: byte offsets from Hxx[0] (see init_tables)
 #pragma unroll
         for (int t = 0; t < 3; t++) {  // column axis d2 = (d + t) mod 3: t == 0 is the lane's own axis
           const int wo = LV(tw_ho)[t], wv = LV(tw_hv)[t];
@@ -1771,17 +1800,13 @@ struct Wave {
 #pragma unroll
             for (int c = 0; c < 3; c++) zvz += z3[c] * L.VZ[(3 * c + d) * 19 + 18];
             const Acc v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Acc)0) + sig * acc;
-            if (p < 9) {
-              L.Hxu[p * 10 + 9] = v;
-            } else {
-              L.Huu[(p - 9) * 10 + 9] = v;
-              L.Huu[90 + (p - 9)] = v;
-            }
+            L.HR[9 * kHRS + p] = v;                      // row 18 (T), column p
+            if (p >= 9) L.HR[(p - 9) * kHRS + 18] = v;   // and its mirror in the rows of u
           } else {
             Acc zv = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) zv += z3[c] * L.Vx[3 * c + d];
-            L.Hz[p] = ((i >= 3) ? wsn * L.Ru[p - 9] : (Acc)0) + zv + acc;
+            *(p < 9 ? &L.Hzx[p] : &L.HR[(p - 9) * kHRS + 19]) = ((i >= 3) ? wsn * L.Ru[p - 9] : (Acc)0) + zv + acc;
           }
         }
       }
@@ -1789,10 +1814,10 @@ struct Wave {
         PLV(Acc, ptt);
         PLV(Acc, pzt);
         LANES {
-          const int t = lane < 45 ? lane : 44;
+          const int tq = lane < 45 ? lane : 44;
           const int a = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
-          const int tr = (t * 43) >> 7, td = t - 3 * tr;  // t = 3 row + axis
-          const Acc dv = L.dval[t], sd = L.Sd[ch_idx(tr, td)], hv = L.hh[ch_idx(tr, td)];
+          const int td = tq / 15, tr = tq - 15 * td;  // tq = 15 axis + row (row-fastest: Sd / hh are [axis][row])
+          const Acc dv = L.dval[3 * tr + td], sd = L.Sd[ch_idx(tr, td)], hv = L.hh[ch_idx(tr, td)];
           const Acc ft = L.fT[a], vzt = L.VZ[a * 19 + 18], vxa = L.Vx[a];
           const Acc zu = L.z[9 + a], r2 = L.Rppu[a], r1 = L.Rpu[a];
           DDP_LOADS_ISSUED();
@@ -1804,8 +1829,8 @@ struct Wave {
         const Acc stt = (Acc)WAVE_SUM_D(ptt), szt = (Acc)WAVE_SUM_D(pzt);
         const Acc quu = (B.k.time_power == 2) ? (Acc)B.k.w_time : (Acc)0;
         const Acc qz = (B.k.time_power == 2) ? (Acc)B.k.w_time * T : (Acc)0.5 * (Acc)B.k.w_time;
-        L.Huu[99] = stt + quu + sig * L.last[0];  // wave-uniform stores
-        L.Hz[18] = szt + qz - L.last[1];
+        L.HR[9 * kHRS + 18] = stt + quu + sig * L.last[0];  // wave-uniform stores
+        L.HR[9 * kHRS + 19] = szt + qz - L.last[1];
       }
       WSYNC();
       DDP_MARK("B_C");
@@ -1825,11 +1850,11 @@ struct Wave {
         const int l5 = lane & 31;
         const int col = l5 < 16 ? l5 : (l5 < 26 ? l5 - 16 : (l5 < 30 ? l5 - 10 : 19));
         LV(colv) = col;
-        const Acc* src = col < 10 ? &L.Huu[col] : (col == 10 ? &L.Hz[9] : &L.Hxu[(col - 11) * 10]);
-        const int stride = col < 10 ? 10 : 1;
+        // column `col` of [Huu | Hu | Hux]: entry a sits in row a of HR (matrix columns behind the nine of Hux, Hu last)
+        const Acc* src = &L.HR[col < 10 ? 9 + col : (col == 10 ? 19 : col - 11)];
 #pragma unroll
-        for (int a = 0; a < 10; a++) LV(m)[a] = src[a * stride];
-        const Acc hu = L.Hz[9 + (lane < 10 ? lane : 9)];  // Hu = Hz[9..18], one entry per lane: max |Qu| for the optimality error
+        for (int a = 0; a < 10; a++) LV(m)[a] = src[a * kHRS];
+        const Acc hu = L.HR[(lane < 10 ? lane : 9) * kHRS + 19];  // Hu, one entry per lane: max |Qu| for the optimality error
         DDP_LOADS_ISSUED();
         LV(e_qu) = fmax(LV(e_qu), fabs(hu));
         if (regi > 0) {  // lam = base^reg - 1 is exactly 0 at reg = 0 (the common case)
@@ -1964,7 +1989,7 @@ struct Wave {
           const int aa = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
           // lanes 0..44: (colA, colB) = Y columns 1+a, 1+c2;  lanes 45..53: Y column 1+aa against y (column 0)
           const int cA = lane < 45 ? 1 + a : 1 + aa, cB = lane < 45 ? 1 + c2 : 0;
-          const Acc h0 = lane < 45 ? L.Hxx[a * 9 + c2] : L.Hz[aa];
+          const Acc h0 = lane < 45 ? L.Hxx[a * 9 + c2] : L.Hzx[aa];
           Acc yy = 0, kk2 = 0;
 #pragma unroll
           for (int half = 0; half < 2; half++) {  // two batches of operands: 40 live doubles would spill

@@ -34,6 +34,16 @@ using namespace direct;
 // Arithmetic is double for both storage types (DESIGN.md "Precision"): St = float halves the HBM
 // traffic, it does not change the arithmetic.
 typedef double Cmp;
+// Waves per SIMD of the wide row-slot classes.  Classes 5..7 (polytopes of 34..65 planes, where the real pipeline's
+// corridors sit: widest polytope per corridor median 32, p90 42) take 258..290 registers when left alone; capped at 256
+// they spill 32..240 bytes and run TWO waves per SIMD: 5680 real-corridor plans 39.1 -> 30.8 ms (f32), 38.6 -> 31.7 ms
+// (f64), bit-identical (profiles/r05_real_corridors.json).  Classes 8..14: DDP_WAVES_WIDER.
+#ifndef DDP_WAVES_WIDE
+#define DDP_WAVES_WIDE 2
+#endif
+#ifndef DDP_WAVES_WIDER
+#define DDP_WAVES_WIDER 1
+#endif
 template <typename St>
 struct MinWaves { static constexpr int v = DDP_WAVES_F32; };
 template <>
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(64) void k_begin(Batch<St> B) {
 
 // the hot kernel: n trips of the outer loop (ddp_optimizer.cpp:295-412) per trajectory
 template <typename St, int RPL>
-__global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate(Batch<St> B, int n_iters) {
+__global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAVES_WIDE : MinWaves<St>::v))) void k_iterate(Batch<St> B, int n_iters) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, traj_of(B, blockIdx.x));
   W.load_state();
@@ -135,7 +145,7 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, con
   return (int)t;
 }
 template <typename St, int RPL>
-__global__ __launch_bounds__(64, (RPL > 4 ? 1 : MinWaves<St>::v)) void k_iterate_dyn(Batch<St> B, int n_iters, Sched S) {
+__global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAVES_WIDE : MinWaves<St>::v))) void k_iterate_dyn(Batch<St> B, int n_iters, Sched S) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
   Wave<Cmp, St, RPL> W(B, lds, 0);
   W.init_tables();

@@ -12,6 +12,9 @@
 #include <vector>
 
 using namespace direct;
+#if defined(DDP_EMU_TRACE)
+extern "C" void ddp_emu_lds_range(void*, size_t);
+#endif
 
 template <typename Real>   // Real = storage type here; the compute type is chosen per call
 struct Emu {
@@ -28,6 +31,9 @@ struct Emu {
 template <typename Cmp, typename Real, int RPL, typename F>
 static void for_each_wave(Emu<Real>& E, F f) {
   static WaveLds<Cmp, Real, RPL> lds;
+#if defined(DDP_EMU_TRACE)  // tools/lds_trace
+  ddp_emu_lds_range(&lds, sizeof lds);
+#endif
   for (int b = 0; b < E.B.B; b++) {
     Wave<Cmp, Real, RPL> W(E.B, lds, b);
     f(W);
@@ -125,6 +131,22 @@ struct EmuHandle {
   void* p;
 };
 
+#if defined(DDP_EMU_TRACE)  // tools/lds_trace: byte offsets of the LDS members of the two-slot float-storage wave
+#include <cstddef>
+#include <cstdio>
+extern "C" void ddp_emu_layout(const char* path) {
+  typedef WaveLds<double, float, 2> Lt;
+  FILE* f = fopen(path, "w");
+  if (!f) return;
+#define MEM(m) fprintf(f, "%s %zu\n", #m, offsetof(Lt, m));
+  MEM(st) MEM(WbE) MEM(WdE) MEM(Rc) MEM(lt) MEM(lt16) MEM(ones) MEM(tp) MEM(z) MEM(pl) MEM(val) MEM(G) MEM(We) MEM(dval) MEM(fT) MEM(Ru)
+  MEM(Rpu) MEM(Rppu) MEM(V) MEM(Sd) MEM(dl) MEM(Vx) MEM(Hxx) MEM(HR) MEM(KU) MEM(Hzx) MEM(drow) MEM(grow) MEM(Sp) MEM(hh)
+  MEM(last) MEM(VZ) MEM(UY) MEM(KUr) MEM(ft)
+#undef MEM
+  fprintf(f, "end %zu\n", sizeof(Lt));
+  fclose(f);
+}
+#endif
 extern "C" {
 void* emu_begin(int dtype, const direct_ddp_params_t* p, const direct_ddp_batch_in_t* in) {
   EmuHandle* h = new EmuHandle();
