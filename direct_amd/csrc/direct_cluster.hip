@@ -1136,6 +1136,7 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
   if (!pack(candidate_xyz, n_candidate, pc) || !pack(cluster_xyz, n_cluster, pk)) return cfail(DIRECT_ERR_INVALID, "voxel outside the map");
   Elem E = {};
   E.n_cluster = n_cluster; E.n_cand = n_candidate; E.live = 1;
+  h->resident_batch = 0;  // element 0's cluster, candidates and flags are overwritten below: the last generation's clusters are gone
   CHIP_TRY(hipMemcpyAsync(h->inside_tmp, inside_data, (size_t)D.G, hipMemcpyHostToDevice, h->stream));
   CHIP_TRY(hipMemcpyAsync(D.cand, pc.data(), (size_t)n_candidate * 4, hipMemcpyHostToDevice, h->stream));
   if (n_cluster) CHIP_TRY(hipMemcpyAsync(D.cluster, pk.data(), (size_t)n_cluster * 4, hipMemcpyHostToDevice, h->stream));

@@ -704,6 +704,9 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   if (cfg->dtype != DIRECT_F32 && cfg->dtype != DIRECT_F64) return fail(DIRECT_ERR_INVALID, "bad dtype");
   if (cfg->max_batch <= 0 || cfg->n_seg_max <= 0 || cfg->p_max <= 0) return fail(DIRECT_ERR_INVALID, "bad sizes");
   if (cfg->p_max > DIRECT_P_LIMIT) return fail(DIRECT_ERR_UNSUPPORTED, "p_max > DIRECT_P_LIMIT");
+#if defined(DDP_DEV_RPL2)  // development builds carry the two-slot kernels only: (2 * 64 - 55) / 6 planes
+  if (cfg->p_max > 12) return fail(DIRECT_ERR_UNSUPPORTED, "development build (DDP_DEV_RPL2): p_max > 12");
+#endif
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(DIRECT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -856,7 +859,8 @@ static direct_status_t classify_batch(direct_ddp_handle_t h, const direct_ddp_ba
   if (on_host) {
     for (int b = 0; b < B; b++) {
       int pm = 1;
-      for (int k = 0; k < in->n_seg[b]; k++) pm = std::max(pm, (int)in->n_planes[(size_t)b * nm + k]);
+      const int N = std::min(std::max((int)in->n_seg[b], 0), nm);  // as k_classify: a bad n_seg is begin()'s to report, not ours to follow
+      for (int k = 0; k < N; k++) pm = std::max(pm, (int)in->n_planes[(size_t)b * nm + k]);
       sl[b] = (6 * std::min(pm, h->pmax) + 55 + 63) / 64;
     }
   } else {

@@ -72,7 +72,10 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
  *   accept[i]   = can_clu[i] && for all j < i with accept[j]: can_can[i][j]     -- what polytopeCluster_cpu's
  *                 sequential loop decides (cluster_server_cpu.cpp:360-384), since serialConvexTest is an AND over
  *                 targets and accepted candidates join the cluster at once (may be NULL)
- * All arrays are HOST memory; inside_data is the reference's per-voxel flag array. */
+ * All arrays are HOST memory; inside_data is the reference's per-voxel flag array.
+ * The call uses the handle's cluster storage: it INVALIDATES the clusters a preceding
+ * direct_cluster_polygon_generation_batch left resident (a following direct_cluster_hull_planes_batch with
+ * cluster_xyz == NULL fails with DIRECT_ERR_INVALID until the next generation). */
 direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint8_t* inside_data, int32_t n_candidate,
                                            const int32_t* candidate_xyz, int32_t n_cluster, const int32_t* cluster_xyz,
                                            uint8_t* can_clu, uint8_t* can_can, uint8_t* accept);

@@ -34,21 +34,27 @@ def perturb_float_ulp(batch, seed):
                          infeas_in=batch.infeas_in, init_poly=None if batch.init_poly is None else p(batch.init_poly))
 
 
-def compare(res, ref):
-    """what the caller sees at exit: return code, iteration count, cost, durations"""
+def compare(res, ref, detail=False):
+    """what the caller sees at exit: return code, iteration count, cost, durations (detail: also per problem)"""
     both = (res.rtn >= 0) & (ref.rtn >= 0)
     with np.errstate(divide="ignore", invalid="ignore"):
         dc = np.abs(res.cost / ref.cost - 1.0)
         dT = np.abs(res.T - ref.T).max(axis=1) / np.abs(ref.T).max(axis=1)
     q = lambda a: [float("%.3g" % x) for x in np.quantile(a, [0.5, 0.9, 1.0])] if len(a) else []
     same = (res.rtn == ref.rtn) & (res.iter_used == ref.iter_used)
-    return dict(n=int(len(ref.rtn)), same_rtn=int((res.rtn == ref.rtn).sum()), same_outcome=int(same.sum()),
-                same_feasibility=int(((res.rtn >= 0) == (ref.rtn >= 0)).sum()),
-                same_infeas_out=int((res.infeas_out == ref.infeas_out).sum()),
-                cost_dev_q50_q90_max=q(dc[both]), cost_dev_same_outcome_q50_q90_max=q(dc[both & same]),
-                T_dev_q50_q90_max=q(dT[both]), n_cost_dev_below_1e_8=int((dc[both] < 1e-8).sum()),
-                n_cost_dev_below_1e_3=int((dc[both] < 1e-3).sum()), n_both_ok=int(both.sum()),
-                iter_diff_max=int(np.abs(res.iter_used.astype(int) - ref.iter_used.astype(int)).max()))
+    out = dict(n=int(len(ref.rtn)), same_rtn=int((res.rtn == ref.rtn).sum()), same_outcome=int(same.sum()),
+               same_feasibility=int(((res.rtn >= 0) == (ref.rtn >= 0)).sum()),
+               same_infeas_out=int((res.infeas_out == ref.infeas_out).sum()),
+               cost_dev_q50_q90_max=q(dc[both]), cost_dev_same_outcome_q50_q90_max=q(dc[both & same]),
+               T_dev_q50_q90_max=q(dT[both]), n_cost_dev_below_1e_8=int((dc[both] < 1e-8).sum()),
+               n_cost_dev_below_1e_3=int((dc[both] < 1e-3).sum()), n_both_ok=int(both.sum()),
+               iter_diff_max=int(np.abs(res.iter_used.astype(int) - ref.iter_used.astype(int)).max()))
+    if detail:
+        bez = np.abs(res.bez - ref.bez).reshape(len(ref.rtn), -1).max(axis=1) / np.maximum(np.abs(ref.bez).reshape(len(ref.rtn), -1).max(axis=1), 1e-300)
+        out["per_problem"] = dict(same=[bool(v) for v in same], both=[bool(v) for v in both], cost_dev=[float(v) for v in dc],
+                                  T_dev=[float(v) for v in dT], bez_dev=[float(v) for v in bez], ref_rtn=[int(v) for v in ref.rtn],
+                                  ref_iter=[int(v) for v in ref.iter_used])
+    return out
 
 
 def two_phase(solve, p0, p1, batch0, handoff):
@@ -66,11 +72,13 @@ def sample_report(kind, B, N, idx, dev64, dev32, seed=1000, first=0, control_see
     return out
 
 
-def batch_report(sb, dev64, dev32, control_seeds=(11, 12)):
+def batch_report(sb, dev64, dev32, control_seeds=(11, 12), detail=False):
     """The comparison records of the problems `sb` (any HostBatch): device (double / float storage) against the oracle,
     both phases, phase 1 of every implementation from the ORACLE's phase-0 result, with the oracle-against-itself
-    controls (inputs moved by one ulp of a double / of a float) next to them."""
+    controls (inputs moved by one ulp of a double / of a float) next to them.  detail: per-problem records as well
+    (which problems the double-ulp controls reproduce exactly - the device is then held to the oracle exactly)."""
     p0, p1 = abi.phase0_params(), abi.phase1_params()
+    cmp = lambda a, b: compare(a, b, detail)
     ora = lambda p, b: refapi.solve_batch(p, b)[0]
     r0 = ora(p0, sb)
     b1 = soak_lib.phase1_inputs(sb, r0)             # the reference's own hand-off: time-scaled Bezier points
@@ -79,8 +87,8 @@ def batch_report(sb, dev64, dev32, control_seeds=(11, 12)):
                oracle=dict(phase0_rtn={str(int(v)): int(c) for v, c in zip(*np.unique(r0.rtn, return_counts=True))},
                            phase1_rtn={str(int(v)): int(c) for v, c in zip(*np.unique(r1.rtn, return_counts=True))},
                            phase0_iters_mean=float(r0.fwd_passes.mean()), phase1_iters_mean=float(r1.fwd_passes.mean())))
-    out["control_double_ulp"] = [dict(phase0=compare(ora(p0, soak_lib.perturb_ulp(sb, 1000 * cs)), r0),
-                                      phase1=compare(ora(p1, soak_lib.perturb_ulp(b1, 1000 * cs + 1)), r1))
+    out["control_double_ulp"] = [dict(phase0=cmp(ora(p0, soak_lib.perturb_ulp(sb, 1000 * cs)), r0),
+                                      phase1=cmp(ora(p1, soak_lib.perturb_ulp(b1, 1000 * cs + 1)), r1))
                                  for cs in control_seeds]
     # float-level references: the oracle on float-rounded inputs (what DIRECT_F32 is given), monomial hand-off
     sb32 = sb.astype(np.float32).astype(np.float64)
@@ -89,13 +97,13 @@ def batch_report(sb, dev64, dev32, control_seeds=(11, 12)):
     c1 = sb32.with_init(None, T0=T1, infeas_in=q0.infeas_out.astype(np.uint8), init_poly=q0.poly)
     c1 = c1.astype(np.float32).astype(np.float64)
     q1 = ora(p1, c1)
-    out["control_float_ulp"] = [dict(phase0=compare(ora(p0, perturb_float_ulp(sb32, 1000 * cs)), q0),
-                                     phase1=compare(ora(p1, perturb_float_ulp(c1, 1000 * cs + 1)), q1))
+    out["control_float_ulp"] = [dict(phase0=cmp(ora(p0, perturb_float_ulp(sb32, 1000 * cs)), q0),
+                                     phase1=cmp(ora(p1, perturb_float_ulp(c1, 1000 * cs + 1)), q1))
                                 for cs in control_seeds]
     if dev64 is not None:
-        out["device_f64"] = dict(phase0=compare(dev64(p0, sb), r0), phase1=compare(dev64(p1, b1), r1))
+        out["device_f64"] = dict(phase0=cmp(dev64(p0, sb), r0), phase1=cmp(dev64(p1, b1), r1))
     if dev32 is not None:
-        out["device_f32"] = dict(phase0=compare(dev32(p0, sb32), q0), phase1=compare(dev32(p1, c1), q1))
+        out["device_f32"] = dict(phase0=cmp(dev32(p0, sb32), q0), phase1=cmp(dev32(p1, c1), q1))
     return out
 
 

@@ -267,11 +267,22 @@ def check_against_controls(r, n):
         cmax = lambda cs: max([c["cost_dev_q50_q90_max"][2] for c in cs if c["cost_dev_q50_q90_max"]] or [0.0])
         # double storage
         assert d64["same_feasibility"] >= min(c["same_feasibility"] for c in c64), (ph, d64, c64)
-        assert d64["same_outcome"] >= min(c["same_outcome"] for c in c64) - 1, (ph, d64, c64)
-        assert d64["n_cost_dev_below_1e_8"] >= min(c["n_cost_dev_below_1e_8"] for c in c64) - 1, (ph, d64, c64)
+        assert d64["same_outcome"] >= min(c["same_outcome"] for c in c64), (ph, d64, c64)
+        assert d64["n_cost_dev_below_1e_8"] >= min(c["n_cost_dev_below_1e_8"] for c in c64), (ph, d64, c64)
         assert d64["cost_dev_q50_q90_max"][0] < 1e-9, (ph, d64)                      # the bulk: SURVEY 8(c)'s 1e-8 with a decade to spare
-        assert d64["cost_dev_q50_q90_max"][2] <= max(1e-8, 30 * cmax(c64)), (ph, d64, c64)   # the tail: what the algorithm does to one ulp (the maximum over five seeds
+        assert d64["cost_dev_q50_q90_max"][2] <= max(1e-8, 15 * cmax(c64)), (ph, d64, c64)   # the tail: what the algorithm does to one ulp (the maximum over five seeds
                                                                                             # of eight problems is itself a noisy statistic: measured ratios 0.3 .. 11)
+        if "per_problem" in d64:
+            # Problem by problem: where the oracle CONVERGES (rtn 1 / 2) and every one-ulp control reproduces its return
+            # code and iteration count, nothing is being amplified - the device is held to SURVEY 8(c) exactly there:
+            # identical rtn and iterations, cost / durations / control points within 1e-6.
+            pp = d64["per_problem"]
+            stable = [pp["ref_rtn"][i] in (1, 2) and all(c["per_problem"]["same"][i] for c in c64) for i in range(n)]
+            assert sum(stable) >= 1 or not any(r in (1, 2) for r in pp["ref_rtn"]), (ph, pp["ref_rtn"], c64)
+            for i in range(n):
+                if stable[i]:
+                    assert pp["same"][i], (ph, i, pp)
+                    assert pp["cost_dev"][i] < 1e-6 and pp["T_dev"][i] < 1e-6 and pp["bez_dev"][i] < 1e-5, (ph, i, pp)
         # float storage: SURVEY 8(c)'s fp32 tolerances wherever the float-ulp control keeps them
         assert d32["same_feasibility"] >= min(c["same_feasibility"] for c in c32) - 1, (ph, d32, c32)
         assert d32["same_rtn"] >= min(c["same_rtn"] for c in c32) - 1, (ph, d32, c32)
@@ -300,7 +311,7 @@ def test_many_planes_per_polytope(built, p_max):
             s.close()
             return r
         return solve
-    r = n100_lib.batch_report(batch, dev(np.float64), dev(np.float32), control_seeds=(11, 12, 13, 14, 15))
+    r = n100_lib.batch_report(batch, dev(np.float64), dev(np.float32), control_seeds=(11, 12, 13, 14, 15), detail=True)
     check_against_controls(r, 8)
 
 
