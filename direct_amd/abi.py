@@ -88,7 +88,7 @@ class SampleOut(C.Structure):
 class LaunchInfo(C.Structure):  # direct_ddp_launch_info_t
     _fields_ = [
         ("dynamic", C.c_int32), ("shared_search", C.c_int32), ("pair_trials", C.c_int32), ("single_steps", C.c_int32),
-        ("n_buffers", C.c_int32), ("resident_waves", C.c_int32), ("batch", C.c_int32), ("reserved", C.c_int32),
+        ("n_buffers", C.c_int32), ("resident_waves", C.c_int32), ("batch", C.c_int32), ("shared_sweep", C.c_int32),
         ("bwd_knot_visits", C.c_uint64), ("fwd_knot_visits", C.c_uint64),
     ]
 

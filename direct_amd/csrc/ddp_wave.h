@@ -63,6 +63,7 @@ extern "C" int ddp_emu_set_lane(int);
 #define RDLANE(arr, idx, src) (arr[src][idx])
 #define RDLANE_M(var, member, src) (var[src].member)
 #define RDLANE_V(var, src) (var[src])
+#define RDLANE_I(var, src) (var[src])
 // value of per-lane array entry arr[idx] on lane `src` of the CALLER'S ROW of 16 lanes / acc -= that value * mul
 #define ROW_BCAST(arr, idx, src) (arr[(lane & 48) + (src)][idx])
 #define ROW_FNMA(acc, arr, idx, src, mul) ((acc) -= arr[(lane & 48) + (src)][idx] * (mul))
@@ -121,6 +122,7 @@ extern "C" void ddp_emu_ld2(const void*, int);
 #define RDLANE(arr, idx, src) direct::readlane_real(arr[idx], src)
 #define RDLANE_M(var, member, src) direct::readlane_real(var.member, src)
 #define RDLANE_V(var, src) direct::readlane_real(var, src)
+#define RDLANE_I(var, src) __builtin_amdgcn_readlane(var, src)
 // Row broadcasts on the DP-ALU's DPP path (gfx90a+: 64-bit DPP supports row_newbcast only): lane `src` (a compile-time
 // constant, 0..15) of every row of 16 lanes is the operand of all 16 lanes of that row.  ROW_FNMA is ONE instruction,
 // v_fmac_f64_dpp: acc -= bcast(arr[idx]) * mul - against two v_readlane plus the FMA of the SGPR-broadcast form.
@@ -397,6 +399,22 @@ struct HelpSlot {
 };
 constexpr int kMaxBuf = 12;  // iterate buffers: `cur` + one per concurrently evaluated step, 0 .. 10 (3 without helpers)
 
+// ---- helper-assisted backward sweep (scheduling only, see Wave::bwd_sweep_t) -----------------------
+// One per trajectory.  A third of a backward knot does not depend on the value function (control values, constraint rows,
+// the constraint part of the condensed system: phases T2, R1 rows, S, S2 and the front half of H): the owner of a sweep
+// publishes it, and waves that wait for this trajectory's next ticket compute that part ("front") for knots of their
+// own, from knot 0 upwards, into hand-over records in HBM, while the owner sweeps down from knot N - 1; where the two
+// meet the owner goes on with the value-dependent rest ("back") alone.
+struct BwdShare {
+  unsigned word;             // (tag << 8) | helpers inside the protocol; tag 0: no sweep open.  Only ever changed by atomic RMWs
+  int cur, infeas, seq;      // the sweep's iterate buffer and mode; seq: sweeps opened so far (owner only: the tag source)
+  double mu;
+  unsigned long long claim;  // free knots [low, high): low in bits 0..31 (helpers take from below), high + 2^30 in bits 32..63 (the owner from above)
+};
+constexpr int kRecDoubles = 384;  // one knot's hand-over record: six doubles per lane, stored as three 16-byte halves per lane
+constexpr int kOwnChunk = 4, kHelpChunk = 4;  // knots per claim
+constexpr unsigned long long kClaimBias = 1ull << 30;
+
 // ---- device-resident batch (all pointers are device memory) -----------------------------------
 template <typename Real>
 struct Batch {
@@ -432,6 +450,15 @@ struct Batch {
               // than tail_thresh are left the line searches switch to single steps open from step 0 - few trajectories on
               // many waves, the tail of a natural-exit launch (scheduling only)
   unsigned long long* visits;  // [2] knots executed by backward sweeps / by forward trials (observability; may be null)
+  // helper-assisted backward sweep: null / 0 = every sweep stays with its owner
+  BwdShare* bshare;  // [B]
+  int* bflag;        // [B][nmax]: tag of the sweep whose record of this knot is complete
+  double* brec;      // [B][nmax][kRecDoubles]
+  int bforce;        // tests: the owner itself runs the helpers' half first (every knot but its first claim goes through a record)
+  unsigned long long* bvisits;  // [1] knots whose front half a helper (or the forced split) computed (observability; may be null)
+#if defined(DDP_TIMELINE)  // debug builds (tools/timeline.py): wall-clock stamps per trajectory and outer iteration
+  unsigned long long* tl;  // [B][32][4]: start, end of the backward sweeps, end (100 MHz), knots that came through records
+#endif
   SolveConst k;
 };
 
@@ -682,6 +709,9 @@ struct Wave {
   int N;  // segments
 #if defined(DDP_TIMING) && !defined(DIRECT_EMULATE)
   TickState tick;
+#endif
+#if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
+  int tl_split_ = 0;
 #endif
 
   DDP_DEV Wave(const Batch<St>& batch, Lds& lds, int traj) : B(batch), L(lds), st(lds.st), b(traj), N(0) {}
@@ -1390,73 +1420,246 @@ struct Wave {
   // part of R2).  Only the stepwise entry point direct_ddp_backward_pass wants them (per-pass parity tests read
   // DIRECT_FIELD_KS / KY): the forward pass eliminates them algebraically (see run_round, phase R), so the hot kernels
   // neither compute nor store nor load them - like cx, cu, Ks and Ky they are never materialised.
-  DDP_DEV int bwd_sweep() { return bwd_sweep_t<false>(); }
-  template <bool kGains>
-  DDP_DEV_NOINLINE int bwd_sweep_t() {
-    DDP_LAUNDER_S(b);
-    DDP_LAUNDER_S(N);
-    {  // regulariser schedule (DDP:452-474)
-      int reg = st.reg;
-      if (st.fp_failed || st.bp_failed) reg += 1;
-      else if (st.step == 0) reg -= 1;
-      else if (st.step > 3) reg += 1;
-      st.reg = reg < 0 ? 0 : (reg > 24 ? 24 : reg);
-    }
-    const int regi = DDP_UNIFORM_I(st.reg);
-    double lam_d = 1.0;
-    for (int q = 0; q < regi; q++) lam_d *= B.k.reg_base;
-    const Acc lam = DDP_UNIFORM_R((Acc)(lam_d - 1.0));  // DDP:529
-    const int buf = DDP_UNIFORM_I(st.cur);
-    set_sweep_ptrs(buf);
-    const int infeas = DDP_UNIFORM_I(st.infeas);
-    const Real mu = DDP_UNIFORM_R((Real)st.mu);
-    const Real wsn = (Real)B.k.w_snap;
-    const Acc sig = infeas ? (Acc)1 : (Acc)-1;
-
-    // terminal derivatives (DDP:1318-1323)
-    LANES {
-#pragma unroll 1
-      for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Acc)B.k.w_term : (Acc)0;
-      if (lane < 9) L.Vx[lane] = (Acc)B.k.w_term * (Acc)(ldx(XpU(0, N), lane) - (Real)B.xd[(size_t)b * 9 + lane]);
-    }
-    WSYNC();
-    // opterr = max(|Qu|, |r|, |c + y|) over the sweep (DDP:641): one running maximum per lane is enough
-    PLV(Real, e_mu);
-    PLV(Acc, e_qu);  // running max |Hu[j]| of lane j < 10 over the knots (DDP:633, quirk Q10: Qu after the condensation correction)
-    LANES {
-      LV(e_mu) = 0;
-      LV(e_qu) = 0;
-    }
-
-    // plane counts run two knots ahead of the sweep (the prefetch of knot k-1 needs P(k-1) for its
-    // addresses: loading it on the spot would expose one HBM round trip per knot)
-    int Pn = DDP_UNIFORM_I(npU(N - 1));
-    int Pnn = npU(N > 1 ? N - 2 : 0);
+  //
+  // One knot of the sweep is written ONCE (bwd_knot) and instantiated three ways:
+  //   MODE 0  fused: the whole knot, everything between its phases in LDS / registers - what every sweep runs when it
+  //           has no helper;
+  //   MODE 1  front: the half that does not depend on the value function (phases L, T2, the rows of R1, S, S2 and the
+  //           constraint half of H), ending in a hand-over record of six doubles per lane (BRec) instead of the condensed
+  //           system - run by HELPER waves for knots of their own (bwd_front_run), and by nobody else;
+  //   MODE 2  back: the value-dependent rest (VZ of R1, the Z'VZ half of H, C, R2) from such a record - run by the
+  //           sweep's owner for the knots helpers have prepared.
+  // The split is scheduling only: front + back perform the very operations of the fused knot in the same order (the
+  // record carries the front half's values at the point where the fused code combines them with the back half's), so the
+  // results are bitwise those of the fused sweep whoever computed what (tests/test_gpu_fullsize.py, tests/test_emu_parity.py).
+  struct BRec {  // one knot's hand-over record as ONE LANE holds it (roles of phase H):
+    Acc r[6];    //  r[0..2] the lane's three entries of the 18 x 18 block: quu -/+ A'DA (+ the velocity / acceleration rows)
+  };             //  r[3]    lanes 0..17 T column, 18..35 Hz (constraint halves); 36..53 Z = [F | G] (row c, coefficient i at
+                 //          36 + 6 c + i); 54..62 fT; 63 the knot's max |r|, |c + y| (opterr)
+                 //  r[4]    lanes 0..53 the lane's term of the (T,T) entry's wave sum; 54: quu -/+ D_last; 55: qz - g_last
+                 //  r[5]    lanes 0..53 the lane's term of Hz[T]'s wave sum
+  struct BwdCtx {  // what a run of knots carries from one knot to the next
+    int regi, buf, infeas, klo;  // klo: no prefetch below this knot (0; the bottom of a helper's chunk)
+    Acc lam, sig;
+    Real mu, wsn;
+    int Pn, Pnn;   // plane counts of the next knot and the one after (see the prefetch)
+    Acc emu_u;     // back: running maximum of the row errors of the knots that came through records
+    PLV(Real, e_mu);  // running max |r|, |c + y| of the lane's rows (DDP:641); front: of the knot
+    PLV(Acc, e_qu);   // running max |Hu[j]| of lane j < 10 (DDP:633, quirk Q10: Qu after the condensation correction)
     PLV(Pre, pre);
-    PLA(int, pkn, RPL);  // row descriptors of the prefetched knot / of the knot being processed
-    PLA(int, pkc, RPL);
-    LANES { prefetch(LV(pre), LV(pkn), 0, lane, buf, N - 1, Pn, false, infeas); }
-    // We = WbE o T-powers (rows 0..14: control points, rows 15..17: Z = [F | G]; read by phases R1, H, G) is a by-product
-    // of phase T2, which forms exactly these products on its way to the control values; the entries with a zero weight
-    // (coefficient index below the row's exponent offset) never change: cleared once per sweep (the forward pass uses
-    // the same LDS).
-    LANES {
-      L.We[lane] = (Real)0;
-      if (lane + 64 < 112) L.We[lane + 64] = (Real)0;
+    PLA(int, pkn, RPL);  // row descriptors of the prefetched knot
+    PLV(BRec, rc);       // back: the knot's record; front: the record being formed
+  };
+#ifndef DDP_KSPLIT
+#define DDP_KSPLIT (RPL <= 4)
+#endif
+  static constexpr bool kSplit = DDP_KSPLIT;  // the helper-assisted sweep is built for the narrow classes only (long trajectories: N >= 80)
+
+  // -- the share protocol (wave-uniform; lane 0 performs the atomics).  Every transition of BwdShare::word is an atomic
+  // RMW, so owner and helpers need no fences between them: open = add (tag << 8), enter = add 1 and look at the old tag,
+  // close = and 0xff and look at the old count.  Records and flags are written through (sc1) and drained (vmcnt(0))
+  // before the flag, and read with sc1 loads issued only after the flag has been seen (MI355X_MICROARCH.md, hand-off forms).
+  DDP_DEV BwdShare* bshare_slot() const { return (kSplit && B.bshare) ? &B.bshare[b] : nullptr; }
+  DDP_DEV double* rec_ptr(int k) const { return B.brec + ((size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k)) * kRecDoubles; }
+  DDP_DEV int* flag_ptr(int k) const { return B.bflag + (size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k); }
+#if !defined(DIRECT_EMULATE)
+  typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+  typedef double D2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  DDP_DEV void rec_store(int k, const BRec& r, int lane) const {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec_ptr(k), 0, kRecDoubles * 8, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      D2 v;
+      v.x = r.r[2 * p];
+      v.y = r.r[2 * p + 1];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, v), rs, (p * 64 + lane) * 16, 0, 16 /* sc1 */);
     }
-    WSYNC();
-#pragma unroll 1
-    for (int k_ = N - 1; k_ >= 0; k_--) {
+  }
+  DDP_DEV void rec_load(int k, BRec& r, int lane) const {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec_ptr(k), 0, kRecDoubles * 8, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const D2 v = __builtin_bit_cast(D2, __builtin_amdgcn_raw_buffer_load_b128(rs, (p * 64 + lane) * 16, 0, 16 /* sc1 */));
+      r.r[2 * p] = v.x;
+      r.r[2 * p + 1] = v.y;
+    }
+  }
+  DDP_DEV void flag_set(int k, int tag) const {
+    drain_stores();
+    a_store(flag_ptr(k), tag);
+  }
+  // the flag of knot k as a per-lane value (every lane loads the same word: one transaction, nothing waits here)
+  DDP_DEV int flag_peek(int k) const { return __hip_atomic_load(flag_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  DDP_DEV int flag_wait(int k, int tag) const {
+    int spins = 0;
+    while (a_load(flag_ptr(k)) != tag) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) {
+        proto_error();
+        return 0;
+      }
+    }
+    return 1;
+  }
+  static __device__ __forceinline__ unsigned long long a_add64(unsigned long long* p, unsigned long long v) {
+    unsigned long long o = 0;
+    if (threadIdx.x == 0) o = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)o);
+  }
+  // owner: open the sweep around iterate buffer `cur`; knots [kfloor, N) are the owner's first claim.  Returns the tag.
+  DDP_DEV int bs_open(BwdShare* bs, int cur, int infeas, double mu, int kfloor) {
+    int seq = 0;
+    if (threadIdx.x == 0) {
+      seq = bs->seq + 1;
+      bs->seq = seq;
+      __hip_atomic_store(&bs->cur, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&bs->infeas, infeas, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((unsigned long long*)&bs->mu, (unsigned long long)__double_as_longlong(mu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&bs->claim, ((kClaimBias + (unsigned long long)kfloor) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    seq = __builtin_amdgcn_readfirstlane(seq) & 0xffffff;
+    if (seq == 0) seq = 1;
+    drain_stores();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&bs->word, (unsigned)seq << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return seq;
+  }
+  // owner: close it and wait until no helper is inside (they finish the chunk they hold; nothing of theirs is awaited)
+  DDP_DEV void bs_close(BwdShare* bs) {
+    unsigned o = 0;
+    if (threadIdx.x == 0) o = __hip_atomic_fetch_and(&bs->word, 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int inside = __builtin_amdgcn_readfirstlane((int)(o & 0xffu));
+    int spins = 0;
+    while (inside) {
+      __builtin_amdgcn_s_sleep(2);
+      inside = a_load((int*)&bs->word) & 0xff;
+      if (++spins > (1 << 22)) {
+        proto_error();
+        break;
+      }
+    }
+  }
+  DDP_DEV int bs_tag(BwdShare* bs) const { return (int)((unsigned)a_load((int*)&bs->word) >> 8); }
+  // helper: join the open sweep of trajectory b, if there is one
+  DDP_DEV int bs_enter(BwdShare* bs, int& tag, int& cur, int& infeas, double& mu) {
+    unsigned o = 0;
+    if (threadIdx.x == 0) o = __hip_atomic_fetch_add(&bs->word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tag = __builtin_amdgcn_readfirstlane((int)(o >> 8));
+    if (!tag) {
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(&bs->word, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the iterate: released by whoever wrote it before the owner's ticket was ready
+    int cv = 0, iv = 0, ml = 0, mh = 0;
+    if (threadIdx.x == 0) {
+      cv = __hip_atomic_load(&bs->cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      iv = __hip_atomic_load(&bs->infeas, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long m = __hip_atomic_load((unsigned long long*)&bs->mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ml = (int)m;
+      mh = (int)(m >> 32);
+    }
+    cur = __builtin_amdgcn_readfirstlane(cv);
+    infeas = __builtin_amdgcn_readfirstlane(iv);
+    mu = __hiloint2double(__builtin_amdgcn_readfirstlane(mh), __builtin_amdgcn_readfirstlane(ml));
+    return 1;
+  }
+  DDP_DEV void bs_leave(BwdShare* bs) {
+    drain_stores();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&bs->word, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // helper: the next kHelpChunk free knots from below -> [k0, k1), empty when none are left
+  DDP_DEV void bs_claim_low(BwdShare* bs, int& k0, int& k1) {
+    const unsigned long long o = a_add64(&bs->claim, (unsigned long long)kHelpChunk);
+    const long long lo = (long long)(o & 0xffffffffull), hi = (long long)(o >> 32) - (long long)kClaimBias;
+    k0 = (int)lo;
+    k1 = (int)(lo + kHelpChunk < hi ? lo + kHelpChunk : hi);
+  }
+  // owner: take kOwnChunk more knots from above; the answer (the old claim word) is looked at a chunk later
+  struct Pend {
+    unsigned lo, hi;  // per-lane halves of lane 0's returned word
+  };
+  DDP_DEV void bs_claim_high_issue(BwdShare* bs, Pend& pd) {
+    unsigned long long o = 0;
+    if (threadIdx.x == 0) o = __hip_atomic_fetch_add(&bs->claim, 0ull - ((unsigned long long)kOwnChunk << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pd.lo = (unsigned)o;
+    pd.hi = (unsigned)(o >> 32);
+  }
+  DDP_DEV int bs_claim_high_low(const Pend& pd) const {  // how many knots the helpers had taken from below at that moment
+    return __builtin_amdgcn_readfirstlane((int)pd.lo);
+  }
+#else  // the emulator runs one wave: the same bookkeeping on plain memory (forced split only)
+  DDP_DEV void rec_store(int k, const BRec& r, int lane) const {
+    double* p = rec_ptr(k);
+    for (int q = 0; q < 3; q++) {
+      p[(q * 64 + lane) * 2] = r.r[2 * q];
+      p[(q * 64 + lane) * 2 + 1] = r.r[2 * q + 1];
+    }
+  }
+  DDP_DEV void rec_load(int k, BRec& r, int lane) const {
+    const double* p = rec_ptr(k);
+    for (int q = 0; q < 3; q++) {
+      r.r[2 * q] = p[(q * 64 + lane) * 2];
+      r.r[2 * q + 1] = p[(q * 64 + lane) * 2 + 1];
+    }
+  }
+  DDP_DEV void flag_set(int k, int tag) const { *flag_ptr(k) = tag; }
+  DDP_DEV int flag_peek(int k) const { return *flag_ptr(k); }
+  DDP_DEV int flag_wait(int k, int tag) const { return *flag_ptr(k) == tag; }
+  DDP_DEV int bs_open(BwdShare* bs, int cur, int infeas, double mu, int kfloor) {
+    bs->seq++;
+    bs->cur = cur;
+    bs->infeas = infeas;
+    bs->mu = mu;
+    bs->claim = (kClaimBias + (unsigned long long)kfloor) << 32;
+    bs->word += (unsigned)bs->seq << 8;
+    return bs->seq;
+  }
+  DDP_DEV void bs_close(BwdShare* bs) { bs->word &= 0xffu; }
+  DDP_DEV int bs_tag(BwdShare* bs) const { return (int)(bs->word >> 8); }
+  DDP_DEV int bs_enter(BwdShare*, int&, int&, int&, double&) { return 0; }
+  DDP_DEV void bs_leave(BwdShare*) {}
+  DDP_DEV void bs_claim_low(BwdShare* bs, int& k0, int& k1) {
+    const unsigned long long o = bs->claim;
+    bs->claim += (unsigned long long)kHelpChunk;
+    const long long lo = (long long)(o & 0xffffffffull), hi = (long long)(o >> 32) - (long long)kClaimBias;
+    k0 = (int)lo;
+    k1 = (int)(lo + kHelpChunk < hi ? lo + kHelpChunk : hi);
+  }
+  struct Pend {
+    unsigned lo, hi;
+  };
+  DDP_DEV void bs_claim_high_issue(BwdShare* bs, Pend& pd) {
+    const unsigned long long o = bs->claim;
+    bs->claim -= (unsigned long long)kOwnChunk << 32;
+    pd.lo = (unsigned)o;
+    pd.hi = (unsigned)(o >> 32);
+  }
+  DDP_DEV int bs_claim_high_low(const Pend& pd) const { return (int)pd.lo; }
+#endif
+
+  DDP_DEV int bwd_sweep() { return bwd_sweep_t<false>(); }
+
+  // ---- one knot of the backward sweep (see above for MODE) -----------------------------------------------------
+  template <int MODE, bool kGains>
+  DDP_DEV int bwd_knot(BwdCtx& C, int k_) {
+    constexpr bool kF = MODE != 2, kB = MODE != 1;  // the knot's front / back half is part of this instantiation
+    {
       // the knot index is re-materialised every trip: as a visible induction variable it makes loop
       // strength reduction keep one 64-bit pointer PER ARRAY live (and spilled) across the whole body
       int k = k_;
+      if constexpr (MODE == 2) k = DDP_UNIFORM_I(k_);  // a loop behind a loop with several exits: the counter may not be provably uniform
       DDP_LAUNDER_S(k);
-      const int P = Pn;
+      const int regi = C.regi, infeas = C.infeas, buf = C.buf;
+      const Acc lam = C.lam, sig = C.sig;
+      const Real mu = C.mu, wsn = C.wsn;
+      const int P = C.Pn;
       const int nc = 6 * P + 55;
+      (void)nc; (void)mu; (void)buf; (void)lam; (void)wsn; (void)sig;
       PLA(Real, rs, RPL);
       PLA(Real, ry, RPL);
       PLA(Real, rc, RPL);
       PLA(Real, rr, RPL);  // r (feasible) or rhat (infeasible)
+      PLA(int, pkc, RPL);  // row descriptors of the knot being processed
       // Per-lane role descriptors (init_tables), each loaded ONE PHASE AHEAD of its use: a descriptor that is read in
       // the phase that needs it puts a second LDS round trip (descriptor, then the operands it addresses) on the
       // phase's critical path, and with three waves per SIMD those round trips are what the waves park on
@@ -1468,319 +1671,382 @@ struct Wave {
       PLA(int, tw_hv, 3);
       PLV(int, tw_r2);
       DDP_MARK("B_L");
-      // ---- L: this knot's data from the prefetch registers; issue the loads of the next knot
-      LANES {
-        LV(tw_t2) = L.lt[7][lane];
-        commit(LV(pre), lane, P, false);
-        for (int i = 0; i < RPL; i++) {
-          LV(pkc)[i] = LV(pkn)[i];
-          if (!slot_on(i, P)) continue;
-          LV(rs)[i] = (Real)LV(pre).s[i];
-          LV(ry)[i] = infeas ? (Real)LV(pre).y[i] : (Real)1;
+      Real T = (Real)0;
+      (void)T;
+      if constexpr (kF) {
+        // ---- L: this knot's data from the prefetch registers; issue the loads of the next knot
+        LANES {
+          LV(tw_t2) = L.lt[7][lane];
+          commit(LV(C.pre), lane, P, false);
+          for (int i = 0; i < RPL; i++) {
+            LV(pkc)[i] = LV(C.pkn)[i];
+            if (!slot_on(i, P)) continue;
+            LV(rs)[i] = (Real)LV(C.pre).s[i];
+            LV(ry)[i] = infeas ? (Real)LV(C.pre).y[i] : (Real)1;
+          }
+          if constexpr (MODE == 1) LV(C.e_mu) = 0;  // front: the knot's own maximum goes into its record
         }
-      }
-      // the segment time straight from lane 18's prefetch registers (hi + lo with float storage, see ldx()):
-      // the T-dependent tables then need no LDS round trip and share this phase
-      const Real T = (sizeof(St) < sizeof(double)) ? (Real)RDLANE_M(pre, zh, 18) + (Real)RDLANE_M(pre, zl, 18) : (Real)RDLANE_M(pre, zh, 18);
-      if (k > 0) {
-        Pn = DDP_UNIFORM_I(Pnn);
-        Pnn = npU(k > 1 ? k - 2 : 0);
-        const int same = (Pn == P) ? 1 : 0;
-        LANES { prefetch(LV(pre), LV(pkn), same, lane, buf, k - 1, Pn, false, infeas); }
-      }
-      WSYNC();
-      DDP_MARK("B_T2");
-      // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u (all lanes run all roles, clamped)
-      const Real T2 = DDP_UNIFORM_R(T * T), T4 = DDP_UNIFORM_R(T2 * T2);
-      Real pw[6];  // T^j as wave-uniform operands
-#pragma unroll
-      for (int j = 0; j < 6; j++) pw[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(T, T2, T4, j));
-      LANES {
-        // One code path for 21 table rows x 3 axes (lanes 0..62, see ctrl_off()): rows 0..14 give the control
-        // values and their d/dT; rows 15..17 give fT = (F' (x) I) x + (G' (x) I) u as the d/dT value
-        // (DDP:1332); rows 18..20 give R u, R'u and R''u (DDP:1349-1355) as value, first and second derivative.
-        // summed over the exponent j = i - o (see fwd_pass, phase T): uniform powers, no table reads.  lt[7]: byte
-        // offsets of the row's first live weight WbE[cr][o] and of z[3 o + d], and o; terms past the end of the
-        // row (j + o > 5) read a zero weight (WbE[108] = WdE[108] = 0) against a finite z (z[19..23] = 0)
-        const int w2 = LV(tw_t2);
-#pragma unroll
-        for (int pass = 0; pass < 3; pass++) LV(tw_r1)[pass] = L.lt[4 + pass][lane];
-        const int wbb = w2 & 1023, o = (w2 >> 17) & 3;
-        const Real* zb = byte_at(L.z, (w2 >> 10) & 127);
-        Real v = 0, dv = 0, ddv = 0, z6[6], wb6[6], wd6[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          const int wa = (j < 4 || j + o < 6) ? wbb + j * (int)sizeof(Real) : 108 * (int)sizeof(Real);
-          wb6[j] = *byte_at(L.WbE, wa);
-          wd6[j] = *byte_at(L.WdE, wa);
-          z6[j] = zb[3 * j];
+        // the segment time straight from lane 18's prefetch registers (hi + lo with float storage, see ldx()):
+        // the T-dependent tables then need no LDS round trip and share this phase
+        T = (sizeof(St) < sizeof(double)) ? (Real)RDLANE_M(C.pre, zh, 18) + (Real)RDLANE_M(C.pre, zl, 18) : (Real)RDLANE_M(C.pre, zh, 18);
+        if (k > C.klo) {
+          C.Pn = DDP_UNIFORM_I(C.Pnn);
+          C.Pnn = npU(k > 1 ? k - 2 : 0);
+          const int same = (C.Pn == P) ? 1 : 0;
+          LANES { prefetch(LV(C.pre), LV(C.pkn), same, lane, buf, k - 1, C.Pn, false, infeas); }
         }
-        DDP_LOADS_ISSUED();
-        // the lane's products weight x power of T ARE entries of We (rows 0..17, axis-0 lanes): stored on the way, the
-        // others go to the dump slot behind the table; the powers of T themselves go to L.tp (read by phase H)
-        Real* const wst = byte_at(L.We, ((unsigned)w2 >> 19) & 1023);
-        const int nst = (int)((unsigned)w2 >> 29);
-        L.tp[lane & 7] = pow3(T, T2, T4, lane & 7);
+      } else {
+        // ---- L (back): Z = [F | G] and fT of the knot from its record; the row errors' maximum
+        LANES {
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          const Real pj = wb6[j] * pw[j];  // We[cr][o + j]
-          *(j < nst ? wst + 18 * j : &L.We[108]) = pj;
-          v += pj * z6[j];
-          dv += wd6[j] * pw[j < 1 ? 0 : j - 1] * z6[j];
-          if (j >= 2) ddv += (wd6[j] * (Real)(j - 1)) * pw[j - 2] * z6[j];  // only read for rows 18..20
+          for (int pass = 0; pass < 3; pass++) LV(tw_r1)[pass] = L.lt[4 + pass][lane];
+          const Acc v = LV(C.rc).r[3];
+          if (lane >= 36 && lane < 54) {
+            const int j = lane - 36;
+            L.We[we_idx(15 + j / 6, j % 6)] = (Real)v;
+          }
+          if (lane >= 54 && lane < 63) L.fT[lane - 54] = v;
         }
-        if (lane < 45) {
-          L.val[lane] = v;
-          L.dval[lane] = dv;
-        } else if (lane < 54) {
-          L.fT[lane - 45] = dv;
-        } else if (lane < 63) {
-          L.Ru[lane - 54] = v;
-          L.Rpu[lane - 54] = dv;
-          L.Rppu[lane - 54] = ddv;
-        } else {
-          L.val[45] = T;
-        }
+        C.emu_u = fmax(C.emu_u, (Acc)RDLANE_M(C.rc, r[3], 63));
       }
       WSYNC();
+      if constexpr (kF) {
+        DDP_MARK("B_T2");
+        // ---- T2: control values and their d/dT, fT, Ru / R'u / R''u (all lanes run all roles, clamped)
+        const Real T2 = DDP_UNIFORM_R(T * T), T4 = DDP_UNIFORM_R(T2 * T2);
+        Real pw[6];  // T^j as wave-uniform operands
+#pragma unroll
+        for (int j = 0; j < 6; j++) pw[j] = (j == 0) ? (Real)1 : DDP_UNIFORM_R(pow3(T, T2, T4, j));
+        LANES {
+          // One code path for 21 table rows x 3 axes (lanes 0..62, see ctrl_off()): rows 0..14 give the control
+          // values and their d/dT; rows 15..17 give fT = (F' (x) I) x + (G' (x) I) u as the d/dT value
+          // (DDP:1332); rows 18..20 give R u, R'u and R''u (DDP:1349-1355) as value, first and second derivative.
+          // summed over the exponent j = i - o (see fwd_pass, phase T): uniform powers, no table reads.  lt[7]: byte
+          // offsets of the row's first live weight WbE[cr][o] and of z[3 o + d], and o; terms past the end of the
+          // row (j + o > 5) read a zero weight (WbE[108] = WdE[108] = 0) against a finite z (z[19..23] = 0)
+          const int w2 = LV(tw_t2);
+          if constexpr (kB) {
+#pragma unroll
+            for (int pass = 0; pass < 3; pass++) LV(tw_r1)[pass] = L.lt[4 + pass][lane];
+          }
+          const int wbb = w2 & 1023, o = (w2 >> 17) & 3;
+          const Real* zb = byte_at(L.z, (w2 >> 10) & 127);
+          Real v = 0, dv = 0, ddv = 0, z6[6], wb6[6], wd6[6];
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            const int wa = (j < 4 || j + o < 6) ? wbb + j * (int)sizeof(Real) : 108 * (int)sizeof(Real);
+            wb6[j] = *byte_at(L.WbE, wa);
+            wd6[j] = *byte_at(L.WdE, wa);
+            z6[j] = zb[3 * j];
+          }
+          DDP_LOADS_ISSUED();
+          // the lane's products weight x power of T ARE entries of We (rows 0..17, axis-0 lanes): stored on the way, the
+          // others go to the dump slot behind the table; the powers of T themselves go to L.tp (read by phase H)
+          Real* const wst = byte_at(L.We, ((unsigned)w2 >> 19) & 1023);
+          const int nst = (int)((unsigned)w2 >> 29);
+          L.tp[lane & 7] = pow3(T, T2, T4, lane & 7);
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            const Real pj = wb6[j] * pw[j];  // We[cr][o + j]
+            *(j < nst ? wst + 18 * j : &L.We[108]) = pj;
+            v += pj * z6[j];
+            dv += wd6[j] * pw[j < 1 ? 0 : j - 1] * z6[j];
+            if (j >= 2) ddv += (wd6[j] * (Real)(j - 1)) * pw[j - 2] * z6[j];  // only read for rows 18..20
+          }
+          if (lane < 45) {
+            L.val[lane] = v;
+            L.dval[lane] = dv;
+          } else if (lane < 54) {
+            L.fT[lane - 45] = dv;
+          } else if (lane < 63) {
+            L.Ru[lane - 54] = v;
+            L.Rpu[lane - 54] = dv;
+            L.Rppu[lane - 54] = ddv;
+          } else {
+            L.val[45] = T;
+          }
+        }
+        WSYNC();
+      }
       DDP_MARK("B_R1");
-      // ---- R1: constraint rows -> D, g ; VZ = Vxx * Z
+      // ---- R1: constraint rows -> D, g (front) ; VZ = Vxx * Z (back)
       LANES {
-        LV(tw_s) = L.lt16[1][lane];
-        RowK<Real> rk1[RPL];
-        Row3 ov1[RPL];
+        if constexpr (kF) {
+          LV(tw_s) = L.lt16[1][lane];
+          RowK<Real> rk1[RPL];
+          Row3 ov1[RPL];
 #pragma unroll
-        for (int i = 0; i < RPL; i++) {
-          if (!slot_on(i, P)) continue;
-          rk1[i] = row_unpack2(LV(pkc)[i]);
-          ov1[i] = row_ops(L.val, LV(pkc)[i]);
-        }
-        DDP_LOADS_ISSUED();
-#pragma unroll
-        for (int i = 0; i < RPL; i++) {
-          if (!slot_on(i, P)) continue;
-          // every lane runs the row arithmetic (empty slots alias row 0); only the stores and the
-          // running maxima are masked
-          const RowK<Real>& rk = rk1[i];
-          const int r = rk.r;
-          const bool in = r >= 0;
-          Real c = row_dot(rk, ov1[i]) + rk.o - (Real)B.k.shift, s = LV(rs)[i], y = LV(ry)[i];
-          Real D, g, rv, frcp_reuse = (Real)0;
-          if (infeas) {  // DDP:535-539, 554
-            Real rm = s * y - mu;
-            rv = s * (c + y) - rm;  // rhat
-            Real yinv = frcp(y);
-            D = s * yinv;
-            g = s + yinv * rv;
-            LV(e_mu) = fmax(LV(e_mu), in ? fmax(fabs(rm), fabs(c + y)) : (Real)0);
-          } else {  // DDP:583-587, 601
-            rv = s * c + mu;
-            Real cinv = frcp(c);
-            frcp_reuse = cinv;
-            D = s * cinv;
-            g = -mu * cinv;  // s - r/c
-            LV(e_mu) = fmax(LV(e_mu), in ? fabs(rv) : (Real)0);
-          }
-          if constexpr (kGains) {
-            // for phase R2: infeasible mode needs c and rhat; feasible mode only the two quotients r / c and s / c, so
-            // that the slack gain ks = -(r + s cu ku) / c costs no second reciprocal there
-            LV(rc)[i] = infeas ? c : D;
-            LV(rr)[i] = infeas ? rv : rv * frcp_reuse;
-          }
-          if (in) {
-            L.drow[r] = (Acc)D;
-            L.grow[r] = (Acc)g;
-          }
-        }
-#pragma unroll
-        for (int pass = 0; pass < 3; pass++) {  // VZ[a][q], q < 18: 162 three-term entries (idle lanes redo the last)
-          const int wz = LV(tw_r1)[pass];  // byte offsets: V[a][d] | We[row 15][i] << 10 | VZ[a][q] << 20 (loaded in phase T2)
-          const Acc* vp = byte_at(L.V, wz & 1023);
-          const Real* hp = byte_at(L.We, (wz >> 10) & 1023);
-          Acc v3[3];
-          Real h3[3];
-#pragma unroll
-          for (int c = 0; c < 3; c++) v3[c] = vp[3 * c];
-          h3[0] = hp[0];
-          ld2(hp + 1, h3[1], h3[2]);  // rows 16, 17
-          DDP_LOADS_ISSUED();
-          Acc acc = 0;
-#pragma unroll
-          for (int c = 0; c < 3; c++) acc += v3[c] * h3[c];
-          *byte_at(L.VZ, (wz >> 20) & 2047) = acc;
-        }
-        if (lane >= 34 && lane < 43) {  // the T column VZ[a][18] = V[a][:] . fT on lanes the third pass leaves idle
-          const int a = lane - 34;
-          Acc v9[9], f9[9];
-#pragma unroll
-          for (int c = 0; c < 9; c++) {
-            v9[c] = L.V[a * 9 + c];
-            f9[c] = L.fT[c];
+          for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
+            rk1[i] = row_unpack2(LV(pkc)[i]);
+            ov1[i] = row_ops(L.val, LV(pkc)[i]);
           }
           DDP_LOADS_ISSUED();
-          Acc acc = 0;
 #pragma unroll
-          for (int c = 0; c < 9; c++) acc += v9[c] * f9[c];
-          L.VZ[a * 19 + 18] = acc;
+          for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
+            // every lane runs the row arithmetic (empty slots alias row 0); only the stores and the
+            // running maxima are masked
+            const RowK<Real>& rk = rk1[i];
+            const int r = rk.r;
+            const bool in = r >= 0;
+            Real c = row_dot(rk, ov1[i]) + rk.o - (Real)B.k.shift, s = LV(rs)[i], y = LV(ry)[i];
+            Real D, g, rv, frcp_reuse = (Real)0;
+            if (infeas) {  // DDP:535-539, 554
+              Real rm = s * y - mu;
+              rv = s * (c + y) - rm;  // rhat
+              Real yinv = frcp(y);
+              D = s * yinv;
+              g = s + yinv * rv;
+              LV(C.e_mu) = fmax(LV(C.e_mu), in ? fmax(fabs(rm), fabs(c + y)) : (Real)0);
+            } else {  // DDP:583-587, 601
+              rv = s * c + mu;
+              Real cinv = frcp(c);
+              frcp_reuse = cinv;
+              D = s * cinv;
+              g = -mu * cinv;  // s - r/c
+              LV(C.e_mu) = fmax(LV(C.e_mu), in ? fabs(rv) : (Real)0);
+            }
+            if constexpr (kGains) {
+              // for phase R2: infeasible mode needs c and rhat; feasible mode only the two quotients r / c and s / c, so
+              // that the slack gain ks = -(r + s cu ku) / c costs no second reciprocal there
+              LV(rc)[i] = infeas ? c : D;
+              LV(rr)[i] = infeas ? rv : rv * frcp_reuse;
+            }
+            if (in) {
+              L.drow[r] = (Acc)D;
+              L.grow[r] = (Acc)g;
+            }
+          }
+        } else {
+          // (back) the role descriptors of phase H, a phase ahead as in the fused knot's phase S2
+          LV(tw_h0) = L.lt[0][lane];
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            LV(tw_ho)[t] = L.lt[1 + t][lane];
+            LV(tw_hv)[t] = L.lt16[2 + t][lane];
+          }
         }
-      }
-      WSYNC();
-      DDP_MARK("B_S");
-      // ---- S: 3x3 accumulators per control row.  Every lane runs every role on a clamped index: idle
-      // lanes recompute (and re-store) a neighbour's value, which costs no extra instruction in SIMT and
-      // removes the exec-mask bookkeeping of role branches.
-      LANES {
-        {  // lanes 0..35: S_j[d0][d1] = sum_q D_(jP+q) n_q[d0] n_q[d1]; lanes 36..53: h_j[d0] = sum_q g_(jP+q) n_q[d0] * 1
-          const int ws = LV(tw_s);  // (loaded in phase R1) d0 | d1 << 2 | isS << 4 | j << 5 | destination (doubles from Sp[0]) << 8
-          const bool isS = (ws >> 4) & 1;
-          const Acc* w = (isS ? L.drow : L.grow) + ((ws >> 5) & 7) * P;
-          const Real* n0 = &L.pl[ws & 3];
-          const Real* nf = isS ? &L.pl[(ws >> 2) & 3] : &L.ones[0];
-          const int fstep = isS ? 4 : 0;
-          Acc acc = 0;
-          int q = 0;
-#pragma unroll 1
-          for (; q + 6 <= P; q += 6) {  // six planes per trip: eighteen loads in flight before the first FMA (P >= 6 for every
-                                        // corridor the planner produces: a polytope of its decomposition has at least six faces)
-            Acc w6[6];
-            Real a6[6], f6[6];
+        if constexpr (kB) {
 #pragma unroll
-            for (int u = 0; u < 6; u++) {
-              w6[u] = w[q + u];
-              a6[u] = n0[4 * (q + u)];
-              f6[u] = nf[fstep * (q + u)];
+          for (int pass = 0; pass < 3; pass++) {  // VZ[a][q], q < 18: 162 three-term entries (idle lanes redo the last)
+            const int wz = LV(tw_r1)[pass];  // byte offsets: V[a][d] | We[row 15][i] << 10 | VZ[a][q] << 20 (loaded a phase ahead)
+            const Acc* vp = byte_at(L.V, wz & 1023);
+            const Real* hp = byte_at(L.We, (wz >> 10) & 1023);
+            Acc v3[3];
+            Real h3[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) v3[c] = vp[3 * c];
+            h3[0] = hp[0];
+            ld2(hp + 1, h3[1], h3[2]);  // rows 16, 17
+            DDP_LOADS_ISSUED();
+            Acc acc = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc += v3[c] * h3[c];
+            *byte_at(L.VZ, (wz >> 20) & 2047) = acc;
+          }
+          if (lane >= 34 && lane < 43) {  // the T column VZ[a][18] = V[a][:] . fT on lanes the third pass leaves idle
+            const int a = lane - 34;
+            Acc v9[9], f9[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+              v9[c] = L.V[a * 9 + c];
+              f9[c] = L.fT[c];
             }
             DDP_LOADS_ISSUED();
+            Acc acc = 0;
 #pragma unroll
-            for (int u = 0; u < 6; u++) acc += w6[u] * a6[u] * f6[u];
+            for (int c = 0; c < 9; c++) acc += v9[c] * f9[c];
+            L.VZ[a * 19 + 18] = acc;
           }
-#pragma unroll 2
-          for (; q < P; q++) acc += w[q] * n0[4 * q] * nf[fstep * q];
-          (&L.Sp[0])[(ws >> 8) & 255] = acc;
         }
-        {  // velocity / acceleration rows: +/- pairs
-          const int lq = lane < 27 ? lane : 26;
-          const int d9 = lq / 9, cp9 = lq - 9 * d9;  // lq = 9 axis + control point: consecutive lanes store consecutive words
-          const int l27 = 3 * cp9 + d9;                     // the row's number among the 27: 3 (control point) + axis
-          const int rp = 6 * P + (l27 < 15 ? l27 : 15 + l27);  // 6P + l | 6P + 30 + (l - 15)
-          const int rm = rp + (l27 < 15 ? 15 : 12);
-          L.dl[dl_idx(cp9, d9)] = L.drow[rp] + L.drow[rm];
-          L.hh[ch_idx(6 + cp9, d9)] = L.grow[rp] - L.grow[rm];
-        }
-        L.last[0] = L.drow[nc - 1];
-        L.last[1] = L.grow[nc - 1];
       }
       WSYNC();
-      DDP_MARK("B_S2");
-      // ---- S2: Sd = S_cr * dval[cr]
-      LANES {
-        LV(tw_h0) = L.lt[0][lane];
+      if constexpr (kF) {
+        DDP_MARK("B_S");
+        // ---- S: 3x3 accumulators per control row.  Every lane runs every role on a clamped index: idle
+        // lanes recompute (and re-store) a neighbour's value, which costs no extra instruction in SIMT and
+        // removes the exec-mask bookkeeping of role branches.
+        LANES {
+          {  // lanes 0..35: S_j[d0][d1] = sum_q D_(jP+q) n_q[d0] n_q[d1]; lanes 36..53: h_j[d0] = sum_q g_(jP+q) n_q[d0] * 1
+            const int ws = LV(tw_s);  // (loaded in phase R1) d0 | d1 << 2 | isS << 4 | j << 5 | destination (doubles from Sp[0]) << 8
+            const bool isS = (ws >> 4) & 1;
+            const Acc* w = (isS ? L.drow : L.grow) + ((ws >> 5) & 7) * P;
+            const Real* n0 = &L.pl[ws & 3];
+            const Real* nf = isS ? &L.pl[(ws >> 2) & 3] : &L.ones[0];
+            const int fstep = isS ? 4 : 0;
+            Acc acc = 0;
+            int q = 0;
+#pragma unroll 1
+            for (; q + 6 <= P; q += 6) {  // six planes per trip: eighteen loads in flight before the first FMA (P >= 6 for every
+                                          // corridor the planner produces: a polytope of its decomposition has at least six faces)
+              Acc w6[6];
+              Real a6[6], f6[6];
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-          LV(tw_ho)[t] = L.lt[1 + t][lane];
-          LV(tw_hv)[t] = L.lt16[2 + t][lane];
+              for (int u = 0; u < 6; u++) {
+                w6[u] = w[q + u];
+                a6[u] = n0[4 * (q + u)];
+                f6[u] = nf[fstep * (q + u)];
+              }
+              DDP_LOADS_ISSUED();
+#pragma unroll
+              for (int u = 0; u < 6; u++) acc += w6[u] * a6[u] * f6[u];
+            }
+#pragma unroll 2
+            for (; q < P; q++) acc += w[q] * n0[4 * q] * nf[fstep * q];
+            (&L.Sp[0])[(ws >> 8) & 255] = acc;
+          }
+          {  // velocity / acceleration rows: +/- pairs
+            const int lq = lane < 27 ? lane : 26;
+            const int d9 = lq / 9, cp9 = lq - 9 * d9;  // lq = 9 axis + control point: consecutive lanes store consecutive words
+            const int l27 = 3 * cp9 + d9;                     // the row's number among the 27: 3 (control point) + axis
+            const int rp = 6 * P + (l27 < 15 ? l27 : 15 + l27);  // 6P + l | 6P + 30 + (l - 15)
+            const int rm = rp + (l27 < 15 ? 15 : 12);
+            L.dl[dl_idx(cp9, d9)] = L.drow[rp] + L.drow[rm];
+            L.hh[ch_idx(6 + cp9, d9)] = L.grow[rp] - L.grow[rm];
+          }
+          L.last[0] = L.drow[nc - 1];
+          L.last[1] = L.grow[nc - 1];
         }
-        const int lq = lane < 45 ? lane : 44;
-        const int d = lq / 15, cr = lq - 15 * d;  // row-fastest roles: consecutive lanes store consecutive words of Sd
-        const int l45 = 3 * cr + d;
-        const int crp = cr < 6 ? cr : 5;
-        const Acc* S = &L.Sp[sp_idx(crp, 0)];  // entries xx,xy,xz,yy,yz,zz of control point crp, six apart
-        const Real* dv = &L.dval[crp * 3];
-        // row d of the symmetric 3x3: (0,1,2) | (1,3,4) | (2,4,5)
-        const int i0 = d, i1 = d == 0 ? 1 : (d == 1 ? 3 : 4), i2 = d == 2 ? 5 : (d == 1 ? 4 : 2);
-        const Acc pos = S[6 * i0] * dv[0] + S[6 * i1] * dv[1] + S[6 * i2] * dv[2];
-        const Acc oth = L.dl[dl_idx(cr < 6 ? 0 : cr - 6, d)] * L.dval[l45];
-        L.Sd[ch_idx(cr, d)] = cr < 6 ? pos : oth;
+        WSYNC();
+        DDP_MARK("B_S2");
+        // ---- S2: Sd = S_cr * dval[cr]
+        LANES {
+          LV(tw_h0) = L.lt[0][lane];
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            LV(tw_ho)[t] = L.lt[1 + t][lane];
+            LV(tw_hv)[t] = L.lt16[2 + t][lane];
+          }
+          const int lq = lane < 45 ? lane : 44;
+          const int d = lq / 15, cr = lq - 15 * d;  // row-fastest roles: consecutive lanes store consecutive words of Sd
+          const int l45 = 3 * cr + d;
+          const int crp = cr < 6 ? cr : 5;
+          const Acc* S = &L.Sp[sp_idx(crp, 0)];  // entries xx,xy,xz,yy,yz,zz of control point crp, six apart
+          const Real* dv = &L.dval[crp * 3];
+          // row d of the symmetric 3x3: (0,1,2) | (1,3,4) | (2,4,5)
+          const int i0 = d, i1 = d == 0 ? 1 : (d == 1 ? 3 : 4), i2 = d == 2 ? 5 : (d == 1 ? 4 : 2);
+          const Acc pos = S[6 * i0] * dv[0] + S[6 * i1] * dv[1] + S[6 * i2] * dv[2];
+          const Acc oth = L.dl[dl_idx(cr < 6 ? 0 : cr - 6, d)] * L.dval[l45];
+          L.Sd[ch_idx(cr, d)] = cr < 6 ? pos : oth;
+        }
+        WSYNC();
       }
-      WSYNC();
       DDP_MARK("B_H");
       // ---- H: assemble the 19x19 system  Hzz = Z'VZ + quu -/+ A'DA,  Hz = qz + Z'Vx + A'g
       // The 18x18 block, p <= q.  A lane owns one (i, i2 >= i) pair of control points and one axis d and
       // walks the three axes d2 of the column: the twelve We operands, their products and the three H
       // operands are loaded once for three entries, and the velocity / acceleration rows (which only touch
       // d2 == d) need no second pass over the stored block.
+      // Every entry is  (value half: Z'VZ, back)  +  (constraint half: quu -/+ A'DA ..., front)  with the constraint
+      // half complete BEFORE the one addition that joins them: that value is what a record hands over.
       LANES {
-        const int w0 = LV(tw_h0);  // (loaded in phase S2) byte offsets of We[.][i] | We[.][i2] << 10 | dl[.][d] << 20; Rc index << 28
+        const int w0 = LV(tw_h0);  // (loaded a phase ahead) byte offsets of We[.][i] | We[.][i2] << 10 | dl[.][d] << 20; Rc index << 28
         const Real* Wi = byte_at(L.We, w0 & 1023);
-        const Real* Wi2 = byte_at(L.We, (w0 >> 10) & 1023);
-        const Acc* dld = byte_at(L.dl, (w0 >> 20) & 255);
         Acc ww[6], adv = 0;
         Real hh3[3];
-        {
-          Real w1[6], w2[6];
+        if constexpr (kF) {
+          const Real* Wi2 = byte_at(L.We, (w0 >> 10) & 1023);
+          const Acc* dld = byte_at(L.dl, (w0 >> 20) & 255);
+          {
+            Real w1[6], w2[6];
 #pragma unroll
-          for (int cr = 0; cr < 6; cr += 2) {
-            ld2(Wi + cr, w1[cr], w1[cr + 1]);
-            ld2(Wi2 + cr, w2[cr], w2[cr + 1]);
+            for (int cr = 0; cr < 6; cr += 2) {
+              ld2(Wi + cr, w1[cr], w1[cr + 1]);
+              ld2(Wi2 + cr, w2[cr], w2[cr + 1]);
+            }
+            if constexpr (kB) {
+              hh3[0] = Wi[15];
+              ld2(Wi + 16, hh3[1], hh3[2]);
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int cr = 0; cr < 6; cr++) {
+              ww[cr] = w1[cr] * w2[cr];
+              DDP_PIN(ww[cr]);
+            }
           }
+#pragma unroll
+          for (int part = 0; part < 3; part++) {  // the nine velocity / acceleration control points in batches of 4, 4, 1
+            Real w1[4], w2[4];
+            Acc dl4[4];
+            if (part < 2) {
+#pragma unroll
+              for (int c2 = 0; c2 < 4; c2 += 2) {
+                ld2(Wi + 6 + 4 * part + c2, w1[c2], w1[c2 + 1]);
+                ld2(Wi2 + 6 + 4 * part + c2, w2[c2], w2[c2 + 1]);
+                ld2(dld + 4 * part + c2, dl4[c2], dl4[c2 + 1]);
+              }
+            } else {
+              w1[0] = Wi[14];
+              w2[0] = Wi2[14];
+              dl4[0] = dld[8];
+            }
+            DDP_LOADS_ISSUED();
+#pragma unroll
+            for (int c2 = 0; c2 < (part < 2 ? 4 : 1); c2++) adv += w1[c2] * w2[c2] * dl4[c2];
+            DDP_PIN(adv);  // or the FMAs sink below the later batches' loads and all operands stay live
+          }
+          adv *= sig;
+        } else {
           hh3[0] = Wi[15];
           ld2(Wi + 16, hh3[1], hh3[2]);
-          DDP_LOADS_ISSUED();
-#pragma unroll
-          for (int cr = 0; cr < 6; cr++) {
-            ww[cr] = w1[cr] * w2[cr];
-            DDP_PIN(ww[cr]);
-          }
         }
-#pragma unroll
-        for (int part = 0; part < 3; part++) {  // the nine velocity / acceleration control points in batches of 4, 4, 1
-          Real w1[4], w2[4];
-          Acc dl4[4];
-          if (part < 2) {
-#pragma unroll
-            for (int c2 = 0; c2 < 4; c2 += 2) {
-              ld2(Wi + 6 + 4 * part + c2, w1[c2], w1[c2 + 1]);
-              ld2(Wi2 + 6 + 4 * part + c2, w2[c2], w2[c2 + 1]);
-              ld2(dld + 4 * part + c2, dl4[c2], dl4[c2 + 1]);
-            }
-          } else {
-            w1[0] = Wi[14];
-            w2[0] = Wi2[14];
-            dl4[0] = dld[8];
-          }
-          DDP_LOADS_ISSUED();
-#pragma unroll
-          for (int c2 = 0; c2 < (part < 2 ? 4 : 1); c2++) adv += w1[c2] * w2[c2] * dl4[c2];
-          DDP_PIN(adv);  // or the FMAs sink below the later batches' loads and all operands stay live
-        }
-        adv *= sig;
         Acc* Hb = L.Hxx;  // Hxx | HR | Hzx | hdump are consecutive members: byte offsets from Hxx[0] (see init_tables)
 #pragma unroll
         for (int t = 0; t < 3; t++) {  // column axis d2 = (d + t) mod 3: t == 0 is the lane's own axis
           const int wo = LV(tw_ho)[t], wv = LV(tw_hv)[t];
-          const Acc* vzq = byte_at(L.VZ, wv);
-          const Acc* sps = byte_at(L.Sp, ((unsigned)wo >> 24) & 0xf0);
           Acc sp6[6], vz3[3];
-#pragma unroll
-          for (int cr = 0; cr < 6; cr += 2) ld2(sps + cr, sp6[cr], sp6[cr + 1]);
-#pragma unroll
-          for (int c = 0; c < 3; c++) vz3[c] = vzq[3 * c * 19];
-          // quu (DDP:1349-1355): w_snap Rc T^(i + i2 - 5) on the lane's own axis; Rc[9] = 0 where the pair has none
           Real rc1 = 0, tp1 = 0;
-          if (t == 0) {
-            rc1 = L.Rc[(unsigned)w0 >> 28];
-            tp1 = L.tp[(wo >> 12) & 7];
+          if constexpr (kF) {
+            const Acc* sps = byte_at(L.Sp, ((unsigned)wo >> 24) & 0xf0);
+#pragma unroll
+            for (int cr = 0; cr < 6; cr += 2) ld2(sps + cr, sp6[cr], sp6[cr + 1]);
+          }
+          if constexpr (kB) {
+            const Acc* vzq = byte_at(L.VZ, wv);
+#pragma unroll
+            for (int c = 0; c < 3; c++) vz3[c] = vzq[3 * c * 19];
+          }
+          if constexpr (kF) {
+            // quu (DDP:1349-1355): w_snap Rc T^(i + i2 - 5) on the lane's own axis; Rc[9] = 0 where the pair has none
+            if (t == 0) {
+              rc1 = L.Rc[(unsigned)w0 >> 28];
+              tp1 = L.tp[(wo >> 12) & 7];
+            }
           }
           DDP_LOADS_ISSUED();
-          Acc ada = 0, zvz = 0;
+          Acc hc;  // the constraint half of the entry
+          if constexpr (kF) {
+            Acc ada = 0;
 #pragma unroll
-          for (int cr = 0; cr < 6; cr++) ada += ww[cr] * sp6[cr];
+            for (int cr = 0; cr < 6; cr++) ada += ww[cr] * sp6[cr];
+            const Acc quu = (t == 0) ? wsn * rc1 * tp1 : (Acc)0;
+            hc = fma(sig, ada, quu);
+            if (t == 0) hc = hc + adv;  // the velocity / acceleration rows only couple equal axes
+            DDP_PIN(hc);
+            if constexpr (MODE == 1) LV(C.rc).r[t] = hc;
+          } else {
+            hc = LV(C.rc).r[t];
+          }
+          if constexpr (kB) {
+            Acc zvz = 0;
 #pragma unroll
-          for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
-          const Acc quu = (t == 0) ? wsn * rc1 * tp1 : (Acc)0;
-          Acc v = zvz + quu + sig * ada;
-          if (t == 0) v = v + adv;  // the velocity / acceleration rows only couple equal axes
-          *byte_at(Hb, wo & 0xfff) = v;
-          *byte_at(Hb, (wo >> 16) & 0xfff) = v;
+            for (int c = 0; c < 3; c++) zvz += hh3[c] * vz3[c];
+            const Acc v = zvz + hc;
+            *byte_at(Hb, wo & 0xfff) = v;
+            *byte_at(Hb, (wo >> 16) & 0xfff) = v;
+          }
         }
         if (lane < 36) {  // T column (lanes 0..17, against Sd) and Hz (lanes 18..35, against hh)
           const int p = lane < 18 ? lane : lane - 18;
           const int i = p / 3, d = p % 3;
-          const Acc* vec = (lane < 18 ? L.Sd : L.hh) + ch_idx(0, d);
           const Real* Wc = &L.We[we_idx(0, i)];
-          Acc acc = 0;
+          Acc hT;  // the constraint half
           Real z3[3];  // Z[.][i]: rows 15..17
-          {
+          if constexpr (kF) {
+            const Acc* vec = (lane < 18 ? L.Sd : L.hh) + ch_idx(0, d);
+            Acc acc = 0;
             Real w1[16];
             Acc v15[16];
 #pragma unroll
@@ -1791,48 +2057,100 @@ struct Wave {
             ld2(Wc + 14, w1[14], z3[0]);  // rows 14 and 15
             ld2(Wc + 16, z3[1], z3[2]);
             v15[14] = vec[14];
+            const Acc rq = (i >= 3) ? (lane < 18 ? L.Rpu[p - 9] : L.Ru[p - 9]) : (Acc)0;
             DDP_LOADS_ISSUED();
 #pragma unroll
             for (int cr = 0; cr < 15; cr++) acc += w1[cr] * v15[cr];
-          }
-          if (lane < 18) {
-            Acc zvz = 0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) zvz += z3[c] * L.VZ[(3 * c + d) * 19 + 18];
-            const Acc v = zvz + ((i >= 3) ? wsn * L.Rpu[p - 9] : (Acc)0) + sig * acc;
-            L.HR[9 * kHRS + p] = v;                      // row 18 (T), column p
-            if (p >= 9) L.HR[(p - 9) * kHRS + 18] = v;   // and its mirror in the rows of u
+            hT = (lane < 18) ? fma(sig, acc, wsn * rq) : (wsn * rq + acc);
+            DDP_PIN(hT);
+            if constexpr (MODE == 1) LV(C.rc).r[3] = hT;
           } else {
-            Acc zv = 0;
+            z3[0] = Wc[15];
+            ld2(Wc + 16, z3[1], z3[2]);
+            hT = LV(C.rc).r[3];
+          }
+          if constexpr (kB) {
+            if (lane < 18) {
+              Acc zvz = 0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) zv += z3[c] * L.Vx[3 * c + d];
-            *(p < 9 ? &L.Hzx[p] : &L.HR[(p - 9) * kHRS + 19]) = ((i >= 3) ? wsn * L.Ru[p - 9] : (Acc)0) + zv + acc;
+              for (int c = 0; c < 3; c++) zvz += z3[c] * L.VZ[(3 * c + d) * 19 + 18];
+              const Acc v = zvz + hT;
+              L.HR[9 * kHRS + p] = v;                      // row 18 (T), column p
+              if (p >= 9) L.HR[(p - 9) * kHRS + 18] = v;   // and its mirror in the rows of u
+            } else {
+              Acc zv = 0;
+#pragma unroll
+              for (int c = 0; c < 3; c++) zv += z3[c] * L.Vx[3 * c + d];
+              *(p < 9 ? &L.Hzx[p] : &L.HR[(p - 9) * kHRS + 19]) = zv + hT;
+            }
           }
         }
       }
       {  // (T,T) entry and Hz[T]: 45 + 9 + 9 products each, one per lane, then a wave sum on the VALU
         PLV(Acc, ptt);
         PLV(Acc, pzt);
+        Acc rtt = 0, rzt = 0;  // quu -/+ D_last, qz - g_last: the parts that are no sum over lanes
         LANES {
-          const int tq = lane < 45 ? lane : 44;
           const int a = lane < 45 ? 0 : (lane < 54 ? lane - 45 : 8);
-          const int td = tq / 15, tr = tq - 15 * td;  // tq = 15 axis + row (row-fastest: Sd / hh are [axis][row])
-          const Acc dv = L.dval[3 * tr + td], sd = L.Sd[ch_idx(tr, td)], hv = L.hh[ch_idx(tr, td)];
-          const Acc ft = L.fT[a], vzt = L.VZ[a * 19 + 18], vxa = L.Vx[a];
-          const Acc zu = L.z[9 + a], r2 = L.Rppu[a], r1 = L.Rpu[a];
-          DDP_LOADS_ISSUED();
-          const Acc tt = lane < 45 ? sig * (dv * sd) : (ft * vzt + (Acc)0.5 * wsn * (zu * r2));
-          const Acc zt = lane < 45 ? dv * hv : (ft * vxa + (Acc)0.5 * wsn * (zu * r1));
-          LV(ptt) = lane < 54 ? tt : (Acc)0;
-          LV(pzt) = lane < 54 ? zt : (Acc)0;
+          Acc tt, zt;
+          if constexpr (kF) {
+            const int tq = lane < 45 ? lane : 44;
+            const int td = tq / 15, tr = tq - 15 * td;  // tq = 15 axis + row (row-fastest: Sd / hh are [axis][row])
+            const Acc dv = L.dval[3 * tr + td], sd = L.Sd[ch_idx(tr, td)], hv = L.hh[ch_idx(tr, td)];
+            const Acc zu = L.z[9 + a], r2 = L.Rppu[a], r1 = L.Rpu[a];
+            DDP_LOADS_ISSUED();
+            tt = lane < 45 ? sig * (dv * sd) : (Acc)0.5 * wsn * (zu * r2);
+            zt = lane < 45 ? dv * hv : (Acc)0.5 * wsn * (zu * r1);
+            DDP_PIN(tt);
+            DDP_PIN(zt);
+          } else {
+            tt = LV(C.rc).r[4];
+            zt = LV(C.rc).r[5];
+          }
+          if constexpr (kB) {
+            const Acc ft = L.fT[a], vzt = L.VZ[a * 19 + 18], vxa = L.Vx[a];
+            DDP_LOADS_ISSUED();
+            LV(ptt) = lane < 45 ? tt : (lane < 54 ? fma(ft, vzt, tt) : (Acc)0);
+            LV(pzt) = lane < 45 ? zt : (lane < 54 ? fma(ft, vxa, zt) : (Acc)0);
+          } else {
+            LV(ptt) = lane < 54 ? tt : (Acc)0;
+            LV(pzt) = lane < 54 ? zt : (Acc)0;
+          }
         }
-        const Acc stt = (Acc)WAVE_SUM_D(ptt), szt = (Acc)WAVE_SUM_D(pzt);
-        const Acc quu = (B.k.time_power == 2) ? (Acc)B.k.w_time : (Acc)0;
-        const Acc qz = (B.k.time_power == 2) ? (Acc)B.k.w_time * T : (Acc)0.5 * (Acc)B.k.w_time;
-        L.HR[9 * kHRS + 18] = stt + quu + sig * L.last[0];  // wave-uniform stores
-        L.HR[9 * kHRS + 19] = szt + qz - L.last[1];
+        if constexpr (kF) {
+          const Acc quu = (B.k.time_power == 2) ? (Acc)B.k.w_time : (Acc)0;
+          const Acc qz = (B.k.time_power == 2) ? (Acc)B.k.w_time * T : (Acc)0.5 * (Acc)B.k.w_time;
+          rtt = fma(sig, L.last[0], quu);
+          rzt = qz - L.last[1];
+        } else {
+          rtt = (Acc)RDLANE_M(C.rc, r[4], 54);
+          rzt = (Acc)RDLANE_M(C.rc, r[4], 55);
+        }
+        if constexpr (kB) {
+          const Acc stt = (Acc)WAVE_SUM_D(ptt), szt = (Acc)WAVE_SUM_D(pzt);
+          L.HR[9 * kHRS + 18] = stt + rtt;  // wave-uniform stores
+          L.HR[9 * kHRS + 19] = szt + rzt;
+        } else {
+          // ---- (front) the rest of the record: Z and fT as phase T2 left them, the knot's row errors, the two sums' terms
+          const Acc emu = (Acc)WAVE_MAX_D(C.e_mu);
+          LANES {
+            BRec& R = LV(C.rc);
+            if (lane >= 36 && lane < 54) {
+              const int j = lane - 36;
+              R.r[3] = (Acc)L.We[we_idx(15 + j / 6, j % 6)];
+            } else if (lane >= 54 && lane < 63) {
+              R.r[3] = L.fT[lane - 54];
+            } else if (lane == 63) {
+              R.r[3] = emu;
+            }
+            R.r[4] = lane == 54 ? rtt : (lane == 55 ? rzt : LV(ptt));
+            R.r[5] = LV(pzt);
+          }
+        }
       }
       WSYNC();
+      if constexpr (!kB) return 1;
+      if constexpr (kB) {
       DDP_MARK("B_C");
       // ---- C: LLT of Huu + lam I and the 10 right-hand sides [Hu | Hux], one column per lane in registers.
       // Columns live in ROWS OF 16 LANES so that every multiplier is a DP-ALU DPP row broadcast folded into the FMA
@@ -1856,7 +2174,7 @@ struct Wave {
         for (int a = 0; a < 10; a++) LV(m)[a] = src[a * kHRS];
         const Acc hu = L.HR[(lane < 10 ? lane : 9) * kHRS + 19];  // Hu, one entry per lane: max |Qu| for the optimality error
         DDP_LOADS_ISSUED();
-        LV(e_qu) = fmax(LV(e_qu), fabs(hu));
+        LV(C.e_qu) = fmax(LV(C.e_qu), fabs(hu));
         if (regi > 0) {  // lam = base^reg - 1 is exactly 0 at reg = 0 (the common case)
 #pragma unroll
           for (int a = 0; a < 10; a++) LV(m)[a] += ((a == col) ? lam : (Acc)0);
@@ -1883,12 +2201,7 @@ struct Wave {
         }
       });
       const int ok = DDP_PRED_LANE0(bad) ? 0 : 1;  // every row of lanes has seen the same ten pivots
-      if (!ok) {  // DDP:546-551, 595-600
-        st.bp_failed = 1;
-        st.opterr = INFINITY;
-        count_visits(0, N - k);
-        return 0;
-      }
+      if (!ok) return 0;  // DDP:546-551, 595-600 (the sweep reports it)
       // Back substitution L^T X = [y | Y] in the right-hand-side lanes: L[j][i] (j > i) is entry i of matrix lane j,
       // again a row broadcast folded into the FMA.  The lanes carry Z = -X, the gains themselves ([ku | Ku] = -X,
       // DDP:561-564, 607-609):  x_i = (y_i - sum L_ji x_j) / L_ii  <=>  z_i = (y_i + sum L_ji z_j) * (-1 / L_ii).
@@ -2029,11 +2342,207 @@ struct Wave {
         }
       }
       WSYNC();
+      }
+    }
+    return 1;
+  }
+
+  // ---- the helpers' half of a shared sweep: the front halves of the knots this wave claims, from below, each into its
+  // record.  Also run by the owner itself in the forced split of the tests (Batch::bforce), before its own sweep.
+  DDP_DEV void bwd_front_run(BwdShare* bs, int tag, int cur, int infeas, double mu_d) {
+    BwdCtx C;
+    C.regi = 0; C.buf = DDP_UNIFORM_I(cur); C.infeas = DDP_UNIFORM_I(infeas); C.klo = 0;
+    C.lam = (Acc)0;
+    C.sig = infeas ? (Acc)1 : (Acc)-1;
+    C.mu = DDP_UNIFORM_R((Real)mu_d);
+    C.wsn = (Real)B.k.w_snap;
+    C.emu_u = (Acc)0;
+    set_sweep_ptrs(C.buf);
+    LANES {
+      LV(C.e_mu) = 0;
+      LV(C.e_qu) = 0;
+      L.We[lane] = (Real)0;  // the entries of We with a zero weight (see bwd_sweep_t)
+      if (lane + 64 < 112) L.We[lane + 64] = (Real)0;
+    }
+    WSYNC();
+    int done = 0;
+#pragma unroll 1
+    while (true) {
+      if (bs_tag(bs) != tag) break;  // the owner has closed the sweep (its LLT failed): nobody waits for more records
+      int k0, k1;
+      bs_claim_low(bs, k0, k1);
+      if (k0 >= k1) break;
+      C.klo = k0;
+      C.Pn = DDP_UNIFORM_I(npU(k1 - 1));
+      C.Pnn = npU(k1 - 2 > 0 ? k1 - 2 : 0);
+      LANES { prefetch(LV(C.pre), LV(C.pkn), 0, lane, C.buf, k1 - 1, C.Pn, false, C.infeas); }
+#pragma unroll 1
+      for (int k_ = k1 - 1; k_ >= k0; k_--) {
+        bwd_knot<1, false>(C, k_);
+        LANES { rec_store(k_, LV(C.rc), lane); }
+        flag_set(k_, tag);
+      }
+      done += k1 - k0;
+    }
+#if !defined(DIRECT_EMULATE)
+    if (B.bvisits != nullptr && threadIdx.x == 0 && done) atomicAdd(B.bvisits, (unsigned long long)done);
+#endif
+  }
+  // a wave that waits for trajectory b's next ticket: join the sweep b's owner has open
+  DDP_DEV_NOINLINE void bwd_help() {
+    DDP_LAUNDER_S(b);
+    DDP_LAUNDER_S(N);
+    BwdShare* bs = bshare_slot();
+    if (bs == nullptr) return;
+    int tag = 0, cur = 0, infeas = 0;
+    double mu_d = 0.0;
+    if (!bs_enter(bs, tag, cur, infeas, mu_d)) return;
+    bwd_front_run(bs, tag, cur, infeas, mu_d);
+    bs_leave(bs);
+  }
+
+  template <bool kGains>
+  DDP_DEV_NOINLINE int bwd_sweep_t() {
+    DDP_LAUNDER_S(b);
+    DDP_LAUNDER_S(N);
+    {  // regulariser schedule (DDP:452-474)
+      int reg = st.reg;
+      if (st.fp_failed || st.bp_failed) reg += 1;
+      else if (st.step == 0) reg -= 1;
+      else if (st.step > 3) reg += 1;
+      st.reg = reg < 0 ? 0 : (reg > 24 ? 24 : reg);
+    }
+    BwdCtx C;
+    C.regi = DDP_UNIFORM_I(st.reg);
+    double lam_d = 1.0;
+    for (int q = 0; q < C.regi; q++) lam_d *= B.k.reg_base;
+    C.lam = DDP_UNIFORM_R((Acc)(lam_d - 1.0));  // DDP:529
+    C.buf = DDP_UNIFORM_I(st.cur);
+    C.infeas = DDP_UNIFORM_I(st.infeas);
+    C.mu = DDP_UNIFORM_R((Real)st.mu);
+    C.wsn = (Real)B.k.w_snap;
+    C.sig = C.infeas ? (Acc)1 : (Acc)-1;
+    C.klo = 0;
+    C.emu_u = (Acc)0;
+    const int buf = C.buf, infeas = C.infeas;
+
+    // Shared sweep: publish it (the top kOwnChunk knots are the owner's from the start).  In the tests' forced split the
+    // owner plays the helper first - before its own sweep, whose value function and prefetch live where the front
+    // halves' operands do.
+    BwdShare* bs = kGains ? nullptr : bshare_slot();
+    int kfloor = 0, tag = 0;
+    Pend pend;
+    pend.lo = 0; pend.hi = 0;
+    if (bs != nullptr) {
+      kfloor = N > kOwnChunk ? N - kOwnChunk : 0;
+      tag = bs_open(bs, buf, infeas, st.mu, kfloor);
+      if (B.bforce) bwd_front_run(bs, tag, buf, infeas, st.mu);
+    }
+    set_sweep_ptrs(buf);
+
+    // terminal derivatives (DDP:1318-1323)
+    LANES {
+#pragma unroll 1
+      for (int e = lane; e < 81; e += 64) L.V[e] = (e / 9 == e % 9) ? (Acc)B.k.w_term : (Acc)0;
+      if (lane < 9) L.Vx[lane] = (Acc)B.k.w_term * (Acc)(ldx(XpU(0, N), lane) - (Real)B.xd[(size_t)b * 9 + lane]);
+    }
+    WSYNC();
+    // opterr = max(|Qu|, |r|, |c + y|) over the sweep (DDP:641): one running maximum per lane is enough
+    LANES {
+      LV(C.e_mu) = 0;
+      LV(C.e_qu) = 0;
+    }
+
+    // plane counts run two knots ahead of the sweep (the prefetch of knot k-1 needs P(k-1) for its
+    // addresses: loading it on the spot would expose one HBM round trip per knot)
+    C.Pn = DDP_UNIFORM_I(npU(N - 1));
+    C.Pnn = npU(N > 1 ? N - 2 : 0);
+    LANES { prefetch(LV(C.pre), LV(C.pkn), 0, lane, buf, N - 1, C.Pn, false, infeas); }
+    // We = WbE o T-powers (rows 0..14: control points, rows 15..17: Z = [F | G]; read by phases R1, H, G) is a by-product
+    // of phase T2, which forms exactly these products on its way to the control values; the entries with a zero weight
+    // (coefficient index below the row's exponent offset) never change: cleared once per sweep (the forward pass uses
+    // the same LDS).
+    LANES {
+      L.We[lane] = (Real)0;
+      if (lane + 64 < 112) L.We[lane + 64] = (Real)0;
+    }
+    WSYNC();
+    if (bs != nullptr && kfloor > 0) bs_claim_high_issue(bs, pend);
+    int ok = 1, kfail = 0;
+    int ks = -1;  // knots ks .. 0 are the helpers': through records
+#pragma unroll 1
+    for (int k_ = N - 1; k_ >= 0; k_--) {
+      if (k_ < kfloor) {  // the owner's claim is used up: what did the next one get?
+        const int low = bs_claim_high_low(pend);
+        if (low >= kfloor) {  // the helpers have taken everything below
+          ks = k_;
+          break;
+        }
+        kfloor = kfloor - kOwnChunk > low ? kfloor - kOwnChunk : low;
+        if (kfloor > 0) bs_claim_high_issue(bs, pend);
+      }
+      ok = bwd_knot<0, kGains>(C, k_);
+      if (!ok) {
+        kfail = k_;
+        break;
+      }
+    }
+#if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
+    tl_split_ += ks + 1;
+#endif
+    if constexpr (kSplit && !kGains) {
+      if (ok && ks >= 0) {
+        // ---- the knots helpers have prepared.  The flag of a knot is asked for two knots ahead and its record one knot
+        // ahead (only once the flag has been seen: the loads must not overtake it); a record that is late is waited for.
+        int have = flag_wait(ks, tag);
+        if (have) {
+          LANES { rec_load(ks, LV(C.rc), lane); }
+        }
+        PLV(int, fl);
+        LANES { LV(fl) = ks > 0 ? flag_peek(ks - 1) : 0; }
+        PLV(BRec, rn);
+#pragma unroll 1
+        for (int k_ = ks; k_ >= 0 && have; k_--) {
+          int next = 0;
+          if (k_ > 0) {
+            if (RDLANE_I(fl, 0) == tag) {
+              LANES { rec_load(k_ - 1, LV(rn), lane); }
+              next = 1;
+            }
+            LANES { LV(fl) = k_ > 1 ? flag_peek(k_ - 2) : 0; }
+          }
+          ok = bwd_knot<2, false>(C, k_);
+          if (!ok) {
+            kfail = k_;
+            break;
+          }
+          if (k_ > 0) {
+            if (!next) {
+              have = flag_wait(k_ - 1, tag);
+              if (have) {
+                LANES { rec_load(k_ - 1, LV(rn), lane); }
+              }
+            }
+            LANES { LV(C.rc) = LV(rn); }
+          }
+        }
+        if (!have) {  // a record never came (the protocol's error flag is up): the sweep counts as failed
+          ok = 0;
+          kfail = 0;
+        }
+      }
+    }
+    if (bs != nullptr) bs_close(bs);
+    if (!ok) {  // DDP:546-551, 595-600
+      st.bp_failed = 1;
+      st.opterr = INFINITY;
+      count_visits(0, N - kfail);
+      return 0;
     }
     DDP_MARK("B_END");
     count_visits(0, N);
-    const double mu_err = WAVE_MAX_D(e_mu);
-    const double qu_err = WAVE_MAX_D(e_qu);
+    const double mu_err = fmax((double)WAVE_MAX_D(C.e_mu), (double)C.emu_u);
+    const double qu_err = WAVE_MAX_D(C.e_qu);
     st.bp_failed = 0;
     st.opterr = fmax((double)qu_err, mu_err);  // DDP:641
     return 1;
@@ -2770,8 +3279,18 @@ struct Wave {
   }
 
   // ---- one trip of the outer loop (DDP:295-412).  Sets st.done when the loop breaks. ------------
-  // helper != 0: no trip at all - this wave joins the line search that trajectory b's owner has open (fwd_pass)
+  // helper != 0: no trip at all - this wave joins what trajectory b's owner has open: 1 its line search (fwd_pass),
+  // 2 its backward sweep (bwd_help)
   DDP_DEV void iterate_once(int helper = 0) {
+    if (helper == 2) {
+      bwd_help();
+      return;
+    }
+#if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
+    unsigned long long* tl_ = (!helper && B.tl != nullptr && st.fwd_passes < 32) ? B.tl + ((size_t)b * 32 + st.fwd_passes) * 4 : nullptr;
+    if (tl_ != nullptr && threadIdx.x == 0) { tl_[0] = __builtin_amdgcn_s_memrealtime(); tl_[3] = 0; }
+    tl_split_ = 0;
+#endif
     if (!helper) {
       while (true) {  // DDP:297-310
         if (bwd_sweep()) break;
@@ -2780,8 +3299,14 @@ struct Wave {
         if (st.bp_no_upd > 20) break;
       }
     }
+#if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
+    if (tl_ != nullptr && threadIdx.x == 0) { tl_[1] = __builtin_amdgcn_s_memrealtime(); tl_[3] = (unsigned long long)tl_split_; }
+#endif
     fwd_pass(helper);
     if (helper) return;
+#if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
+    if (tl_ != nullptr && threadIdx.x == 0) tl_[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     DDP_MARK("X_A");
     st.fwd_passes++;
     if (st.neg_time) {  // DDP:317-326
@@ -2846,6 +3371,11 @@ struct Wave {
           break;
         }
       }
+#if !defined(DIRECT_EMULATE)
+      // a later trip of the same ticket: the iterate this wave has just written must be in memory before a helper of
+      // the next sweep reads it (the first trip's iterate was released by the previous ticket's owner)
+      if (!helper && it > 0 && bshare_slot() != nullptr) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
       iterate_once(helper);
       if (helper) break;
       if (!st.done) {

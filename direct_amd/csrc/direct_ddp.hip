@@ -96,11 +96,11 @@ struct Sched {
 // t % batch); else continues to wait with ticket `held` in hand.  Waits for the previous chunk of the ticket's trajectory.
 // Returns the ticket, with *help = 0 when its chunk can run now, or *help = 1 when the predecessor is still running and
 // has opened its line search to helpers (ddp_wave.h, fwd_pass): the caller runs a round of it and comes back with the
-// ticket.  -1: no tickets left; -2: the ticket's trajectory has already finished (kDoneBit in done_epoch); -3 - b: the
+// ticket; *help = 2 likewise when the predecessor's backward sweep is open and has unclaimed knots (bwd_help).  -1: no tickets left; -2: the ticket's trajectory has already finished (kDoneBit in done_epoch); -3 - b: the
 // wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early
 // exits on purpose: inlined into the (huge) iterate loop the structuriser turned the nested uniform loops into
 // exec-masked ones.
-__device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, const int32_t* idx, unsigned nb, unsigned total, int held,
+__device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, BwdShare* sweeps, const int32_t* idx, unsigned nb, unsigned total, int held,
                                                    int* waited, int* help) {
   unsigned t = (unsigned)held;
   if (held < 0) {
@@ -116,7 +116,7 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, con
   int ready = (e == 0) ? 1 : 0, have = 0, wanted = 0;
   int spins = 0;
   for (; !ready && !wanted && spins < (1 << 22); spins++) {
-    int hv = 0, g = 0, r = 0, lr = 0;
+    int hv = 0, g = 0, r = 0, lr = 0, sw = 0;
     if (threadIdx.x == 0) {
       hv = __hip_atomic_load(&S.done_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (slots) {
@@ -124,15 +124,21 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, con
         r = __hip_atomic_load(&slots[b].next_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lr = __hip_atomic_load(&slots[b].last_round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (sweeps) {  // the predecessor's backward sweep is open and has knots nobody has claimed yet
+        const unsigned w = __hip_atomic_load(&sweeps[b].word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long c = __hip_atomic_load(&sweeps[b].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sw = ((w >> 8) != 0 && (long long)(c & 0xffffffffull) < (long long)(c >> 32) - (long long)kClaimBias) ? 1 : 0;
+      }
     }
     have = __builtin_amdgcn_readfirstlane(hv);
     ready = (have >= e) ? 1 : 0;
     wanted = (!ready && __builtin_amdgcn_readfirstlane((g != 0 && r <= lr) ? 1 : 0)) ? 1 : 0;
+    if (!ready && !wanted && __builtin_amdgcn_readfirstlane(sw)) wanted = 2;
     if (!ready && !wanted) __builtin_amdgcn_s_sleep(32);
   }
   if (spins > 1 || wanted) *waited = 1;
   if (wanted) {
-    *help = 1;
+    *help = wanted;
     return (int)t;
   }
   if (!ready) {  // a scheduling bug: never a hang, and never a chunk run on a trajectory whose previous chunk
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
   for (;;) {
     int help_v = 0;
     DDP_MARK("X_T");
-    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, B.idx, nb, total, held, &waited, &help_v));
+    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, B.bshare, B.idx, nb, total, held, &waited, &help_v));
     const int help = __builtin_amdgcn_readfirstlane(help_v);
     DDP_MARK("X_G");
     held = -1;
@@ -292,6 +298,10 @@ __global__ void k_best(const Real* cost, const int32_t* rtn, int n, int* best_id
 
 // ---- host side ---------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+#if defined(DDP_TIMELINE)
+static unsigned long long* g_tl;
+static size_t g_tl_n;
+#endif
 static direct_status_t fail(direct_status_t st, const std::string& msg) {
   g_err = msg;
   return st;
@@ -337,6 +347,12 @@ struct direct_ddp_handle_s {
   int help_early = 1;        // single-step shared searches are open from step 0 on (DIRECT_DDP_EARLY=0: after step 0 failed)
   int single_ratio = 8;      // shared line search in single steps when batch * ratio <= resident waves (DIRECT_DDP_SINGLE)
   int help_mode = -1;        // shared line search: -1 auto (batches up to 1.5 x the resident waves), DIRECT_DDP_HELP=0|1 forces
+  // helper-assisted backward sweep (ddp_wave.h, bwd_sweep_t): waiting waves compute the value-independent half of knots
+  BwdShare* bshare = nullptr;  // [max_batch], allocated with `help` (narrow row-slot classes only)
+  int* bflag = nullptr;        // [max_batch][nmax]
+  double* brec = nullptr;      // [max_batch][nmax][kRecDoubles]
+  int bshare_mode = -1;        // -1 auto (wherever the line search is shared), DIRECT_DDP_BSHARE=0 off, 1 on, 2 forced split: every
+                               // owner runs the helpers' half itself first (tests: the hand-over path without any helper)
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
   double* filt = nullptr;
   TrajState* st = nullptr;
@@ -524,7 +540,12 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     (void)hipMemsetAsync(h->tickets, 0, 16 * sizeof(int), h->stream);
     (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);  // done_epoch; the error flag [1] is sticky: cleared in stage_inputs
     if (h->help) (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
+    if (h->bshare && h->bshare_mode != 0) {  // sweep tags restart with every launch: no flag of an earlier one may survive
+      (void)hipMemsetAsync(h->bshare, 0, (size_t)h->B * sizeof(BwdShare), h->stream);
+      (void)hipMemsetAsync(h->bflag, 0, (size_t)h->B * h->nmax * sizeof(int), h->stream);
+    }
   }
+  (void)hipMemsetAsync(h->visits + 2, 0, sizeof(unsigned long long), h->stream);
   bool forked = false;
   if (mode == 0 && classes.size() > 1 && class_stream(h, 0, classes.size()) != h->stream) {
     (void)hipEventRecord(h->fork_ev, h->stream);
@@ -535,6 +556,15 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     const auto& c = classes[ci];
     auto Bt = make_batch<Real>(h, h->cur_in, h->params, c);
     Bt.visits = h->visits;
+#if defined(DDP_TIMELINE)
+    if (g_tl_n < (size_t)h->B * 32 * 4) {
+      if (g_tl) (void)hipFree(g_tl);
+      g_tl_n = (size_t)h->B * 32 * 4;
+      (void)hipMalloc((void**)&g_tl, g_tl_n * 8);
+    }
+    (void)hipMemsetAsync(g_tl, 0, (size_t)h->B * 32 * 4 * 8, h->stream);
+    Bt.tl = g_tl;
+#endif
     hipStream_t st = h->stream;
     if (forked) {
       st = class_stream(h, ci, classes.size());
@@ -554,6 +584,13 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     if (is_big) {
       biggest = (int)ci;
       li.pair_trials = Bt.k.pair_trials; li.resident_waves = slots; li.dynamic = 0; li.shared_search = 0; li.single_steps = 0;
+      li.shared_sweep = 0;
+    }
+    // backward sweeps shared with helpers wherever the line search is; the forced split needs no helper (any launch form)
+    const bool sweep_ok = h->bshare != nullptr && c.rpl <= 4;
+    if (sweep_ok && h->bshare_mode == 2) {
+      Bt.bshare = h->bshare; Bt.bflag = h->bflag; Bt.brec = h->brec; Bt.bforce = 1; Bt.bvisits = h->visits + 2;
+      if (is_big) li.shared_sweep = 2;
     }
     // The static launch is tail-free when every trajectory is resident at once - but then the waves that are left
     // over have nothing to do, while the ticket scheduler turns them into helpers: with help it is used for small
@@ -575,6 +612,10 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
         Bt.live = live;
         Bt.tail_thresh = h->single_ratio > 0 ? slots / h->single_ratio : 0;
         if (is_big) { li.shared_search = 1; li.single_steps = Bt.k.pair_trials ? 0 : 1; }
+        if (sweep_ok && h->bshare_mode != 0 && h->bshare_mode != 2 && h->sched_chunk == 1) {
+          Bt.bshare = h->bshare; Bt.bflag = h->bflag; Bt.brec = h->brec; Bt.bforce = 0; Bt.bvisits = h->visits + 2;
+          if (is_big) li.shared_sweep = 1;
+        }
       }
       if (is_big) li.dynamic = 1;
       RPL_LAUNCH(c.rpl, st, k_iterate_dyn, Real, slots, Bt, n, S);
@@ -741,6 +782,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   if (const char* ev = getenv("DIRECT_DDP_SINGLE")) h->single_ratio = atoi(ev) > 0 ? atoi(ev) : (1 << 30);
   if (const char* ev = getenv("DIRECT_DDP_SMALL")) h->small_dyn = atoi(ev) != 0;
   if (const char* ev = getenv("DIRECT_DDP_EARLY")) h->help_early = atoi(ev);
+  if (const char* ev = getenv("DIRECT_DDP_BSHARE")) h->bshare_mode = atoi(ev);
   // The shared line search needs a trial buffer per step.  It only ever runs where trials are paired, i.e. (unless
   // forced) for batches up to twice the resident waves: larger handles keep the three-buffer layout.
   const bool can_help = h->dynamic && h->sched_slots > 0 && h->help_mode != 0 &&
@@ -748,7 +790,8 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   bool fits = true;
   if (can_help && h->help_mode < 0) {  // the extra trial buffers must stay a small part of the device's memory
     size_t free_b = 0, total_b = 0;
-    const size_t extra = (size_t)(kMaxBuf - 3) * (B * (nm + 1) * xs * r + 2 * B * nm * h->ncs * r);
+    const size_t extra = (size_t)(kMaxBuf - 3) * (B * (nm + 1) * xs * r + 2 * B * nm * h->ncs * r) +
+                         (h->rpl <= 4 ? B * nm * (size_t)kRecDoubles * 8 : 0);
     fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && extra <= free_b / 8;
   }
   h->nbuf = (can_help && fits) ? kMaxBuf : 3;
@@ -756,6 +799,9 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
     A(&h->X[i], B * (nm + 1) * xs * r); A(&h->S[i], B * nm * h->ncs * r); A(&h->Y[i], B * nm * h->ncs * r);
   }
   if (h->nbuf == kMaxBuf) A(&h->help, B * sizeof(HelpSlot));
+  if (h->rpl <= 4 && h->bshare_mode != 0 && (h->nbuf == kMaxBuf || h->bshare_mode == 2)) {
+    A(&h->bshare, B * sizeof(BwdShare)); A(&h->bflag, B * nm * sizeof(int)); A(&h->brec, B * nm * (size_t)kRecDoubles * 8);
+  }
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
   A(&h->st, B * sizeof(TrajState));
   A(&h->o.rtn, B * 4); A(&h->o.iter_used, B * 4); A(&h->o.fwd_passes, B * 4);
@@ -765,7 +811,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
   A(&h->best_idx, 16); A(&h->best_cost, 16);
   A(&h->sched, (B + 2) * sizeof(int));
-  A(&h->visits, 2 * sizeof(unsigned long long));
+  A(&h->visits, 4 * sizeof(unsigned long long));  // [0] backward knots, [1] forward trial-knots, [2] knots whose front half a helper computed
   A(&h->live, 16 * sizeof(int));
   A(&h->tickets, 16 * sizeof(int));
   A(&h->order, B * sizeof(int32_t)); A(&h->cls_dev, B * sizeof(int32_t));
@@ -1150,6 +1196,25 @@ direct_status_t direct_ddp_last_launch_info(direct_ddp_handle_t h, direct_ddp_la
   *info = h->last_info;
   info->bwd_knot_visits = v[0];
   info->fwd_knot_visits = v[1];
+  return DIRECT_OK;
+}
+
+#if defined(DDP_TIMELINE)  // debug builds only (tools/timeline.py)
+direct_status_t direct_ddp_debug_timeline(direct_ddp_handle_t h, void* dst) {
+  if (!g_tl) return fail(DIRECT_ERR_INVALID, "no timeline");
+  HIP_TRY(hipMemcpy(dst, g_tl, (size_t)h->B * 32 * 4 * 8, hipMemcpyDeviceToHost));
+  return DIRECT_OK;
+}
+#endif
+
+direct_status_t direct_ddp_last_helper_knots(direct_ddp_handle_t h, uint64_t* knots) {
+  if (!h || !knots) return fail(DIRECT_ERR_INVALID, "null argument");
+  if (!h->timed) return fail(DIRECT_ERR_INVALID, "no hot-kernel launch yet");
+  HIP_TRY(hipSetDevice(h->device));
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, h->visits + 2, sizeof v, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *knots = v;
   return DIRECT_OK;
 }
 

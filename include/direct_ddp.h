@@ -311,12 +311,18 @@ typedef struct {
   int32_t single_steps;   /* 1: shared searches hand out single steps (few trajectories on many waves) */
   int32_t n_buffers;      /* iterate buffers allocated per array (3, or 12 with the shared line search) */
   int32_t resident_waves; /* persistent waves launched / one-wave workgroups resident at once on this device */
-  int32_t batch, reserved;
+  int32_t batch;
+  int32_t shared_sweep;   /* 1: waiting waves compute the value-independent half of backward knots of the trajectory they wait
+                             for (hand-over records in HBM; results bitwise those of the owner-only sweep); 2: the same path
+                             forced without helpers (DIRECT_DDP_BSHARE=2, tests); 0: every sweep stays with its owner */
   uint64_t bwd_knot_visits; /* backward-sweep knots executed by the launch (all trajectories, retries included) */
   uint64_t fwd_knot_visits; /* forward trial-knots executed (every trial of every line search, helpers' included;
                                a trial cut short by the fraction-to-boundary rule counts the knots it reached) */
 } direct_ddp_launch_info_t;
 direct_status_t direct_ddp_last_launch_info(direct_ddp_handle_t h, direct_ddp_launch_info_t* info);
+/* Backward knots of the last hot-kernel launch whose value-independent half was computed by a helper wave (or by the
+ * forced split) and handed over through HBM; 0 when the launch did not share its sweeps.  Observability only. */
+direct_status_t direct_ddp_last_helper_knots(direct_ddp_handle_t h, uint64_t* knots);
 
 /* Config-5 reduction: index and value of the smallest cost among problems with rtn >= 0.
  * cost/rtn are device or host arrays per `mem`; the result is written to host. */

@@ -25,6 +25,10 @@ struct Emu {
   std::vector<uint8_t> infeas_in;
   std::vector<double> filt;
   std::vector<TrajState> st;
+  // forced split of the backward sweep (DIRECT_EMU_BSPLIT=1): front halves through hand-over records, as helper waves would
+  std::vector<BwdShare> bshare;
+  std::vector<int> bflag;
+  std::vector<double> brec;
   int rpl;
 };
 
@@ -101,6 +105,13 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.Y[2] = E->Y2.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
   Bt.KY = E->KY.data(); Bt.filt = E->filt.data(); Bt.st = E->st.data();
   Bt.nbuf = 3; Bt.help = nullptr; Bt.sched_err = nullptr; Bt.visits = nullptr;
+  if (getenv("DIRECT_EMU_BSPLIT") && atoi(getenv("DIRECT_EMU_BSPLIT")) != 0) {
+    E->bshare.assign(B, BwdShare());
+    memset(E->bshare.data(), 0, sizeof(BwdShare) * (size_t)B);
+    E->bflag.assign((size_t)B * nm, 0);
+    E->brec.assign((size_t)B * nm * kRecDoubles, 0.0);
+    Bt.bshare = E->bshare.data(); Bt.bflag = E->bflag.data(); Bt.brec = E->brec.data(); Bt.bforce = 1;
+  }
   SolveConst& k = Bt.k;
   k.max_vel = p->max_vel; k.max_acc = p->max_acc; k.w_snap = p->w_snap; k.w_term = p->w_terminal;
   k.w_time = p->w_time; k.reg_base = p->zero_init ? 1.6 : 4.0; k.shift = p->minvo ? 0.0 : 2.0e-4;
@@ -178,6 +189,12 @@ void emu_finish(void* hv, direct_ddp_batch_out_t* out) {
     O.bez = (Real*)out->bez; O.poly = (Real*)out->poly; O.T = (Real*)out->T;
     with_state(E, [&](auto& W) { finish_wave(W, O); });
   })
+}
+// knots whose front half went through a hand-over record in the last sweeps (forced split; 0 without DIRECT_EMU_BSPLIT)
+int emu_split_knots(void* hv) {
+  int n = 0;
+  EMU_CALL({ for (int v : E.bflag) n += v != 0; })
+  return n;
 }
 void emu_end(void* hv) {
   EmuHandle* h = (EmuHandle*)hv;

@@ -34,6 +34,8 @@ def lib():
         L.emu_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_set_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_finish.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_split_knots.argtypes = [C.c_void_p]
+        L.emu_split_knots.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -85,6 +87,10 @@ class EmuSolver:
     def scalars(self):
         s = self.get(abi.FIELD_SCALARS)
         return {n: s[:, i] for i, n in enumerate(abi.SCALAR_NAMES)}
+
+    def split_knots(self):
+        """knots whose front half went through a hand-over record (DIRECT_EMU_BSPLIT=1 at construction; else 0)"""
+        return int(lib().emu_split_knots(self.h))
 
     def finish(self):
         res = abi.HostResult(self.batch.batch, self.batch.n_seg_max, self.np_dtype)

@@ -206,3 +206,24 @@ def test_line_search_round_layouts_are_bitwise_equal(name, monkeypatch):
                 assert np.array_equal(a.view(np.uint8), np.asarray(getattr(o[ph], f)).view(np.uint8)), (ph, f)
         steps += int((outs[0][ph].fwd_passes > 1).sum())
     assert steps > 0
+
+
+@pytest.mark.parametrize("kind,N,B,seed", [("free", 5, 3, 21), ("corridor", 12, 4, 3), ("free", 30, 2, 5)])
+def test_emulated_split_backward_sweep_is_bitwise_the_fused_one(kind, N, B, seed, monkeypatch):
+    """bwd_knot is written once and instantiated fused / front / back (ddp_wave.h): the front half of every knot below the
+    owner's first claim computed on its own, handed over through a BRec record, and finished by the back half must give
+    the very bits of the fused knot - both phases, both storage types, natural exits."""
+    batch = problems.make_batch(kind, B, N, seed=seed)
+    for params in (abi.phase0_params(), abi.phase1_params()):
+        for dtype, c64 in ((np.float64, False), (np.float32, True)):
+            res, knots = [], []
+            for split in ("0", "1"):
+                monkeypatch.setenv("DIRECT_EMU_BSPLIT", split)
+                s = emuapi.EmuSolver(params, batch, dtype, c64)
+                s.iterate(params.iter_max)
+                knots.append(s.split_knots())
+                res.append(s.finish())
+                s.close()
+            assert knots[0] == 0 and knots[1] == B * max(N - 4, 0), knots
+            for f in ("rtn", "iter_used", "fwd_passes", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
+                assert np.array_equal(getattr(res[0], f), getattr(res[1], f)), (f, dtype, params.zero_init)

@@ -251,6 +251,45 @@ def test_shared_line_search_is_bitwise_equal_to_the_owner_only_search(built, cor
     assert int(fixed["1"][0].fwd_passes.sum()) == B * 20
 
 
+@pytest.mark.parametrize("dt,nb,kind", [(np.float32, B, "free"), (np.float32, B, "corridor"), (np.float64, 600, "corridor"),
+                                        (np.float32, 1, "free"), (np.float64, 40, "free")])
+def test_shared_backward_sweep_is_bitwise_equal_to_the_owner_only_sweep(built, dt, nb, kind, monkeypatch):
+    """Waves that wait for a trajectory's next ticket compute the value-independent half of knots of its backward sweep
+    (phases T2, rows, S, S2, the constraint half of H) and hand it over through records in HBM (ddp_wave.h, bwd_knot
+    MODE 1 / 2, BwdShare): who computed which knot must not show anywhere.  DIRECT_DDP_BSHARE = 0 (every sweep with its
+    owner), 1 (helpers), 2 (the forced split: every knot below the owner's first claim goes through a record, no helper
+    needed): natural exits of both phases and the fixed-20 launch, every output bit-identical, no scheduler error, and the
+    hand-over path really taken."""
+    batch = problems.make_batch(kind, nb, N, seed=1000 if nb == B else 500 + nb).astype(dt)
+    fields = ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez")
+    res, fixed, knots = {}, {}, {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("DIRECT_DDP_BSHARE", mode)
+        s = solver.DdpSolver(nb, N, batch.p_max, dt)
+        res[mode] = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=30), batch)
+        assert s.sched_error() == 0
+        g0 = res[mode][0]
+        b1 = batch.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, batch.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
+        for _ in range(2):  # the interleaving differs from launch to launch
+            fixed.setdefault(mode, []).append(s.solve(abi.phase1_params(iter_max=20, fixed_iters=1), b1))
+            assert s.sched_error() == 0
+        li = s.launch_info()
+        knots[mode] = (li["shared_sweep"], li["helper_front_knots"], li["bwd_knot_visits"])
+        s.close()
+    for mode in ("1", "2"):
+        for a, b in zip(res["0"], res[mode]):
+            for f in fields:
+                assert np.array_equal(getattr(a, f), getattr(b, f)), (mode, f)
+        for g in fixed[mode] + fixed["0"][1:]:
+            for f in fields:
+                assert np.array_equal(getattr(fixed["0"][0], f), getattr(g, f)), (mode, f)
+    assert knots["0"][:2] == (0, 0), knots
+    assert knots["2"][0] == 2 and knots["2"][1] > 0.9 * knots["2"][2], knots   # every knot below the owner's first claim (the top four)
+    assert knots["1"][0] == 1, knots
+    if nb in (1, B):   # helpers exist: idle waves of a lone trajectory; the waiters of the headline batch
+        assert knots["1"][1] > 0, knots
+
+
 @pytest.mark.parametrize("dt,nb,nseg,chunk", [(np.float64, 3300, 40, "1"), (np.float32, 3500, 60, "3")])
 def test_shared_line_search_other_storage_types_and_chunk_sizes(built, dt, nb, nseg, chunk, monkeypatch):
     """The same bitwise equality for double storage, an awkward batch size, shorter trajectories and tickets of three
