@@ -41,6 +41,10 @@ CONFIGS = {  # BASELINE.json configs[1..4]
     3: dict(kind="corridor", batch=4096, nseg=100, dtype="f32", name="config 3"),
     4: dict(kind="corridor", batch=16384, nseg=300, dtype="f64", name="config 4"),
     5: dict(kind="corridor", batch=16384, nseg=100, dtype="f32", name="config 5 (per-GPU shard of 131072 / 8)"),
+    # config 4's shape (N = 300, double storage, 16384 per GPU) on the free-space generator: every trajectory leaves phase 0
+    # feasible, so the timed iterations run FULL-LENGTH forward rollouts (config 4's own corridors stay in infeasible mode,
+    # where every line-search trial dies at the fraction-to-boundary rule after a few knots: VERDICT r04 missing #1)
+    6: dict(kind="free", batch=16384, nseg=300, dtype="f64", name="config 4, feasible-mode variant (free-space generator)"),
 }
 
 
@@ -158,6 +162,102 @@ def live_hbm_traffic(workload, timeout_s=150):
             "kernel_ms_under_pmc": [ms["FETCH_SIZE"], ms["WRITE_SIZE"]], "calibration": cal}
 
 
+def live_sq_counters(workload, timeout_s=150):
+    """The SQ counters behind roofline_compute, measured NOW on this box: two more rocprofv3 --pmc passes over
+    tools/prof_one.py (instruction mix; pipe activity and LDS bank conflicts), last k_iterate* dispatch, checked against
+    the HIP-event time like the traffic passes.  Returns the derived figures of tools/pmc_collect.py, or None."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    sets = (["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_LDS"],
+            ["SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES"])
+    c, ms = {}, []
+    tmp = tempfile.mkdtemp(prefix="bench_sq_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        for i, names in enumerate(sets):
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [rp, "--pmc"] + names + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "q", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "prof_one.py"), workload["kind"], workload["dtype"], str(workload["batch"]),
+                   str(workload["nseg"]), str(workload["fixed_iters"])]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout_s)
+            ev = [float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("kernel ms")]
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not ev or not files:
+                return None
+            by = {}
+            for row in csv.DictReader(open(files[0])):
+                if "k_iterate" in row["Kernel_Name"]:
+                    q = by.setdefault(row["Counter_Name"], {})
+                    q[int(row["Dispatch_Id"])] = q.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
+            for n, q in by.items():
+                c[n] = q[max(q)]
+            ms.append(ev[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_ACTIVE_INST_VALU",
+            "SQ_BUSY_CU_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT")
+    if any(k not in c for k in need):
+        return None
+    it = float(workload["batch"] * workload["fixed_iters"])
+    arith = c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]
+    return {"kernel_ms_under_pmc": ms, "counters": c,
+            "derived": {"valu_insts_per_ddp_iteration": c["SQ_INSTS_VALU"] / it,
+                        "lds_insts_per_ddp_iteration": c.get("SQ_INSTS_LDS", 0.0) / it,
+                        "f64_arith_frac_of_valu": arith / c["SQ_INSTS_VALU"],
+                        "f64_flops_per_ddp_iteration": (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) * 64 / it,
+                        "valu_busy_frac_per_simd": c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CU_CYCLES"],
+                        "lds_busy_frac_per_cu": c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"],
+                        "lds_bank_conflict_frac_of_lds_cycles": c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0)}}
+
+
+def live_cluster_pmc(timeout_s=200):
+    """L1 line accesses and HBM fetch of k_convex, measured NOW: two rocprofv3 --pmc passes over the cluster generator's
+    own 64-seed run (tests/soak/cluster_bench.py 64: a 2-seed warm-up and six 64-seed calls), summed over k_convex's
+    dispatches.  Returns the dict corridor_clusters_line reads from a committed profile, or None."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    script = os.path.join(ROOT, "tests", "soak", "cluster_bench.py")
+    if not os.path.exists(rp) or not os.path.exists(script):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_cl_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = {}
+    try:
+        for name in ("TCP_TOTAL_CACHE_ACCESSES_sum", "FETCH_SIZE"):
+            d = os.path.join(tmp, name)
+            r = subprocess.run([rp, "--pmc", name, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "q", "--", sys.executable, script, "64"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            tot = 0.0
+            for row in csv.DictReader(open(files[0])):
+                if "k_convex" in row["Kernel_Name"] and row["Counter_Name"] == name:
+                    tot += float(row["Counter_Value"])
+            if tot <= 0:
+                return None
+            out[name] = tot
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"k_convex": out, "generation_calls_of_64_seeds": 6, "_file": None}
+
+
 def hbm_copy_gbs(torch, dev):
     """Measured HBM bandwidth of a device-to-device copy (read + write bytes / time): the second, measured
     denominator SURVEY.md 8(d) asks for next to the 8 TB/s datasheet figure."""
@@ -219,7 +319,7 @@ def label_model_line(torch, dev, B, with_cpu):
 L1_PEAK_GBS = 39300.0  # vector L1: 64 B per clock and CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md: 32 KiB L1 per CU, 2.4 GHz)
 
 
-def corridor_clusters_line(dev, with_cpu):
+def corridor_clusters_line(dev, with_cpu, live=True):
     """SURVEY.md 8(f-4), reported SEPARATELY: seed voxels -> voxel clusters -> polytope planes on the device
     (include/direct_cluster.h; polyhedron_generator + poly_utils.cpp:127-206, 282-389), 64 seeds on a synthetic
     200 x 200 x 40 map, clusters left on the device, planes back to the host.  Not part of `value`.
@@ -248,8 +348,11 @@ def corridor_clusters_line(dev, with_cpu):
            "planes_mean": float(hp["n_planes"].mean()),
            "planes_max": int(hp["n_planes"].max()), "seeds_ok": int(((r["rtn"] == 0) & (hp["rtn"] == 0)).sum()),
            "note": "bit-identical to the reference's CPU path (clusters) / exact facet planes pinned against its quickhull: tests/test_gpu_cluster.py, tests/test_gpu_hull.py"}
-    pmc = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cluster_pmc.json")), reverse=True):
+    pmc = live_cluster_pmc() if live else None
+    pmc_kind = "live: TCP_TOTAL_CACHE_ACCESSES / FETCH_SIZE passes of tests/soak/cluster_bench.py 64 on this box, in this run"
+    for f in ([] if pmc is not None else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cluster_pmc.json")), reverse=True)):
+        pmc_kind = ("static: committed PMC profile of tests/soak/cluster_bench.py 64 (L1 accesses and HBM fetch per call), "
+                    "this run's kernel time")
         try:
             pmc = json.load(open(f))
             pmc["_file"] = os.path.relpath(f, ROOT)
@@ -275,8 +378,7 @@ def corridor_clusters_line(dev, with_cpu):
         ach = byts / (kms * share * 1e-3) / 1e9
         out["roofline"] = {"bound": "l1", "kernel": "k_convex", "achieved": ach, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": ach / L1_PEAK_GBS,
                            "traffic": pmc["k_convex"].get("FETCH_SIZE", 0) * 1024.0 * 2 / calls if "FETCH_SIZE" in pmc["k_convex"] else None,
-                           "traffic_kind": "static: committed PMC profile of tests/soak/cluster_bench.py 64 (L1 accesses and HBM fetch per call), "
-                                           "this run's kernel time", "source": pmc["_file"]}
+                           "traffic_kind": pmc_kind, "source": pmc["_file"]}
     if with_cpu:
         from oracle import clusterapi as ca
         ca.use_reference_convex_test(ca.ref_lib() is not None)
@@ -290,6 +392,54 @@ def corridor_clusters_line(dev, with_cpu):
         out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/seed", "cores": 1, "kind": kind,
                                "sample": "%d of the 64 seeds: serialConvexTest of polyhedron_generator/src/cluster_engine_cpu.cpp (oracle/_ref) "
                                          "inside the restated loops of cluster_server_cpu.cpp:257-528, one thread" % m}
+    return out
+
+
+def single_plan_line(dev, with_cpu):
+    """The reference's actual call pattern: ONE corridor, planned when the user clicks (teach_repeat_planner.cpp:895-921:
+    phase 0, UpdateTime, phase 1), host buffers in and out.  The corridor is a real one: a 12-segment replay plan of the
+    voxel-map -> corridorGeneration chain (direct_amd/data/real_corridor_n12.npz, tools/make_real_corridor_fixture.py),
+    double storage like the reference.  Wall time of direct_ddp_plan_batch with batch = 1 (H2D of the corridor, both
+    phases' kernels, D2H of the coefficients), median of 20 calls; the oracle on one host thread beside it.  Never `value`."""
+    from direct_amd import abi, solver
+    f = os.path.join(ROOT, "direct_amd", "data", "real_corridor_n12.npz")
+    if not os.path.exists(f):
+        return None
+    d = np.load(f)
+    batch = abi.HostBatch(d["n_seg"], d["x0"], d["xd"], d["T0"], d["n_planes"], d["planes"], seeds=d["seeds"])
+    p0, p1 = abi.phase0_params(), abi.phase1_params()
+    s = solver.DdpSolver(1, batch.n_seg_max, batch.p_max, np.float64, device=dev.index or 0)
+    s.plan(p0, p1, batch)
+    ts, ks = [], []
+    for _ in range(20):
+        t = time.perf_counter()
+        g0, g1 = s.plan(p0, p1, batch)
+        ts.append(time.perf_counter() - t)
+        ks.append(s.last_kernel_ms()[0])
+    li = s.launch_info()
+    s.close()
+    its = int(g0.fwd_passes.sum() + g1.fwd_passes.sum())
+    ms = float(np.median(ts)) * 1e3
+    out = {"workload": "1 real corridor, N=%d segments, widest polytope %d planes, f64 storage, two-phase plan (phase 0 + UpdateTime + phase 1), host buffers"
+                       % (int(batch.n_seg[0]), int(batch.p_max)),
+           "ms_per_plan": ms, "ms_per_plan_min": float(np.min(ts)) * 1e3, "phase1_kernel_ms": float(np.median(ks)),
+           "iterations": its, "iter_per_s": its / (ms * 1e-3), "rtn": [int(g0.rtn[0]), int(g1.rtn[0])],
+           "schedule": {k: li.get(k) for k in ("dynamic", "shared_search", "shared_sweep", "single_steps", "resident_waves")},
+           "source": str(d["source"])}
+    if with_cpu:
+        from oracle import refapi
+        refapi.build()
+        refapi.plan_batch(p0, p1, batch)
+        t = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            r0, r1 = refapi.plan_batch(p0, p1, batch)
+        cms = (time.perf_counter() - t) * 1e3 / reps
+        out["cpu_baseline"] = {"value": cms, "unit": "ms/plan", "cores": 1, "kind": "port",
+                               "sample": "the same plan, oracle/direct_ref.c, one host thread, mean of %d" % reps,
+                               "iterations": int(r0.fwd_passes.sum() + r1.fwd_passes.sum()),
+                               "same_rtn_and_iterations": bool(r1.rtn[0] == g1.rtn[0] and r1.iter_used[0] == g1.iter_used[0]
+                                                               and r0.rtn[0] == g0.rtn[0] and r0.iter_used[0] == g0.iter_used[0])}
     return out
 
 
@@ -330,7 +480,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]; 6 = config 4's shape in feasible mode")
     ap.add_argument("--batch", type=int, default=0, help="corridors per GPU (0 = the config's)")
     ap.add_argument("--nseg", type=int, default=0)
     ap.add_argument("--kind", default="", choices=["", "free", "corridor"])
@@ -381,8 +531,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the library has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # DIRECT_BENCH_FORCE_DIST=1: every branch of the N > 1 path (RCCL process group, the all-reduces, the object
+    # broadcast, the library's communicator) runs at world size 1 too - so that each of its lines has executed on a GPU
+    # before the first multi-GPU run (tests/test_gpu_configs.py); the timed region is the same
+    dist_on = world > 1 or os.environ.get("DIRECT_BENCH_FORCE_DIST", "0") not in ("", "0")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     np_dt = np.float32 if cfg["dtype"] == "f32" else np.float64
@@ -413,7 +568,7 @@ def main():
         s.solve_device(params, cin, cout)
 
     def sync_all():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -427,7 +582,7 @@ def main():
         kernel_ms.append(s.last_kernel_ms()[0])  # HIP events around the hot kernel on its own stream
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -435,7 +590,7 @@ def main():
         raise SystemExit("the ticket scheduler reported an error: results are invalid")
     launch = s.launch_info()  # how the timed launch was scheduled + the sweep work it executed
     rank_kernel_ms = [float(np.mean(kernel_ms))]
-    if world > 1:  # stragglers show: every rank's mean kernel time
+    if dist_on:  # stragglers show: every rank's mean kernel time
         km = torch.zeros(world, dtype=torch.float64, device=dev)
         km[rank] = rank_kernel_ms[0]
         dist.all_reduce(km, op=dist.ReduceOp.SUM)
@@ -444,7 +599,7 @@ def main():
     # the mode every trajectory's timed iterations ran in (taken now: the secondary solves reuse the output arrays)
     infeas_mask = outs["infeas_out"].cpu().numpy().astype(bool)
     total = torch.tensor([float(iters_step)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
     iters_all = float(total.item()) * args.steps
 
@@ -457,11 +612,12 @@ def main():
     blk_src = max(li, 0)
     block = torch.cat([outs["bez"][blk_src].reshape(-1), outs["T"][blk_src].reshape(-1)])
     tg = time.perf_counter()
-    bc, bidx, owner, blk = distributed.gather_best(lc, first + li if li >= 0 else -1, block)
+    bc, bidx, owner, blk = distributed.gather_best(lc, first + li if li >= 0 else -1, block, force_collective=dist_on)
     torch.cuda.synchronize()
-    gather = {"torch_ms": (time.perf_counter() - tg) * 1e3, "best_cost": bc, "best_index": bidx, "owner": owner}
+    gather = {"torch_ms": (time.perf_counter() - tg) * 1e3, "best_cost": bc, "best_index": bidx, "owner": owner,
+              "forced_dist_path": bool(dist_on and world == 1)}
     devices = [local]
-    if world > 1:  # every torch.distributed exchange the line needs happens BEFORE the library's own communicator is tried
+    if dist_on:  # every torch.distributed exchange the line needs happens BEFORE the library's own communicator is tried
         got = [None] * world
         dist.all_gather_object(got, (rank, local, torch.cuda.get_device_name(local)))
         devices = got
@@ -471,7 +627,7 @@ def main():
         uid = [s.rccl_unique_id() if rank == 0 else None]
     except Exception as e:  # noqa: BLE001
         gather.update({"c_abi_error": repr(e)})
-    if world > 1:
+    if dist_on:
         dist.broadcast_object_list(uid, src=0)  # None: rank 0 could not talk to RCCL, nobody tries
 
     def c_abi_gather(res):
@@ -554,11 +710,15 @@ def main():
                    "iterations_max": int(fp.max()), "iterations_min": int(fp.min()),
                    "rtn_histogram": {str(int(v)): int(c) for v, c in zip(*np.unique(rt, return_counts=True))}}
         hbm_copy = hbm_copy_gbs(torch, dev)
-    label, clusters = None, None
+    label, clusters, single = None, None, None
     if not args.no_secondary and rank == 0:
+        try:
+            single = single_plan_line(dev, not args.no_cpu_baseline and world == 1)
+        except Exception as ex:  # a secondary block never takes the line down
+            single = {"error": str(ex)[:200]}
         label = label_model_line(torch, dev, B, not args.no_cpu_baseline and world == 1)
         try:
-            clusters = corridor_clusters_line(dev, not args.no_cpu_baseline and world == 1)
+            clusters = corridor_clusters_line(dev, not args.no_cpu_baseline and world == 1, live=not args.no_live_traffic)
         except Exception as ex:  # a secondary block never takes the line down
             clusters = {"error": str(ex)[:200]}
 
@@ -595,7 +755,18 @@ def main():
             numer, numer_kind = float(traffic["traffic_bytes_per_launch"]), "measured HBM traffic (below the algorithmic figure)"
         achieved = numer / (avg_ms * 1e-3) / 1e9
         value = iters_all / dt
-        sq = matching_profile("r*_sq_counters.json", workload)
+        sq, sq_source = None, None
+        if world == 1 and not args.no_live_traffic and not args.no_secondary:
+            sq = live_sq_counters(workload)
+            if sq is not None and max(abs(m / avg_ms - 1.0) for m in sq["kernel_ms_under_pmc"]) > 0.10:
+                sq = None
+            if sq is not None:
+                sq_source = "live"
+        if sq is None:
+            sq = matching_profile("r*_sq_counters.json", workload)
+            sq_source = None if sq is None else "static: " + sq["_file"]
+        fwd_passes_launch = max(1, iters_step)
+        accepted = launch.get("accepted_line_searches")
         line = {
             "metric": "ddp_iterations_per_sec", "value": value, "unit": "iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -610,8 +781,8 @@ def main():
                        "storage_dtype": cfg["dtype"], "kind": cfg["kind"], "devices": devices,
                        "total_corridors": B * world,
                        # what the library actually did with this launch (direct_ddp_last_launch_info, rank 0)
-                       "schedule": {k: launch[k] for k in ("dynamic", "shared_search", "pair_trials", "single_steps",
-                                                           "n_buffers", "resident_waves")}},
+                       "schedule": {k: launch.get(k) for k in ("dynamic", "shared_search", "shared_sweep", "pair_trials", "single_steps",
+                                                               "n_buffers", "resident_waves")}},
             # bound "hbm" is the roofline BASELINE.json's north_star stipulates; the counters say the kernel is
             # instruction-issue bound, which roofline_compute prices
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -627,6 +798,11 @@ def main():
                          # the same words under the unit formula's assumption (one FULL forward trial per iteration)
                          "algorithmic_bytes_unit_formula": bytes_unit_formula,
                          "infeasible_mode_frac": float(infeas_mask.mean()),
+                         # what the iterations of the timed launch were: line searches that accepted a step / that ended
+                         # with fp_failed (DDP:760-762: the iterate does not move), forward trial-knots per backward knot
+                         "accepted_step_frac": None if accepted is None else accepted / fwd_passes_launch,
+                         "fp_failed_frac": None if accepted is None else 1.0 - accepted / fwd_passes_launch,
+                         "fwd_per_bwd_knot": launch["fwd_knot_visits"] / max(1, launch["bwd_knot_visits"]),
                          # sweep work the launch really executed (forward trials cut short by the fraction-to-boundary
                          # rule count the knots they reached)
                          "bwd_knot_visits": launch["bwd_knot_visits"], "fwd_trial_knot_visits": launch["fwd_knot_visits"],
@@ -643,15 +819,19 @@ def main():
                                         "frac": tf / F64_VECTOR_PEAK_TF, "valu_busy": sq["derived"]["valu_busy_frac_per_simd"],
                                         "f64_arith_frac_of_valu": sq["derived"]["f64_arith_frac_of_valu"],
                                         "valu_insts_per_ddp_iteration": sq["derived"]["valu_insts_per_ddp_iteration"],
-                                        "source": sq["_file"],
-                                        "note": "flops per DDP iteration counted by rocprofv3 (committed profile of this "
-                                                "workload, all 64 lanes of an instruction counted) x this run's kernel rate"}
+                                        "lds_busy": sq["derived"].get("lds_busy_frac_per_cu"),
+                                        "lds_bank_conflict_frac_of_lds_cycles": sq["derived"].get("lds_bank_conflict_frac_of_lds_cycles"),
+                                        "source": sq_source,
+                                        "note": "flops per DDP iteration counted by rocprofv3 (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of the "
+                                                "timed launch, all 64 lanes of an instruction counted) x this run's kernel rate"}
         if sustained is not None:
             line["sustained_ms_per_step_100"] = sustained
         if e2e is not None:
             line["e2e_host_buffers"] = e2e
         if natural is not None:
             line["natural_exit"] = natural
+        if single is not None:
+            line["single_plan_latency"] = single
         if label is not None:
             line["label_model"] = label
             line["corridor_clusters"] = clusters
@@ -662,7 +842,7 @@ def main():
         sys.stderr.flush()
         os._exit(0)
     s.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

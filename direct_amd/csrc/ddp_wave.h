@@ -31,6 +31,8 @@ using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::lo
 // GPU silently uses lane 0's value for all of them.  emu_lane is the lane being emulated (64 outside blocks).
 inline int& emu_lane() { static thread_local int l = 64; return l; }
 template <typename T>
+inline T* uniform_ptr(T* p) { return p; }
+template <typename T>
 inline T emu_uniform(T x, int line) {
   static thread_local unsigned char seen[4096][sizeof(double)];
   const int l = emu_lane();
@@ -276,6 +278,11 @@ __device__ __forceinline__ void row_fnma(double& acc, double a, double b) {
 __device__ __forceinline__ float uniform_real(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long a = (unsigned long long)p;
+  return (T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+}
 __device__ __forceinline__ double uniform_real(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -412,7 +419,7 @@ struct BwdShare {
   unsigned long long claim;  // free knots [low, high): low in bits 0..31 (helpers take from below), high + 2^30 in bits 32..63 (the owner from above)
 };
 constexpr int kRecDoubles = 384;  // one knot's hand-over record: six doubles per lane, stored as three 16-byte halves per lane
-constexpr int kOwnChunk = 4, kHelpChunk = 4;  // knots per claim
+constexpr int kOwnChunk = 2, kHelpChunk = 4;  // knots per claim (the owner takes little: a knot it runs fused costs it twice a knot from a record)
 constexpr unsigned long long kClaimBias = 1ull << 30;
 
 // ---- device-resident batch (all pointers are device memory) -----------------------------------
@@ -449,12 +456,13 @@ struct Batch {
   int* live;  // trajectories of the launch still in their outer loop (ticket scheduler; null otherwise): when no more
               // than tail_thresh are left the line searches switch to single steps open from step 0 - few trajectories on
               // many waves, the tail of a natural-exit launch (scheduling only)
-  unsigned long long* visits;  // [2] knots executed by backward sweeps / by forward trials (observability; may be null)
+  unsigned long long* visits;  // [4] knots executed by backward sweeps / by forward trials, -, accepted line searches (observability; may be null)
   // helper-assisted backward sweep: null / 0 = every sweep stays with its owner
   BwdShare* bshare;  // [B]
   int* bflag;        // [B][nmax]: tag of the sweep whose record of this knot is complete
   double* brec;      // [B][nmax][kRecDoubles]
   int bforce;        // tests: the owner itself runs the helpers' half first (every knot but its first claim goes through a record)
+  const void* self;  // this very struct in device memory: what the out-of-line halves of a shared sweep (front_cold, back_cold) are handed
   unsigned long long* bvisits;  // [1] knots whose front half a helper (or the forced split) computed (observability; may be null)
 #if defined(DDP_TIMELINE)  // debug builds (tools/timeline.py): wall-clock stamps per trajectory and outer iteration
   unsigned long long* tl;  // [B][32][4]: start, end of the backward sweeps, end (100 MHz), knots that came through records
@@ -696,10 +704,36 @@ struct RowK {
   Real n0, n1, n2, o;
 };
 
+// The two halves of a SHARED backward sweep that are not the fused knot (Wave::bwd_front_run, Wave::bwd_back_run) are
+// real function calls, compiled on their own: inlined next to the fused sweep and the forward rounds - one function
+// of 14 k instructions at the register limit of three waves per SIMD - they cost the FUSED path 8 .. 20 % through
+// register allocation alone (spills moved into the forward rounds; same-box A/B, round 5), although a launch that
+// shares nothing never executes them.  The callee rebuilds its own Wave from the device copy of the Batch
+// (Batch::self) and the wave's LDS; what it exchanges with the caller goes through private memory.
+#if defined(DIRECT_EMULATE)
+#define DDP_COLD inline
+template <typename T>
+using LdsPtr = T*;
+#else
+#define DDP_COLD __device__ __attribute__((noinline))
+template <typename T>
+using LdsPtr = __attribute__((address_space(3))) T*;
+#endif
+template <typename Real, typename St, int RPL, bool SHARE = false>
+struct Wave;
+template <typename Real, typename St, int RPL>
+DDP_COLD void front_cold(const Batch<St>* Bg, LdsPtr<WaveLds<Real, St, RPL>> lds, int b, int N, int tag, int cur, int infeas, double mu);
+template <typename Real, typename St, int RPL>
+DDP_COLD void back_cold(const Batch<St>* Bg, LdsPtr<WaveLds<Real, St, RPL>> lds, int b, int N, void* io);
+
 // ------------------------------------------------------------------------------------------------
 // Real = arithmetic type of the per-row / roll-out work, St = storage type of everything in HBM
 // (the dtype of the C-ABI), Acc (double) = type of the condensed system.
-template <typename Real, typename St, int RPL>
+// SHARE: the instantiation can share its backward sweeps with helper waves (bwd_knot MODE 1 / 2, the claim protocol).  The
+// hot kernels exist WITH and WITHOUT it (direct_ddp.hip): the kernel sits on the register cliff of three waves per
+// SIMD, and the mere presence of the protocol's few live values costs the fused path 7 % (spills move into the forward
+// rounds; same-box A/B, round 5) - launches that have no idle waves run the instantiation without it.
+template <typename Real, typename St, int RPL, bool SHARE>
 struct Wave {
   typedef WaveLds<Real, St, RPL> Lds;
   const Batch<St>& B;
@@ -757,15 +791,18 @@ struct Wave {
       int bi = i == 0 ? cur : (i == 1 ? t0 : t1);
       if (bi < 0) bi = cur;
       bi = DDP_UNIFORM_I(bi);
-      sp.X[i] = (GSt*)B.X[bi];
-      sp.S[i] = (GSt*)B.S[bi];
-      sp.Y[i] = (GSt*)B.Y[bi];
+      sp.X[i] = (GSt*)uniform_ptr(B.X[bi]);
+      sp.S[i] = (GSt*)uniform_ptr(B.S[bi]);
+      sp.Y[i] = (GSt*)uniform_ptr(B.Y[bi]);
       DDP_OPAQUE_S(sp.X[i]);
       DDP_OPAQUE_S(sp.S[i]);
       DDP_OPAQUE_S(sp.Y[i]);
     }
-    sp.KS = (GSt*)B.KS; sp.KY = (GSt*)B.KY; sp.KU = (GSt*)B.KU; sp.planes = (GCSt*)B.planes;
-    sp.n_planes = (GCInt*)B.n_planes;
+    // (uniform_ptr: in the out-of-line halves of a shared sweep the Batch is read from memory, and the compiler does not
+    // take every one of these loads for wave-uniform; on kernel arguments it folds away)
+    sp.KS = (GSt*)uniform_ptr(B.KS); sp.KY = (GSt*)uniform_ptr(B.KY); sp.KU = (GSt*)uniform_ptr(B.KU);
+    sp.planes = (GCSt*)uniform_ptr(B.planes);
+    sp.n_planes = (GCInt*)uniform_ptr(B.n_planes);
     DDP_OPAQUE_S(sp.KS);
     DDP_OPAQUE_S(sp.KY);
     DDP_OPAQUE_S(sp.KU);
@@ -1451,7 +1488,7 @@ struct Wave {
     PLV(BRec, rc);       // back: the knot's record; front: the record being formed
   };
 #ifndef DDP_KSPLIT
-#define DDP_KSPLIT (RPL <= 4)
+#define DDP_KSPLIT (SHARE && RPL <= 4)
 #endif
   static constexpr bool kSplit = DDP_KSPLIT;  // the helper-assisted sweep is built for the narrow classes only (long trajectories: N >= 80)
 
@@ -1459,7 +1496,7 @@ struct Wave {
   // RMW, so owner and helpers need no fences between them: open = add (tag << 8), enter = add 1 and look at the old tag,
   // close = and 0xff and look at the old count.  Records and flags are written through (sc1) and drained (vmcnt(0))
   // before the flag, and read with sc1 loads issued only after the flag has been seen (MI355X_MICROARCH.md, hand-off forms).
-  DDP_DEV BwdShare* bshare_slot() const { return (kSplit && B.bshare) ? &B.bshare[b] : nullptr; }
+  DDP_DEV BwdShare* bshare_slot() const { return (kSplit && B.bshare && B.self) ? &B.bshare[b] : nullptr; }
   DDP_DEV double* rec_ptr(int k) const { return B.brec + ((size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k)) * kRecDoubles; }
   DDP_DEV int* flag_ptr(int k) const { return B.bflag + (size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k); }
 #if !defined(DIRECT_EMULATE)
@@ -2388,17 +2425,80 @@ struct Wave {
     if (B.bvisits != nullptr && threadIdx.x == 0 && done) atomicAdd(B.bvisits, (unsigned long long)done);
 #endif
   }
-  // a wave that waits for trajectory b's next ticket: join the sweep b's owner has open
-  DDP_DEV_NOINLINE void bwd_help() {
-    DDP_LAUNDER_S(b);
-    DDP_LAUNDER_S(N);
+  // owner: publish the backward sweep that is about to run (iterate_once; bwd_sweep_t picks the tag up and closes it)
+  int sh_tag = 0, sh_kfloor = 0;
+  DDP_DEV void bwd_share_open() {
     BwdShare* bs = bshare_slot();
+    sh_tag = 0;
     if (bs == nullptr) return;
-    int tag = 0, cur = 0, infeas = 0;
-    double mu_d = 0.0;
-    if (!bs_enter(bs, tag, cur, infeas, mu_d)) return;
-    bwd_front_run(bs, tag, cur, infeas, mu_d);
-    bs_leave(bs);
+    sh_kfloor = N > kOwnChunk ? N - kOwnChunk : 0;
+    sh_tag = bs_open(bs, DDP_UNIFORM_I(st.cur), DDP_UNIFORM_I(st.infeas), st.mu, sh_kfloor);
+  }
+
+  // ---- the owner's half of a shared sweep below the knots it ran fused: the back halves of knots ks .. 0 from the
+  // helpers' records.  The flag of a knot is asked for two knots ahead and its record one knot ahead (only once the flag
+  // has been seen: the loads must not overtake it); a record that is late is waited for.
+  struct BackIO {  // what bwd_sweep_t hands over and gets back
+    int regi, buf, infeas, tag, ks, ok, kfail;
+    Acc lam, emu_u;
+    PLV(Acc, e_qu);
+  };
+  DDP_DEV void bwd_back_run(BackIO& io) {
+    BwdCtx C;
+    C.regi = DDP_UNIFORM_I(io.regi); C.buf = DDP_UNIFORM_I(io.buf); C.infeas = DDP_UNIFORM_I(io.infeas); C.klo = 0;
+    C.lam = DDP_UNIFORM_R(io.lam);
+    C.sig = C.infeas ? (Acc)1 : (Acc)-1;
+    C.mu = (Real)0;
+    C.wsn = (Real)B.k.w_snap;
+    C.emu_u = DDP_UNIFORM_R(io.emu_u);
+    C.Pn = 0; C.Pnn = 0;
+    const int tag = DDP_UNIFORM_I(io.tag), ks = DDP_UNIFORM_I(io.ks);
+    set_sweep_ptrs(C.buf);
+    LANES {
+      LV(C.e_mu) = 0;
+      LV(C.e_qu) = LV(io.e_qu);
+    }
+    int ok = 1, kfail = 0;
+    int have = flag_wait(ks, tag);
+    if (have) {
+      LANES { rec_load(ks, LV(C.rc), lane); }
+    }
+    PLV(int, fl);
+    LANES { LV(fl) = ks > 0 ? flag_peek(ks - 1) : 0; }
+    PLV(BRec, rn);
+#pragma unroll 1
+    for (int k_ = ks; k_ >= 0 && have; k_--) {
+      int next = 0;
+      if (k_ > 0) {
+        if (RDLANE_I(fl, 0) == tag) {
+          LANES { rec_load(k_ - 1, LV(rn), lane); }
+          next = 1;
+        }
+        LANES { LV(fl) = k_ > 1 ? flag_peek(k_ - 2) : 0; }
+      }
+      ok = bwd_knot<2, false>(C, k_);
+      if (!ok) {
+        kfail = k_;
+        break;
+      }
+      if (k_ > 0) {
+        if (!next) {
+          have = flag_wait(k_ - 1, tag);
+          if (have) {
+            LANES { rec_load(k_ - 1, LV(rn), lane); }
+          }
+        }
+        LANES { LV(C.rc) = LV(rn); }
+      }
+    }
+    if (!have) {  // a record never came (the protocol's error flag is up): the sweep counts as failed
+      ok = 0;
+      kfail = 0;
+    }
+    io.ok = ok;
+    io.kfail = kfail;
+    io.emu_u = C.emu_u;
+    LANES { LV(io.e_qu) = LV(C.e_qu); }
   }
 
   template <bool kGains>
@@ -2426,18 +2526,13 @@ struct Wave {
     C.emu_u = (Acc)0;
     const int buf = C.buf, infeas = C.infeas;
 
-    // Shared sweep: publish it (the top kOwnChunk knots are the owner's from the start).  In the tests' forced split the
-    // owner plays the helper first - before its own sweep, whose value function and prefetch live where the front
-    // halves' operands do.
-    BwdShare* bs = kGains ? nullptr : bshare_slot();
-    int kfloor = 0, tag = 0;
+    // Shared sweep: iterate_once has published it (bwd_share_open: the top kOwnChunk knots are the owner's from the start)
+    BwdShare* bs = (kGains || sh_tag == 0) ? nullptr : bshare_slot();
+    int kfloor = bs != nullptr ? sh_kfloor : 0;
+    const int tag = sh_tag;
+    sh_tag = 0;
     Pend pend;
     pend.lo = 0; pend.hi = 0;
-    if (bs != nullptr) {
-      kfloor = N > kOwnChunk ? N - kOwnChunk : 0;
-      tag = bs_open(bs, buf, infeas, st.mu, kfloor);
-      if (B.bforce) bwd_front_run(bs, tag, buf, infeas, st.mu);
-    }
     set_sweep_ptrs(buf);
 
     // terminal derivatives (DDP:1318-1323)
@@ -2491,45 +2586,16 @@ struct Wave {
     tl_split_ += ks + 1;
 #endif
     if constexpr (kSplit && !kGains) {
-      if (ok && ks >= 0) {
-        // ---- the knots helpers have prepared.  The flag of a knot is asked for two knots ahead and its record one knot
-        // ahead (only once the flag has been seen: the loads must not overtake it); a record that is late is waited for.
-        int have = flag_wait(ks, tag);
-        if (have) {
-          LANES { rec_load(ks, LV(C.rc), lane); }
-        }
-        PLV(int, fl);
-        LANES { LV(fl) = ks > 0 ? flag_peek(ks - 1) : 0; }
-        PLV(BRec, rn);
-#pragma unroll 1
-        for (int k_ = ks; k_ >= 0 && have; k_--) {
-          int next = 0;
-          if (k_ > 0) {
-            if (RDLANE_I(fl, 0) == tag) {
-              LANES { rec_load(k_ - 1, LV(rn), lane); }
-              next = 1;
-            }
-            LANES { LV(fl) = k_ > 1 ? flag_peek(k_ - 2) : 0; }
-          }
-          ok = bwd_knot<2, false>(C, k_);
-          if (!ok) {
-            kfail = k_;
-            break;
-          }
-          if (k_ > 0) {
-            if (!next) {
-              have = flag_wait(k_ - 1, tag);
-              if (have) {
-                LANES { rec_load(k_ - 1, LV(rn), lane); }
-              }
-            }
-            LANES { LV(C.rc) = LV(rn); }
-          }
-        }
-        if (!have) {  // a record never came (the protocol's error flag is up): the sweep counts as failed
-          ok = 0;
-          kfail = 0;
-        }
+      if (ok && ks >= 0) {  // the knots helpers have prepared: out of line (see front_cold / back_cold)
+        BackIO io;
+        io.regi = C.regi; io.buf = buf; io.infeas = infeas; io.tag = tag; io.ks = ks; io.ok = 1; io.kfail = 0;
+        io.lam = C.lam; io.emu_u = C.emu_u;
+        LANES { LV(io.e_qu) = LV(C.e_qu); }
+        back_cold<Real, St, RPL>((const Batch<St>*)B.self, (LdsPtr<Lds>)&L, b, N, (void*)&io);
+        ok = DDP_UNIFORM_I(io.ok);
+        kfail = DDP_UNIFORM_I(io.kfail);
+        C.emu_u = DDP_UNIFORM_R(io.emu_u);
+        LANES { LV(C.e_qu) = LV(io.e_qu); }
       }
     }
     if (bs != nullptr) bs_close(bs);
@@ -3262,6 +3328,7 @@ struct Wave {
       st.fp_failed = 1;
       st.stepsize = 0.0;
     } else {  // DDP:763-776
+      count_visits(3, 1);
       st.nfilter = A.nkeep + 1;
       st.cost = A.cost;
       st.costq = A.costq;
@@ -3280,19 +3347,36 @@ struct Wave {
 
   // ---- one trip of the outer loop (DDP:295-412).  Sets st.done when the loop breaks. ------------
   // helper != 0: no trip at all - this wave joins what trajectory b's owner has open: 1 its line search (fwd_pass),
-  // 2 its backward sweep (bwd_help)
+  // 2 its backward sweep (bwd_front_run)
   DDP_DEV void iterate_once(int helper = 0) {
-    if (helper == 2) {
-      bwd_help();
-      return;
-    }
+    // The helpers' half of a shared backward sweep: a waiting wave (helper == 2) joins the sweep that trajectory b's owner
+    // has open; in the tests' forced split the owner itself plays the helper before each of its sweeps.
+    BwdShare* bsf = bshare_slot();
+    int f_tag = 0, f_cur = 0, f_infeas = 0;
+    double f_mu = 0.0;
+    if (helper == 2 && (bsf == nullptr || !bs_enter(bsf, f_tag, f_cur, f_infeas, f_mu))) return;
 #if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
     unsigned long long* tl_ = (!helper && B.tl != nullptr && st.fwd_passes < 32) ? B.tl + ((size_t)b * 32 + st.fwd_passes) * 4 : nullptr;
     if (tl_ != nullptr && threadIdx.x == 0) { tl_[0] = __builtin_amdgcn_s_memrealtime(); tl_[3] = 0; }
     tl_split_ = 0;
 #endif
-    if (!helper) {
+    if (helper != 1) {
+#pragma unroll 1
       while (true) {  // DDP:297-310
+        if (!helper) {
+          bwd_share_open();
+          if (sh_tag != 0 && B.bforce) {
+            f_tag = sh_tag; f_cur = DDP_UNIFORM_I(st.cur); f_infeas = DDP_UNIFORM_I(st.infeas); f_mu = st.mu;
+          }
+        }
+        if constexpr (kSplit) {
+          if (f_tag != 0) front_cold<Real, St, RPL>((const Batch<St>*)B.self, (LdsPtr<Lds>)&L, b, N, f_tag, f_cur, f_infeas, f_mu);
+        }
+        f_tag = 0;
+        if (helper == 2) {
+          bs_leave(bsf);
+          return;
+        }
         if (bwd_sweep()) break;
         if (st.reg == 24 && st.bp_failed) st.bp_no_upd++;
         else st.bp_no_upd = 0;
@@ -3386,6 +3470,36 @@ struct Wave {
   }
 };
 
+// The launch's Batch as the callee sees it: the device copy itself.  The callee's arguments arrive in vector registers;
+// the pointer is made wave-uniform, so that everything loaded through it is uniform for the compiler as well (a
+// kernel argument's fields are; the sweep pins some of them in scalar registers).
+template <typename St>
+DDP_DEV const Batch<St>& batch_of(const Batch<St>* Bg) {
+#if defined(DIRECT_EMULATE)
+  return *Bg;
+#else
+  const unsigned long long a = (unsigned long long)Bg;
+  const unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+  typedef __attribute__((address_space(1))) const Batch<St> GB;
+  return *(const Batch<St>*)(GB*)u;
+#endif
+}
+template <typename Real, typename St, int RPL>
+DDP_COLD void front_cold(const Batch<St>* Bg, LdsPtr<WaveLds<Real, St, RPL>> lds, int b, int N, int tag, int cur, int infeas, double mu) {
+  const Batch<St>& Bl = batch_of(Bg);
+  Wave<Real, St, RPL, true> W(Bl, *(WaveLds<Real, St, RPL>*)lds, DDP_UNIFORM_I(b));
+  W.N = DDP_UNIFORM_I(N);
+  W.bwd_front_run(&Bl.bshare[W.b], DDP_UNIFORM_I(tag), DDP_UNIFORM_I(cur), DDP_UNIFORM_I(infeas), mu);
+}
+template <typename Real, typename St, int RPL>
+DDP_COLD void back_cold(const Batch<St>* Bg, LdsPtr<WaveLds<Real, St, RPL>> lds, int b, int N, void* io) {
+  const Batch<St>& Bl = batch_of(Bg);
+  Wave<Real, St, RPL, true> W(Bl, *(WaveLds<Real, St, RPL>*)lds, DDP_UNIFORM_I(b));
+  W.N = DDP_UNIFORM_I(N);
+  W.bwd_back_run(*(typename Wave<Real, St, RPL, true>::BackIO*)io);
+}
+
 // ---- results (DDP:414-437 and the getters of DDPH:299-340) --------------------------------------
 template <typename Real>
 struct OutPtrs {
@@ -3394,8 +3508,8 @@ struct OutPtrs {
   Real *cost, *costq, *jerk_cost, *terminal_norm2, *opterr, *mu, *bez, *poly, *T;
 };
 
-template <typename Real, typename St, int RPL>
-DDP_DEV void finish_wave(Wave<Real, St, RPL>& W, const OutPtrs<St>& O) {
+template <typename Real, typename St, int RPL, bool SH>
+DDP_DEV void finish_wave(Wave<Real, St, RPL, SH>& W, const OutPtrs<St>& O) {
   const Batch<St>& B = W.B;
   const int b = W.b, N = W.N, buf = W.st.cur;
   PLV(Real, jc);
@@ -3470,8 +3584,8 @@ DDP_DEV void finish_wave(Wave<Real, St, RPL>& W, const OutPtrs<St>& O) {
 
 // ---- stepwise interface helpers: dense read-out / injection of solver fields --------------------
 // Field ids and layouts: include/direct_ddp.h (direct_field_t); nc_max = 6*pmax + 55.
-template <typename Real, typename St, int RPL>
-DDP_DEV void get_field_wave(Wave<Real, St, RPL>& W, int field, St* dst) {
+template <typename Real, typename St, int RPL, bool SH>
+DDP_DEV void get_field_wave(Wave<Real, St, RPL, SH>& W, int field, St* dst) {
   const Batch<St>& B = W.B;
   const int b = W.b, N = W.N, buf = W.st.cur, ncm = 6 * B.pmax + 55;
   if (field == 9) {
@@ -3532,8 +3646,8 @@ DDP_DEV void get_field_wave(Wave<Real, St, RPL>& W, int field, St* dst) {
   }
 }
 
-template <typename Real, typename St, int RPL>
-DDP_DEV void set_field_wave(Wave<Real, St, RPL>& W, int field, const St* src) {
+template <typename Real, typename St, int RPL, bool SH>
+DDP_DEV void set_field_wave(Wave<Real, St, RPL, SH>& W, int field, const St* src) {
   const Batch<St>& B = W.B;
   const int b = W.b, N = W.N, buf = W.st.cur, ncm = 6 * B.pmax + 55;
   if (field == 0) {

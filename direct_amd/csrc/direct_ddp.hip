@@ -96,7 +96,7 @@ struct Sched {
 // t % batch); else continues to wait with ticket `held` in hand.  Waits for the previous chunk of the ticket's trajectory.
 // Returns the ticket, with *help = 0 when its chunk can run now, or *help = 1 when the predecessor is still running and
 // has opened its line search to helpers (ddp_wave.h, fwd_pass): the caller runs a round of it and comes back with the
-// ticket; *help = 2 likewise when the predecessor's backward sweep is open and has unclaimed knots (bwd_help).  -1: no tickets left; -2: the ticket's trajectory has already finished (kDoneBit in done_epoch); -3 - b: the
+// ticket; *help = 2 likewise when the predecessor's backward sweep is open and has unclaimed knots (Wave::iterate_once, bwd_front_run).  -1: no tickets left; -2: the ticket's trajectory has already finished (kDoneBit in done_epoch); -3 - b: the
 // wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early
 // exits on purpose: inlined into the (huge) iterate loop the structuriser turned the nested uniform loops into
 // exec-masked ones.
@@ -150,10 +150,11 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return (int)t;
 }
-template <typename St, int RPL>
+// SHARE: the instantiation whose backward sweeps can be shared with waiting waves (Wave<.., SHARE>; row-slot classes 2 .. 4)
+template <typename St, int RPL, bool SHARE = false>
 __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAVES_WIDE : MinWaves<St>::v))) void k_iterate_dyn(Batch<St> B, int n_iters, Sched S) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
-  Wave<Cmp, St, RPL> W(B, lds, 0);
+  Wave<Cmp, St, RPL, SHARE> W(B, lds, 0);
   W.init_tables();
   const unsigned nb = (unsigned)B.B;
   const unsigned n_epochs = (unsigned)((n_iters + S.chunk - 1) / S.chunk);
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
   for (;;) {
     int help_v = 0;
     DDP_MARK("X_T");
-    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, B.bshare, B.idx, nb, total, held, &waited, &help_v));
+    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, SHARE ? B.bshare : nullptr, B.idx, nb, total, held, &waited, &help_v));
     const int help = __builtin_amdgcn_readfirstlane(help_v);
     DDP_MARK("X_G");
     held = -1;
@@ -351,6 +352,8 @@ struct direct_ddp_handle_s {
   BwdShare* bshare = nullptr;  // [max_batch], allocated with `help` (narrow row-slot classes only)
   int* bflag = nullptr;        // [max_batch][nmax]
   double* brec = nullptr;      // [max_batch][nmax][kRecDoubles]
+  char* batch_dev = nullptr;   // [16][1024]: device copies of the class launches' Batch structs (Batch::self)
+  std::vector<char> batch_host; // their staging copies (a copy must outlive the asynchronous upload)
   int bshare_mode = -1;        // -1 auto (wherever the line search is shared), DIRECT_DDP_BSHARE=0 off, 1 on, 2 forced split: every
                                // owner runs the helpers' half itself first (tests: the hand-over path without any helper)
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
@@ -532,7 +535,7 @@ static hipStream_t class_stream(direct_ddp_handle_t h, size_t ci, size_t n_class
 template <typename Real>
 static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
   const auto classes = batch_classes(h);
-  (void)hipMemsetAsync(h->visits, 0, 2 * sizeof(unsigned long long), h->stream);
+  (void)hipMemsetAsync(h->visits, 0, 4 * sizeof(unsigned long long), h->stream);
   direct_ddp_launch_info_t& li = h->last_info;
   li = direct_ddp_launch_info_t{};
   li.n_buffers = h->nbuf; li.batch = h->B;
@@ -545,7 +548,6 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       (void)hipMemsetAsync(h->bflag, 0, (size_t)h->B * h->nmax * sizeof(int), h->stream);
     }
   }
-  (void)hipMemsetAsync(h->visits + 2, 0, sizeof(unsigned long long), h->stream);
   bool forked = false;
   if (mode == 0 && classes.size() > 1 && class_stream(h, 0, classes.size()) != h->stream) {
     (void)hipEventRecord(h->fork_ev, h->stream);
@@ -588,6 +590,14 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     }
     // backward sweeps shared with helpers wherever the line search is; the forced split needs no helper (any launch form)
     const bool sweep_ok = h->bshare != nullptr && c.rpl <= 4;
+    static_assert(sizeof(Batch<Real>) <= 1024, "Batch grew past its device-copy slot");
+    auto publish = [&](Batch<Real>& Bb) {  // the struct itself in device memory, for the out-of-line halves of a shared sweep
+      if (ci >= 16) { Bb.bshare = nullptr; return; }
+      if (h->batch_host.size() < 16 * 1024) h->batch_host.resize(16 * 1024);
+      Bb.self = h->batch_dev + ci * 1024;
+      memcpy(h->batch_host.data() + ci * 1024, &Bb, sizeof(Bb));
+      (void)hipMemcpyAsync(h->batch_dev + ci * 1024, h->batch_host.data() + ci * 1024, sizeof(Bb), hipMemcpyHostToDevice, st);
+    };
     if (sweep_ok && h->bshare_mode == 2) {
       Bt.bshare = h->bshare; Bt.bflag = h->bflag; Bt.brec = h->brec; Bt.bforce = 1; Bt.bvisits = h->visits + 2;
       if (is_big) li.shared_sweep = 2;
@@ -612,14 +622,31 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
         Bt.live = live;
         Bt.tail_thresh = h->single_ratio > 0 ? slots / h->single_ratio : 0;
         if (is_big) { li.shared_search = 1; li.single_steps = Bt.k.pair_trials ? 0 : 1; }
-        if (sweep_ok && h->bshare_mode != 0 && h->bshare_mode != 2 && h->sched_chunk == 1) {
+        // Shared backward sweeps pay where most waves are idle (a lone N = 100 trajectory 12.2 -> 10.3 ms per 20 iterations,
+        // B = 256 19.1 -> 18.8 ms); from a third of the resident waves on, the waiters' help no longer covers the sharing
+        // instantiation's slower fused path (B = 1024 22.3 -> 23.6 ms, 3072 29.5 -> 32.0, 4096 35.1 -> 37.8; same-box A/B):
+        // auto = batches up to an eighth of the resident waves, like the single-step line search
+        if (sweep_ok && h->bshare_mode != 0 && h->bshare_mode != 2 && h->sched_chunk == 1 && (h->bshare_mode > 0 || 8 * c.cnt <= slots)) {
           Bt.bshare = h->bshare; Bt.bflag = h->bflag; Bt.brec = h->brec; Bt.bforce = 0; Bt.bvisits = h->visits + 2;
           if (is_big) li.shared_sweep = 1;
         }
       }
       if (is_big) li.dynamic = 1;
-      RPL_LAUNCH(c.rpl, st, k_iterate_dyn, Real, slots, Bt, n, S);
+      if (Bt.bshare) {
+        publish(Bt);
+        switch (c.rpl) {  // sweep_ok: row-slot classes 2 .. 4
+          case 2: hipLaunchKernelGGL((k_iterate_dyn<Real, 2, true>), dim3(slots), dim3(64), 0, st, Bt, n, S); break;
+#if !defined(DDP_DEV_RPL2)
+          case 3: hipLaunchKernelGGL((k_iterate_dyn<Real, 3, true>), dim3(slots), dim3(64), 0, st, Bt, n, S); break;
+          default: hipLaunchKernelGGL((k_iterate_dyn<Real, 4, true>), dim3(slots), dim3(64), 0, st, Bt, n, S);
+#endif
+        }
+      } else {
+        RPL_LAUNCH(c.rpl, st, k_iterate_dyn, Real, slots, Bt, n, S);
+      }
     } else {
+      Bt.bshare = nullptr;  // the one-workgroup-per-trajectory kernel has no waiting waves and no sharing instantiation
+      if (is_big && li.shared_sweep) li.shared_sweep = 0;
       RPL_LAUNCH(c.rpl, st, k_iterate, Real, c.cnt, Bt, n);
     }
     if (forked && st != h->stream) {
@@ -801,6 +828,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   if (h->nbuf == kMaxBuf) A(&h->help, B * sizeof(HelpSlot));
   if (h->rpl <= 4 && h->bshare_mode != 0 && (h->nbuf == kMaxBuf || h->bshare_mode == 2)) {
     A(&h->bshare, B * sizeof(BwdShare)); A(&h->bflag, B * nm * sizeof(int)); A(&h->brec, B * nm * (size_t)kRecDoubles * 8);
+    A(&h->batch_dev, 16 * 1024);
   }
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
   A(&h->st, B * sizeof(TrajState));
@@ -811,7 +839,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
   A(&h->best_idx, 16); A(&h->best_cost, 16);
   A(&h->sched, (B + 2) * sizeof(int));
-  A(&h->visits, 4 * sizeof(unsigned long long));  // [0] backward knots, [1] forward trial-knots, [2] knots whose front half a helper computed
+  A(&h->visits, 4 * sizeof(unsigned long long));  // [0] backward knots, [1] forward trial-knots, [2] knots whose front half a helper computed, [3] accepted line searches
   A(&h->live, 16 * sizeof(int));
   A(&h->tickets, 16 * sizeof(int));
   A(&h->order, B * sizeof(int32_t)); A(&h->cls_dev, B * sizeof(int32_t));
@@ -1207,14 +1235,14 @@ direct_status_t direct_ddp_debug_timeline(direct_ddp_handle_t h, void* dst) {
 }
 #endif
 
-direct_status_t direct_ddp_last_helper_knots(direct_ddp_handle_t h, uint64_t* knots) {
-  if (!h || !knots) return fail(DIRECT_ERR_INVALID, "null argument");
+direct_status_t direct_ddp_last_counters(direct_ddp_handle_t h, uint64_t* out4) {
+  if (!h || !out4) return fail(DIRECT_ERR_INVALID, "null argument");
   if (!h->timed) return fail(DIRECT_ERR_INVALID, "no hot-kernel launch yet");
   HIP_TRY(hipSetDevice(h->device));
-  unsigned long long v = 0;
-  HIP_TRY(hipMemcpyAsync(&v, h->visits + 2, sizeof v, hipMemcpyDeviceToHost, h->stream));
+  unsigned long long v[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(v, h->visits, sizeof v, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  *knots = v;
+  for (int i = 0; i < 4; i++) out4[i] = v[i];
   return DIRECT_OK;
 }
 

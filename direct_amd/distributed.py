@@ -32,16 +32,18 @@ def local_best(cost, rtn):
     return i, float(c[i])
 
 
-def gather_best(best_cost, best_global_index, block, device=None):
+def gather_best(best_cost, best_global_index, block, device=None, force_collective=False):
     """All ranks learn the winner: returns (cost, global index, owner rank, block tensor).
 
     best_cost / best_global_index: this rank's local best; block: 1-D tensor with its trajectory
     (Bezier coefficients + durations).  One all_gather of 2 doubles and one of the block per rank.
+    force_collective: run the two all_gathers at world size 1 as well (an initialised process group is needed): the
+    N > 1 code path executed on a single GPU (bench.py, DIRECT_BENCH_FORCE_DIST=1).
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
     device = block.device if device is None else device
     mine = torch.tensor([best_cost, float(best_global_index)], dtype=torch.float64, device=device)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return best_cost, best_global_index, 0, block
     allv = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine)

@@ -26,7 +26,7 @@ EXPORTS = (
     "direct_ddp_best_cost", "direct_ddp_sched_error", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
     "direct_rccl_unique_id", "direct_rccl_comm_create", "direct_rccl_comm_destroy", "direct_ddp_gather_best",
     "direct_corridor_wire_size", "direct_corridor_pack", "direct_corridor_unpack", "direct_corridor_replay_batch",
-    "direct_ddp_last_launch_info", "direct_ddp_last_helper_knots",
+    "direct_ddp_last_launch_info", "direct_ddp_last_counters",
 )
 
 
@@ -65,8 +65,8 @@ def lib():
         L.direct_ddp_sched_error.argtypes = [C.c_void_p, C.c_void_p]
         if hasattr(L, "direct_ddp_last_launch_info"):  # absent from libraries of earlier rounds (tools/ab_libs.sh A/B runs)
             L.direct_ddp_last_launch_info.argtypes = [C.c_void_p, C.c_void_p]
-        if hasattr(L, "direct_ddp_last_helper_knots"):
-            L.direct_ddp_last_helper_knots.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "direct_ddp_last_counters"):
+            L.direct_ddp_last_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.direct_rccl_unique_id.argtypes = [C.c_void_p]
         L.direct_rccl_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.direct_rccl_comm_destroy.argtypes = [C.c_void_p]
@@ -289,10 +289,11 @@ class DdpSolver:
         li = abi.LaunchInfo()
         _check(lib().direct_ddp_last_launch_info(self.h, C.addressof(li)))
         out = {n: int(getattr(li, n)) for n, _ in abi.LaunchInfo._fields_ if n != "reserved"}
-        if hasattr(lib(), "direct_ddp_last_helper_knots"):
-            v = C.c_uint64()
-            _check(lib().direct_ddp_last_helper_knots(self.h, C.addressof(v)))
-            out["helper_front_knots"] = int(v.value)
+        if hasattr(lib(), "direct_ddp_last_counters"):
+            v = (C.c_uint64 * 4)()
+            _check(lib().direct_ddp_last_counters(self.h, C.addressof(v)))
+            out["helper_front_knots"] = int(v[2])
+            out["accepted_line_searches"] = int(v[3])
         return out
 
     def sched_error(self):

@@ -320,9 +320,11 @@ typedef struct {
                                a trial cut short by the fraction-to-boundary rule counts the knots it reached) */
 } direct_ddp_launch_info_t;
 direct_status_t direct_ddp_last_launch_info(direct_ddp_handle_t h, direct_ddp_launch_info_t* info);
-/* Backward knots of the last hot-kernel launch whose value-independent half was computed by a helper wave (or by the
- * forced split) and handed over through HBM; 0 when the launch did not share its sweeps.  Observability only. */
-direct_status_t direct_ddp_last_helper_knots(direct_ddp_handle_t h, uint64_t* knots);
+/* Work counters of the last hot-kernel launch (observability only): out4[0] backward-sweep knots, out4[1] forward
+ * trial-knots (as in direct_ddp_launch_info_t), out4[2] backward knots whose value-independent half a helper wave (or the
+ * forced split) computed and handed over through HBM, out4[3] line searches that accepted a step (out of the forward
+ * passes the launch ran: the rest ended with fp_failed, ddp_optimizer.cpp:760-762). */
+direct_status_t direct_ddp_last_counters(direct_ddp_handle_t h, uint64_t* out4);
 
 /* Config-5 reduction: index and value of the smallest cost among problems with rtn >= 0.
  * cost/rtn are device or host arrays per `mem`; the result is written to host. */

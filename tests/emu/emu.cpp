@@ -39,7 +39,7 @@ static void for_each_wave(Emu<Real>& E, F f) {
   ddp_emu_lds_range(&lds, sizeof lds);
 #endif
   for (int b = 0; b < E.B.B; b++) {
-    Wave<Cmp, Real, RPL> W(E.B, lds, b);
+    Wave<Cmp, Real, RPL, true> W(E.B, lds, b);  // the sharing instantiation: DIRECT_EMU_BSPLIT=1 forces its hand-over path
     f(W);
   }
 }
@@ -111,6 +111,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
     E->bflag.assign((size_t)B * nm, 0);
     E->brec.assign((size_t)B * nm * kRecDoubles, 0.0);
     Bt.bshare = E->bshare.data(); Bt.bflag = E->bflag.data(); Bt.brec = E->brec.data(); Bt.bforce = 1;
+    Bt.self = &E->B;
   }
   SolveConst& k = Bt.k;
   k.max_vel = p->max_vel; k.max_acc = p->max_acc; k.w_snap = p->w_snap; k.w_term = p->w_terminal;

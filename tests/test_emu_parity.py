@@ -224,6 +224,6 @@ def test_emulated_split_backward_sweep_is_bitwise_the_fused_one(kind, N, B, seed
                 knots.append(s.split_knots())
                 res.append(s.finish())
                 s.close()
-            assert knots[0] == 0 and knots[1] == B * max(N - 4, 0), knots
+            assert knots[0] == 0 and knots[1] == B * max(N - 2, 0), knots
             for f in ("rtn", "iter_used", "fwd_passes", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
                 assert np.array_equal(getattr(res[0], f), getattr(res[1], f)), (f, dtype, params.zero_init)
