@@ -146,6 +146,14 @@ class HostBatch:
         self.init_bez = None if init_bez is None else np.ascontiguousarray(init_bez, dtype=self.dtype)
         self.infeas_in = None if infeas_in is None else np.ascontiguousarray(infeas_in, dtype=np.uint8)
         self.init_poly = None if init_poly is None else np.ascontiguousarray(init_poly, dtype=self.dtype)
+        self.omit_T0 = False   # True: the C struct carries T0 = NULL and the library runs initTimeAllocation on the device
+
+    def without_T0(self):
+        """the same corridors with the durations left to the library (T0 = NULL: device-side initTimeAllocation from x0 / xd / seeds)"""
+        b = HostBatch(self.n_seg, self.x0, self.xd, self.T0, self.n_planes, self.planes, self.seeds, self.init_bez,
+                      self.infeas_in, dtype=self.dtype, init_poly=self.init_poly)
+        b.omit_T0 = True
+        return b
 
     @property
     def nc_max(self):
@@ -170,7 +178,7 @@ class HostBatch:
         s = BatchIn()
         s.batch, s.n_seg_max, s.p_max, s.mem = self.batch, self.n_seg_max, self.p_max, MEM_HOST
         s.n_seg = _ptr(self.n_seg)
-        s.x0, s.xd, s.T0 = _ptr(self.x0), _ptr(self.xd), _ptr(self.T0)
+        s.x0, s.xd, s.T0 = _ptr(self.x0), _ptr(self.xd), (None if self.omit_T0 else _ptr(self.T0))
         s.n_planes, s.planes = _ptr(self.n_planes), _ptr(self.planes)
         s.seeds, s.init_bez, s.infeas_in = _ptr(self.seeds), _ptr(self.init_bez), _ptr(self.infeas_in)
         s.init_poly = _ptr(self.init_poly)

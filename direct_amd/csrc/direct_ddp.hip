@@ -262,6 +262,33 @@ __global__ void k_chain(int B, int nmax, const int32_t* rtn0, const Real* T_phas
   if (i % nmax == 0) infeas_next[b] = infeas0[b];
 }
 
+// initTimeAllocation (teach_repeat_planner.cpp:583-639, v0 = 0) on the device: one thread per (corridor, segment), double
+// arithmetic whatever the storage type - the same expressions as direct_time_allocation() below.  Launched in front of
+// k_begin when the caller passes T0 == NULL: the generation -> plan chain then never leaves the device.
+template <typename Real>
+__global__ void k_time_alloc(int B, int nmax, const int32_t* n_seg, const Real* x0, const Real* xd, const Real* seeds,
+                             double max_vel, double max_acc, Real* T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nmax) return;
+  const int b = i / nmax, k = i - b * nmax, N = n_seg[b];
+  const double acct = max_vel / max_acc, accd = max_acc * acct * acct / 2.0;
+  const double dcct = max_vel / max_acc, dccd = max_acc * dcct * dcct / 2.0;
+  double t = 0.0;
+  if (k < N && N <= nmax) {
+    double dd[3];
+    for (int d = 0; d < 3; d++) {
+      const double p0 = (k == 0) ? (double)x0[(size_t)b * 9 + d] : (double)seeds[((size_t)b * nmax + k) * 3 + d];
+      const double p1 = (k == N - 1) ? (double)xd[(size_t)b * 9 + d] : (double)seeds[((size_t)b * nmax + k + 1) * 3 + d];
+      dd[d] = p1 - p0;
+    }
+    // products and sums rounded one by one, as the host twin's are (no contraction into fused multiply-adds)
+    const double D = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dd[0], dd[0]), __dmul_rn(dd[1], dd[1])), __dmul_rn(dd[2], dd[2])));
+    if (D < accd + dccd) t = 2.0 * sqrt(max_acc * D) / max_acc;  // triangle profile
+    else t = acct + (D - accd - dccd) / max_vel + dcct;          // trapezoid profile
+  }
+  T[i] = (Real)t;
+}
+
 // argmin of cost over problems with rtn >= 0 (config 5); one block
 template <typename Real>
 __global__ void k_best(const Real* cost, const int32_t* rtn, int n, int* best_idx, double* best_cost) {
@@ -691,7 +718,7 @@ static direct_status_t sample_t(direct_ddp_handle_t h, const direct_sample_in_t*
   const size_t B = in->batch, nm = in->n_seg_max, cap = in->capacity, r = sizeof(Real);
   const bool host = in->mem == DIRECT_MEM_HOST;
   SampleArgs<Real> A;
-  A.batch = in->batch; A.nmax = in->n_seg_max; A.capacity = in->capacity; A.derivs = in->derivs; A.dt = in->dt;
+  A.batch = in->batch; A.nmax = in->n_seg_max; A.capacity = in->capacity; A.derivs = in->derivs; A.dt = in->dt; A.inv_dt = 1.0 / in->dt;
   std::vector<void*> tmp;
   auto dev = [&](size_t bytes) -> void* {
     void* q = nullptr;
@@ -972,8 +999,10 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
   if (in->batch <= 0 || in->batch > h->max_batch) return fail(DIRECT_ERR_INVALID, "batch exceeds the handle's max_batch");
   if (in->n_seg_max != h->nmax || in->p_max != h->pmax)
     return fail(DIRECT_ERR_INVALID, "n_seg_max / p_max differ from the handle's configuration");
-  if (!in->n_seg || !in->x0 || !in->xd || !in->T0 || !in->n_planes || !in->planes)
+  if (!in->n_seg || !in->x0 || !in->xd || !in->n_planes || !in->planes)
     return fail(DIRECT_ERR_INVALID, "null input array");
+  if (!in->T0 && !in->seeds)
+    return fail(DIRECT_ERR_INVALID, "T0 == NULL asks for initTimeAllocation on the device: that needs the polytope seeds");
   if (p->line_init && !p->zero_init && !in->seeds)
     return fail(DIRECT_ERR_INVALID, "line_init needs the polytope seeds (direct_ddp_batch_in_t.seeds)");
   if (!p->zero_init && !p->line_init && !in->init_bez && !in->init_poly)
@@ -994,7 +1023,7 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
     HIP_TRY(up(h->n_seg, in->n_seg, B * 4)); d.n_seg = h->n_seg;
     HIP_TRY(up(h->x0, in->x0, B * 9 * r)); d.x0 = h->x0;
     HIP_TRY(up(h->xd, in->xd, B * 9 * r)); d.xd = h->xd;
-    HIP_TRY(up(h->T0, in->T0, B * nm * r)); d.T0 = h->T0;
+    if (in->T0) { HIP_TRY(up(h->T0, in->T0, B * nm * r)); d.T0 = h->T0; }
     HIP_TRY(up(h->n_planes, in->n_planes, B * nm * 4)); d.n_planes = h->n_planes;
     HIP_TRY(up(h->planes, in->planes, B * nm * h->pmax * 4 * r)); d.planes = h->planes;
     if (in->init_bez) { HIP_TRY(up(h->init_bez, in->init_bez, B * nm * 18 * r)); d.init_bez = h->init_bez; }
@@ -1005,6 +1034,17 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
   if (!in->infeas_in) {
     HIP_TRY(hipMemsetAsync(h->infeas_in, p->infeas ? 1 : 0, B, h->stream));
     d.infeas_in = h->infeas_in;
+  }
+  if (!in->T0) {  // initTimeAllocation on the device, from the (device-resident) start / goal positions and seeds
+    const int n = (int)(B * nm);
+    if (h->dtype == DIRECT_F64)
+      hipLaunchKernelGGL(k_time_alloc<double>, dim3((n + 255) / 256), dim3(256), 0, h->stream, (int)B, (int)nm, d.n_seg, (const double*)d.x0,
+                         (const double*)d.xd, (const double*)d.seeds, p->max_vel, p->max_acc, (double*)h->T0);
+    else
+      hipLaunchKernelGGL(k_time_alloc<float>, dim3((n + 255) / 256), dim3(256), 0, h->stream, (int)B, (int)nm, d.n_seg, (const float*)d.x0,
+                         (const float*)d.xd, (const float*)d.seeds, p->max_vel, p->max_acc, (float*)h->T0);
+    HIP_TRY(hipGetLastError());
+    d.T0 = h->T0;
   }
   if (fresh) {  // (phase 1 of a plan keeps phase 0's classes: the same polytopes)
     h->B = in->batch;

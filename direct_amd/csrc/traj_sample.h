@@ -27,7 +27,7 @@ struct SampleArgs {
   const int32_t* n_seg;
   const St* bez;
   const St* T;
-  double dt;
+  double dt, inv_dt;  // inv_dt = 1 / dt (host): the sample-count estimate T / dt then needs no division per segment
   int32_t* count;
   int32_t* seg_first;
   St* pos;
@@ -54,6 +54,13 @@ __device__ __forceinline__ void store3(St* dst, double x, double y, double z) {
   *reinterpret_cast<typename Vec3<St>::type*>(dst) = v;
 }
 
+// lane l receives lane l - 1's value, lane 0 receives `first`: a whole-wave shift on the VALU's DPP path (two moves per
+// double) instead of __shfl_up's two ds_bpermute round trips through the LDS pipe
+__device__ __forceinline__ double sample_shift_up(double v, double first) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double sample_readlane(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -65,7 +72,13 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
   const int b = blockIdx.x, lane = threadIdx.x;
   // n_seg is clamped to the array extent: with device-resident inputs nothing has validated it on the host
   const int N = min(max(A.n_seg[b], 0), A.nmax);
-  const St* Tb = A.T + (size_t)b * A.nmax;
+  // Everything a segment reads is the same for the 64 lanes (its duration, its 18 control points): read through the
+  // CONSTANT address space, i.e. by scalar loads.  Vector loads would share the in-order vmcnt counter with the sample
+  // stores: the wait for a segment's coefficients then also waits until every store of the previous segment has drained
+  // to HBM - the kernel ran at 58 % of its own instruction count's time and 64 % of the pure-write rate of its store pattern
+  // (tools/hbm_calib: 5.6 TB/s).  (The arrays are written by earlier kernels only.)
+  typedef __attribute__((address_space(4))) const St CSt;
+  CSt* Tb = (CSt*)(A.T + (size_t)b * A.nmax);
   // a negative duration aborts the reference's loop before anything is published (TRP:1552-1555)
   int neg = 0;
   for (int i = lane; i < N; i += 64) neg |= (Tb[i] < (St)0) ? 1 : 0;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
     const double Ti = (double)Tb[i];
     double step = A.dt / Ti;
     if (!(step > 0.0)) step = 2.0;  // the reference would never leave its loop (step 0 / NaN): one sample instead
-    const St* c = A.bez + ((size_t)b * A.nmax + i) * 18;
+    CSt* c = (CSt*)(A.bez + ((size_t)b * A.nmax + i) * 18);
     double cf[18];
 #pragma unroll
     for (int q = 0; q < 18; q++) cf[q] = (double)c[q];
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
     // fast path: count = the smallest k with k * step >= 1, provided no candidate is within k ulp of 1.0
     int nfast = -1;
     if (step < 1.0 && step > 1.0e-7) {
-      const double kf = floor(1.0 / step);
+      const double kf = floor(Ti * A.inv_dt);  // ~ 1 / step: the candidates around it are examined below
       int cnt = -1, ambiguous = 0;
       for (int c = -1; c <= 2; c++) {
         const double k = kf + (double)c;
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
     } else if (step >= 1.0) {
       nfast = 1;
     }
-    const double invT = 1.0 / Ti;
+    const double invT = frcp(Ti);  // (1-2 ulp: scales the acceleration samples only)
     // The segment's three Bernstein polynomials in the monomial basis, once per segment: with D_i the i-th forward
     // difference of the control points at 0, the degree-5 position polynomial is sum_i C(5,i) D_i t^i, the reference's
     // velocity polynomial (control points 5 (c_j+1 - c_j), degree 4) is sum_i 5 C(4,i) D_i+1 t^i and its acceleration
@@ -175,12 +188,12 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
         }
       }
       // distance to the previous sample (lane - 1, or the carried point for lane 0)
-      double qx = __shfl_up(p[0], 1, 64), qy = __shfl_up(p[1], 1, 64), qz = __shfl_up(p[2], 1, 64);
-      if (lane == 0) { qx = px; qy = py; qz = pz; }
+      const double qx = sample_shift_up(p[0], px), qy = sample_shift_up(p[1], py), qz = sample_shift_up(p[2], pz);
       const double dx = qx - p[0], dy = qy - p[1], dz = qz - p[2];
-      double dist = sqrt(dx * dx + dy * dy + dz * dz);
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      double dist = d2 > 0.0 ? d2 * frsq(d2) : 0.0;  // sqrt by the hardware seed + two Newton steps (1-2 ulp)
       if (!valid || (base == 0 && lane == 0)) dist = 0.0;  // the first point of the trajectory has no predecessor
-      len += wave_sum_d(dist);  // DPP reduction on the VALU (ddp_wave.h): six shuffles through the LDS pipe otherwise
+      len += dist;  // per lane; ONE wave sum per trajectory at the end (a sum per chunk was 15 % of the chunk's instructions)
       const int idx = base + lane;
       if (audit && valid) {  // the planes of a segment are the same for every lane: broadcast loads
         const int np = min(max(A.n_planes[(size_t)b * A.nmax + i], 0), A.pmax);
@@ -206,6 +219,7 @@ __global__ __launch_bounds__(64) void k_sample(SampleArgs<St> A) {
       t_carry = sample_readlane(t, 63) + step;
     }
   }
+  len = wave_sum_d(len);  // DPP reduction on the VALU (ddp_wave.h)
   for (int o = 32; o > 0; o >>= 1) {
     vm = fmax(vm, __shfl_xor(vm, o, 64));
     am = fmax(am, __shfl_xor(am, o, 64));

@@ -18,6 +18,8 @@ class DeviceBatch:
         self.tens = {}
         for k in IN_FIELDS:
             a = getattr(host_batch, k, None)
+            if k == "T0" and getattr(host_batch, "omit_T0", False):
+                a = None   # T0 = NULL: the library allocates the durations on the device
             if a is not None:
                 self.tens[k] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
         c = abi.BatchIn()

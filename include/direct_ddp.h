@@ -94,7 +94,10 @@ typedef struct {
   const int32_t* n_seg;      /* [batch] */
   const void* x0;            /* [batch][9] Real */
   const void* xd;            /* [batch][9] Real */
-  const void* T0;            /* [batch][n_seg_max] Real */
+  const void* T0;            /* [batch][n_seg_max] Real; NULL: initTimeAllocation (teach_repeat_planner.cpp:583-639) runs on the
+                                device, from x0 / xd positions and `seeds` (required then) with params->max_vel / max_acc -
+                                direct_time_allocation()'s expressions in double (within 1e-14 of it); for DIRECT_MEM_DEVICE inputs the
+                                seeds -> durations -> plan chain then never visits the host */
   const int32_t* n_planes;   /* [batch][n_seg_max] */
   const void* planes;        /* [batch][n_seg_max][p_max][4] Real */
   const void* seeds;         /* [batch][n_seg_max][3] Real or NULL */
@@ -187,7 +190,8 @@ direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_pa
                                       direct_ddp_batch_out_t* out1);
 
 /* initTimeAllocation (teach_repeat_planner.cpp:583-639): trapezoid-profile duration per
- * segment from start, seeds[1..n-1] and goal.  Host pointers, double precision. */
+ * segment from start, seeds[1..n-1] and goal.  Host pointers, double precision.  (The device-side twin runs inside
+ * solve / plan / begin when direct_ddp_batch_in_t.T0 is NULL.) */
 direct_status_t direct_time_allocation(int32_t batch, int32_t n_seg_max, const int32_t* n_seg,
                                        const double* start, const double* goal,
                                        const double* seeds, double max_vel, double max_acc,

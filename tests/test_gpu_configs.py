@@ -129,6 +129,59 @@ def test_config4_shape_in_feasible_mode_runs_full_length_rollouts(built, monkeyp
     assert np.array_equal(res["dynamic"].bez, big.bez[:4096]) and np.array_equal(res["dynamic"].iter_used, big.iter_used[:4096])
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_device_side_time_allocation(built, dt):
+    """T0 == NULL: initTimeAllocation (teach_repeat_planner.cpp:583-639) runs on the device in front of the setup kernel,
+    from the start / goal positions and the polytope seeds - for host arrays and for device-resident ones (where the
+    seeds -> durations -> plan chain then never visits the host).  The durations it produces are those of the host twin
+    direct_time_allocation (double arithmetic, 1e-14; rounded once more for float storage), and a plan from them is
+    bit-identical to the plan from the same durations provided by the caller."""
+    torch = _torch()
+    import ctypes as C
+    B, N = 300, 24
+    batch = problems.make_batch("corridor", B, N, seed=31).astype(dt)
+    p0, p1 = abi.phase0_params(), abi.phase1_params(iter_max=25)
+    # the generator's durations ARE a time allocation of its seeds: recompute them with the C twin on what the device sees
+    lib = solver.lib()
+    lib.direct_time_allocation.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_void_p]
+    T_host = np.zeros((B, N))
+    st, gl, sd = (np.ascontiguousarray(a, np.float64) for a in (batch.x0[:, :3], batch.xd[:, :3], batch.seeds))
+    assert lib.direct_time_allocation(B, N, batch.n_seg.ctypes.data, st.ctypes.data, gl.ctypes.data, sd.ctypes.data,
+                                      p0.max_vel, p0.max_acc, T_host.ctypes.data) == 0
+    ref = abi.HostBatch(batch.n_seg, batch.x0, batch.xd, T_host, batch.n_planes, batch.planes, seeds=batch.seeds, dtype=dt)
+    s = solver.DdpSolver(B, N, batch.p_max, dt)
+    # (a) host arrays without durations: what the device allocated (the setup kernel stores it as u[9] of every knot)
+    s.begin(p0, ref.without_T0())
+    T_dev = s.get(abi.FIELD_U)[:, :, 9].astype(np.float64)
+    live = np.arange(N)[None, :] < batch.n_seg[:, None]
+    assert (T_dev[~live] == 0).all() and (T_dev[live] > 0).all()
+    # the host twin's values: to 1e-14 in double (the device's square root is not always the correctly rounded one:
+    # 4 % of the entries differ by one ulp), to a float ulp with float storage
+    assert np.abs(T_dev / np.where(live, T_host, 1.0) - 1.0)[live].max() <= (1e-14 if dt == np.float64 else 1.2e-7)
+    ref = abi.HostBatch(batch.n_seg, batch.x0, batch.xd, T_dev, batch.n_planes, batch.planes, seeds=batch.seeds, dtype=dt)
+    want = s.plan(p0, p1, ref)
+    got = s.plan(p0, p1, ref.without_T0())
+    for a, b in zip(want, got):
+        for f in ("rtn", "iter_used", "cost", "T", "bez", "poly"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    # (b) device-resident arrays without durations
+    dev = torch.device("cuda:0")
+    s.set_stream(torch.cuda.current_stream().cuda_stream)
+    din = devmem.DeviceBatch(ref.without_T0(), dev)
+    assert "T0" not in din.tens
+    o0, o1 = devmem.DeviceResult(B, N, dt, dev), devmem.DeviceResult(B, N, dt, dev)
+    s.plan_device(p0, p1, din.cin, o0.cout, o1.cout)
+    torch.cuda.synchronize()
+    g1 = o1.to_host()
+    for f in ("rtn", "iter_used", "cost", "T", "bez", "poly"):
+        assert np.array_equal(getattr(want[1], f), getattr(g1, f)), f
+    # no durations AND no seeds: refused, nothing launched
+    noseed = abi.HostBatch(batch.n_seg, batch.x0, batch.xd, T_host, batch.n_planes, batch.planes, dtype=dt).without_T0()
+    with pytest.raises(solver.DirectError):
+        s.solve(p0, noseed)
+    s.close()
+
+
 def test_bench_distributed_branches_run_at_world_size_one(built):
     """DIRECT_BENCH_FORCE_DIST=1: bench.py's N > 1 path - the RCCL process group, the barrier and the all-reduces around the
     timed region, the all-gather of the config-5 reduction, the object broadcast of the unique id and the library's own

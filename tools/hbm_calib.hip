@@ -40,6 +40,34 @@ __global__ void calib_write_dwordx4(float4* __restrict__ dst, size_t n4) {
     dst[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
+// The output-sampling kernel's store pattern (direct_amd/csrc/traj_sample.h, float storage): one wavefront per trajectory
+// walks chunks of 64 samples and writes, per chunk, 64 x 12 bytes to each of THREE arrays (positions, velocities,
+// accelerations: one global_store_dwordx3 per lane and array).  Pure writes, no evaluation: the ceiling of that pattern.
+// `mode` 0: dwordx3 per lane as the kernel does; 1: the same bytes as three dword stores per lane and array, lane-contiguous
+// (what a transpose through LDS would issue); 2: as four-dword stores (48 lanes x 16 bytes per 768-byte chunk).
+__global__ __launch_bounds__(64) void calib_write_sampler(float* __restrict__ p0, float* __restrict__ p1, float* __restrict__ p2,
+                                                           size_t floats_per_traj, int mode) {
+  const size_t base = (size_t)blockIdx.x * floats_per_traj;
+  const int lane = threadIdx.x;
+  float* arr[3] = {p0 + base, p1 + base, p2 + base};
+  for (size_t off = 0; off + 192 <= floats_per_traj; off += 192) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      float* d = arr[a] + off;
+      if (mode == 0) {
+        float3 v = make_float3(1.f + a, 2.f, 3.f);
+        *reinterpret_cast<float3*>(d + 3 * lane) = v;
+      } else if (mode == 1) {
+        d[lane] = 1.f + a;
+        d[64 + lane] = 2.f;
+        d[128 + lane] = 3.f;
+      } else {
+        if (lane < 48) *reinterpret_cast<float4*>(d + 4 * lane) = make_float4(1.f + a, 2.f, 3.f, 4.f);
+      }
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : 2048) << 20;  // MiB, default 2 GiB
   const size_t n = bytes / 4;
@@ -70,5 +98,17 @@ int main(int argc, char** argv) {
   time("calib_read_dwordx4", [&] { hipLaunchKernelGGL(calib_read_dwordx4, dim3(grid), dim3(block), 0, 0, (const float4*)a, n / 4, sink); }, (double)bytes);
   time("calib_write_dwordx4", [&] { hipLaunchKernelGGL(calib_write_dwordx4, dim3(grid), dim3(block), 0, 0, (float4*)b, n / 4); }, (double)bytes);
   time("hipMemcpy_d2d(read+write)", [&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); }, 2.0 * bytes);
+  {  // the sampler's pattern: 32768 trajectories x 20544 samples (tools/sample_bench.py: B = 32768, N = 100, dt = 0.02: 673 M points)
+    const int traj = 32768;
+    const size_t fpt = 20544 * 3;  // floats per trajectory and array
+    float *q0, *q1, *q2;
+    const size_t ab = (size_t)traj * fpt * 4;
+    CK(hipMalloc(&q0, ab)); CK(hipMalloc(&q1, ab)); CK(hipMalloc(&q2, ab));
+    const char* names[3] = {"sampler_pattern_dwordx3_x3arrays", "sampler_pattern_dword_lane_contiguous_x3arrays", "sampler_pattern_dwordx4_x3arrays"};
+    for (int mode = 0; mode < 3; mode++)
+      time(names[mode], [&] { hipLaunchKernelGGL(calib_write_sampler, dim3(traj), dim3(64), 0, 0, q0, q1, q2, fpt, mode); },
+           3.0 * (double)traj * (double)(fpt / 192 * 192) * 4.0);
+    CK(hipFree(q0)); CK(hipFree(q1)); CK(hipFree(q2));
+  }
   return 0;
 }
