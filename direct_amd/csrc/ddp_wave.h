@@ -863,6 +863,7 @@ struct Wave {
   };
   DDP_DEV void prefetch(Pre& p, int* pkv, int pk_valid, int lane, int buf, int k, int P, bool fwd, int infeas) const {
     (void)buf;
+
     GCSt* rec = XpU(0, k);
     p.zh = rec[lane < 19 ? lane : 18];
     p.zl = (sizeof(St) < sizeof(double)) ? rec[19 + (lane < 19 ? lane : 18)] : (St)0;  // see ldx()
@@ -897,6 +898,30 @@ struct Wave {
       L.KUr[lane] = (Real)p.ku[0];
       if (lane + 64 < 100) L.KUr[lane + 64] = (Real)p.ku[1];
     }
+  }
+
+  // The prefetched words are waited for HERE (the compiler places the s_waitcnt vmcnt where a loaded register is first
+  // read, and the empty asm is such a read): called BEFORE a knot's global stores are issued.  Loads and stores retire
+  // through one in-order counter: a wait for the prefetch that comes after the stores - at the top of the next knot, where
+  // the registers are consumed - is a wait for the stores' acknowledgements as well, every knot (DDP_PREFETCH_PIN=0: off).
+  DDP_DEV void pin_prefetch(Pre& p, bool fwd, int infeas) const {
+#if !defined(DIRECT_EMULATE) && !defined(DDP_NO_PREFETCH_PIN)
+    DDP_PIN(p.zh);
+    if (sizeof(St) < sizeof(double)) DDP_PIN(p.zl);
+#pragma unroll
+    for (int i = 0; i < kNPL; i++) DDP_PIN(p.pl[i]);
+#pragma unroll
+    for (int i = 0; i < RPL; i++) DDP_PIN(p.s[i]);
+    // (the dual rows of infeasible mode are not pinned: a conditional pin makes the compiler wait right behind the load,
+    // an unconditional one pushes spills into the forward rounds - infeasible sweeps keep their wait at the top of the knot)
+    (void)infeas;
+    if (fwd) {
+      DDP_PIN(p.ku[0]);
+      DDP_PIN(p.ku[1]);
+    }
+#else
+    (void)p; (void)fwd; (void)infeas;
+#endif
   }
 
   DDP_DEV void load_state() {
@@ -2323,6 +2348,10 @@ struct Wave {
             }
           }
         }
+        if constexpr (MODE == 0) {
+          pin_prefetch(LV(C.pre), false, infeas);
+          DDP_PIN(C.Pnn);
+        }
         KUpU(k)[lane] = (St)L.KU[lane];
         {
           const int e2 = lane + 64 < 100 ? lane + 64 : 99;
@@ -2552,7 +2581,11 @@ struct Wave {
     // addresses: loading it on the spot would expose one HBM round trip per knot)
     C.Pn = DDP_UNIFORM_I(npU(N - 1));
     C.Pnn = npU(N > 1 ? N - 2 : 0);
-    LANES { prefetch(LV(C.pre), LV(C.pkn), 0, lane, buf, N - 1, C.Pn, false, infeas); }
+    LANES {
+      prefetch(LV(C.pre), LV(C.pkn), 0, lane, buf, N - 1, C.Pn, false, infeas);
+      pin_prefetch(LV(C.pre), false, infeas);  // (on every path into the loop, or the wait comes back at its top)
+      DDP_PIN(C.Pnn);
+    }
     // We = WbE o T-powers (rows 0..14: control points, rows 15..17: Z = [F | G]; read by phases R1, H, G) is a by-product
     // of phase T2, which forms exactly these products on its way to the control values; the entries with a zero weight
     // (coefficient index below the row's exponent offset) never change: cleared once per sweep (the forward pass uses
@@ -2848,7 +2881,11 @@ struct Wave {
     PLV(Pre, pre);
     PLA(int, pkn, RPL);
     PLA(int, pkc, RPL);
-    LANES { prefetch(LV(pre), LV(pkn), 0, lane, cur, 0, Pn, true, infeas); }
+    LANES {
+      prefetch(LV(pre), LV(pkn), 0, lane, cur, 0, Pn, true, infeas);
+      pin_prefetch(LV(pre), true, infeas);  // (on every path into the loop, or the wait comes back at its top)
+      DDP_PIN(Pnn);
+    }
 #pragma unroll 1
     for (int k_ = 0; k_ < N; k_++) {
       int k = DDP_UNIFORM_I(k_);  // see bwd_sweep(); the loop has several exits and the counter may not be provably uniform
@@ -3041,6 +3078,11 @@ struct Wave {
       // product - no per-row gain ever crosses HBM, and the backward sweep has no row work after its phase R1.
       PLA(int, bad, NT);
       LANES {
+        pin_prefetch(LV(pre), true, infeas);  // before this phase's stores of the trial iterate
+        DDP_PIN(Pnn);
+#if !defined(DIRECT_EMULATE)
+        DDP_PIN(cancel_v);  // (a helper's poll of the cancel flag: loaded a knot ahead like the prefetch)
+#endif
 #pragma unroll
         for (int t = 0; t < NT; t++) LV(bad)[t] = 0;
         if (kWide) {

@@ -97,3 +97,4 @@ for K in (1, 2, 4, 20):
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
+    np.savez_compressed(sys.argv[2].replace(".json", "_raw.npz"), st=st.astype(np.float32), mid=mid.astype(np.float32), en=en.astype(np.float32), sp=sp)
