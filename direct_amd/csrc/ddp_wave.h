@@ -1702,7 +1702,9 @@ struct Wave {
   DDP_DEV int bwd_sweep() { return bwd_sweep_t<false>(); }
 
   // ---- one knot of the backward sweep (see above for MODE) -----------------------------------------------------
-  template <int MODE, bool kGains>
+  // INF: the mode of the sweep as a compile-time constant (0 feasible, 1 infeasible; -1: read from the context).  The fused
+  // sweep is instantiated once per mode: the feasible one carries no dual rows (registers the kernel does not have).
+  template <int MODE, bool kGains, int INF = -1>
   DDP_DEV int bwd_knot(BwdCtx& C, int k_) {
     constexpr bool kF = MODE != 2, kB = MODE != 1;  // the knot's front / back half is part of this instantiation
     {
@@ -1711,8 +1713,8 @@ struct Wave {
       int k = k_;
       if constexpr (MODE == 2) k = DDP_UNIFORM_I(k_);  // a loop behind a loop with several exits: the counter may not be provably uniform
       DDP_LAUNDER_S(k);
-      const int regi = C.regi, infeas = C.infeas, buf = C.buf;
-      const Acc lam = C.lam, sig = C.sig;
+      const int regi = C.regi, infeas = INF < 0 ? C.infeas : INF, buf = C.buf;
+      const Acc lam = C.lam, sig = INF < 0 ? C.sig : (INF ? (Acc)1 : (Acc)-1);
       const Real mu = C.mu, wsn = C.wsn;
       const int P = C.Pn;
       const int nc = 6 * P + 55;
@@ -2530,6 +2532,28 @@ struct Wave {
     LANES { LV(io.e_qu) = LV(C.e_qu); }
   }
 
+  // the owner's fused knots, from N - 1 down to the knot where the helpers' claims begin (ks; -1: the whole sweep)
+  template <bool kGains, int INF>
+  DDP_DEV int bwd_fused_run(BwdCtx& C, BwdShare* bs, Pend& pend, int& kfloor, int& ks, int& kfail) {
+#pragma unroll 1
+    for (int k_ = N - 1; k_ >= 0; k_--) {
+      if (k_ < kfloor) {  // the owner's claim is used up: what did the next one get?
+        const int low = bs_claim_high_low(pend);
+        if (low >= kfloor) {  // the helpers have taken everything below
+          ks = k_;
+          break;
+        }
+        kfloor = kfloor - kOwnChunk > low ? kfloor - kOwnChunk : low;
+        if (kfloor > 0) bs_claim_high_issue(bs, pend);
+      }
+      if (!bwd_knot<0, kGains, INF>(C, k_)) {
+        kfail = k_;
+        return 0;
+      }
+    }
+    return 1;
+  }
+
   template <bool kGains>
   DDP_DEV_NOINLINE int bwd_sweep_t() {
     DDP_LAUNDER_S(b);
@@ -2598,23 +2622,9 @@ struct Wave {
     if (bs != nullptr && kfloor > 0) bs_claim_high_issue(bs, pend);
     int ok = 1, kfail = 0;
     int ks = -1;  // knots ks .. 0 are the helpers': through records
-#pragma unroll 1
-    for (int k_ = N - 1; k_ >= 0; k_--) {
-      if (k_ < kfloor) {  // the owner's claim is used up: what did the next one get?
-        const int low = bs_claim_high_low(pend);
-        if (low >= kfloor) {  // the helpers have taken everything below
-          ks = k_;
-          break;
-        }
-        kfloor = kfloor - kOwnChunk > low ? kfloor - kOwnChunk : low;
-        if (kfloor > 0) bs_claim_high_issue(bs, pend);
-      }
-      ok = bwd_knot<0, kGains>(C, k_);
-      if (!ok) {
-        kfail = k_;
-        break;
-      }
-    }
+    // (one instantiation for both modes: per-mode copies of the fused loop measured no faster, and the compiler contracts
+    // the infeasible rows' arithmetic differently in a copy of its own - the bits would depend on who ran the knot)
+    ok = bwd_fused_run<kGains, -1>(C, bs, pend, kfloor, ks, kfail);
 #if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
     tl_split_ += ks + 1;
 #endif
@@ -2837,7 +2847,11 @@ struct Wave {
   // Leaves res[t] (wave-uniform) and the trial iterates in buffers trial_buf(cur, step0 + t).  `poll` != 0 (helpers):
   // the round is abandoned when the owner cancels the search.
   template <int NT>
-  DDP_DEV void run_round(int step0, int cur, int infeas, Real omt, Real mu, TrialRes* res, int poll, HelpSlot* hs) {
+  DDP_DEV void run_round(int step0, int cur, int infeas_rt, Real omt, Real mu, TrialRes* res, int poll, HelpSlot* hs) {
+    // Trials are only ever paired in feasible mode (fwd_pass): the two-trial instantiation carries no dual rows at all -
+    // registers the kernel does not have (98 -> 81 spilled VGPRs, no scratch access left inside the rounds; config 2
+    // 34.4 -> 33.8 ms same-box).  (A feasible-only copy of the single-trial round as well measured no further gain.)
+    const int infeas = (NT == 2) ? 0 : infeas_rt;
     set_sweep_ptrs(cur, trial_buf(cur, step0), trial_buf(cur, step0 + NT - 1));
     Real alpha[NT], oma[NT], amu[NT];  // step size, 1 - alpha (exact: alpha = 2^-step), alpha * mu
     TrialRes* tr = res;
