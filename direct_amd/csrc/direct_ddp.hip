@@ -379,6 +379,14 @@ struct direct_ddp_handle_s {
   BwdShare* bshare = nullptr;  // [max_batch], allocated with `help` (narrow row-slot classes only)
   int* bflag = nullptr;        // [max_batch][nmax]
   double* brec = nullptr;      // [max_batch][nmax][kRecDoubles]
+  // Small handles (a single plan, a few corridors): every input array is a slice of ONE device allocation with a pinned
+  // host mirror, and so is every output array - host-memory calls then cost one H2D and one D2H copy instead of one per
+  // array (a two-phase plan of one 12-segment corridor: 37 small pageable copies, ~0.5 ms of its 3.2 ms).
+  char *in_blob = nullptr, *out_blob = nullptr;          // device
+  char *in_host = nullptr, *out_host = nullptr, *out0_host = nullptr;  // pinned mirrors (out0: phase-0 results of a plan)
+  size_t in_blob_bytes = 0, out_blob_bytes = 0;
+  hipEvent_t in_ev = nullptr;   // the last upload from in_host (the mirror is not rewritten before it has completed)
+  bool in_ev_pending = false;
   char* batch_dev = nullptr;   // [16][1024]: device copies of the class launches' Batch structs (Batch::self)
   std::vector<char> batch_host; // their staging copies (a copy must outlive the asynchronous upload)
   int bshare_mode = -1;        // -1 auto (wherever the line search is shared), DIRECT_DDP_BSHARE=0 off, 1 on, 2 forced split: every
@@ -608,7 +616,8 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     // protocol's fences (agent-scope release = L2 write-back).  Measured at N = 100: +5 .. +13 % for batches up to 4/3 of
     // the resident waves, -1.4 % at twice the resident waves, +15 .. +20 % below them; at N = 60: -1 .. -5 %; at
     // N = 30: up to -35 %.  Unless forced either way.
-    const bool help = h->help && (h->help_mode >= 0 ? h->help_mode != 0 : (2 * c.cnt <= 3 * slots && h->nmax >= 80));
+    // (short trajectories: only where most of the device is idle anyway - a lone 12-segment plan 3.6 -> 3.2 ms with helpers)
+    const bool help = h->help && (h->help_mode >= 0 ? h->help_mode != 0 : (2 * c.cnt <= 3 * slots && (h->nmax >= 80 || 8 * c.cnt <= slots)));
     const bool is_big = biggest < 0 || c.cnt > classes[biggest].cnt;
     if (is_big) {
       biggest = (int)ci;
@@ -823,10 +832,41 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   const size_t xs = cfg->dtype == DIRECT_F64 ? x_stride<double>() : x_stride<float>();  // knot record of the iterate
   direct_status_t st = DIRECT_OK;
   auto A = [&](auto pp, size_t bytes) { if (st == DIRECT_OK) st = dalloc(h, pp, bytes); };
-  A(&h->x0, B * 9 * r); A(&h->xd, B * 9 * r); A(&h->T0, B * nm * r); A(&h->T_next, B * nm * r);
-  A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r); A(&h->init_poly, B * nm * 18 * r);
-  A(&h->seeds, B * nm * 3 * r);
-  A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B); A(&h->infeas_next, B);
+  // slices of one allocation (small handles, see in_blob) or allocations of their own
+  struct Slice { void** pp; size_t off; };
+  auto carve = [&](std::vector<Slice>& v, size_t& total, auto pp, size_t bytes) {
+    v.push_back(Slice{(void**)pp, total});
+    total += (bytes + 255) & ~(size_t)255;
+  };
+  std::vector<Slice> in_sl, out_sl;
+  size_t in_total = 0, out_total = 0;
+  carve(in_sl, in_total, &h->x0, B * 9 * r); carve(in_sl, in_total, &h->xd, B * 9 * r); carve(in_sl, in_total, &h->T0, B * nm * r);
+  carve(in_sl, in_total, &h->planes, B * nm * cfg->p_max * 4 * r); carve(in_sl, in_total, &h->init_bez, B * nm * 18 * r);
+  carve(in_sl, in_total, &h->init_poly, B * nm * 18 * r); carve(in_sl, in_total, &h->seeds, B * nm * 3 * r);
+  carve(in_sl, in_total, &h->n_seg, B * 4); carve(in_sl, in_total, &h->n_planes, B * nm * 4); carve(in_sl, in_total, &h->infeas_in, B);
+  carve(out_sl, out_total, &h->o.rtn, B * 4); carve(out_sl, out_total, &h->o.iter_used, B * 4); carve(out_sl, out_total, &h->o.fwd_passes, B * 4);
+  carve(out_sl, out_total, &h->o.infeas_out, B); carve(out_sl, out_total, &h->o.line_failed_out, B);
+  carve(out_sl, out_total, &h->o.cost, B * r); carve(out_sl, out_total, &h->o.costq, B * r); carve(out_sl, out_total, &h->o.jerk_cost, B * r);
+  carve(out_sl, out_total, &h->o.terminal_norm2, B * r); carve(out_sl, out_total, &h->o.opterr, B * r); carve(out_sl, out_total, &h->o.mu, B * r);
+  carve(out_sl, out_total, &h->o.bez, B * nm * 18 * r); carve(out_sl, out_total, &h->o.poly, B * nm * 18 * r); carve(out_sl, out_total, &h->o.T, B * nm * r);
+  const bool packed = in_total + out_total <= (512u << 10) && !getenv("DIRECT_DDP_NO_PACK");
+  if (packed) {
+    A(&h->in_blob, in_total); A(&h->out_blob, out_total);
+    if (st == DIRECT_OK && (hipHostMalloc((void**)&h->in_host, in_total) != hipSuccess || hipHostMalloc((void**)&h->out_host, out_total) != hipSuccess ||
+                            hipHostMalloc((void**)&h->out0_host, out_total) != hipSuccess || hipEventCreateWithFlags(&h->in_ev, hipEventDisableTiming) != hipSuccess))
+      st = fail(DIRECT_ERR_DEVICE, "pinned staging buffers");
+    if (st == DIRECT_OK) {
+      for (const Slice& q : in_sl) *q.pp = h->in_blob + q.off;
+      for (const Slice& q : out_sl) *q.pp = h->out_blob + q.off;
+      h->in_blob_bytes = in_total; h->out_blob_bytes = out_total;
+    }
+  } else {
+    A(&h->x0, B * 9 * r); A(&h->xd, B * 9 * r); A(&h->T0, B * nm * r);
+    A(&h->planes, B * nm * cfg->p_max * 4 * r); A(&h->init_bez, B * nm * 18 * r); A(&h->init_poly, B * nm * 18 * r);
+    A(&h->seeds, B * nm * 3 * r);
+    A(&h->n_seg, B * 4); A(&h->n_planes, B * nm * 4); A(&h->infeas_in, B);
+  }
+  A(&h->T_next, B * nm * r); A(&h->infeas_next, B);
   h->dynamic = !(cfg->reserved & DIRECT_FLAG_STATIC_SCHEDULE);
   if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
   h->n_cu = prop.multiProcessorCount;
@@ -840,7 +880,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   // The shared line search needs a trial buffer per step.  It only ever runs where trials are paired, i.e. (unless
   // forced) for batches up to twice the resident waves: larger handles keep the three-buffer layout.
   const bool can_help = h->dynamic && h->sched_slots > 0 && h->help_mode != 0 &&
-                        (h->help_mode > 0 || (cfg->max_batch <= 2 * h->sched_slots && cfg->n_seg_max >= 80));
+                        (h->help_mode > 0 || (cfg->max_batch <= 2 * h->sched_slots && cfg->n_seg_max >= 80) || 8 * cfg->max_batch <= h->sched_slots);
   bool fits = true;
   if (can_help && h->help_mode < 0) {  // the extra trial buffers must stay a small part of the device's memory
     size_t free_b = 0, total_b = 0;
@@ -859,11 +899,13 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   }
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
   A(&h->st, B * sizeof(TrajState));
-  A(&h->o.rtn, B * 4); A(&h->o.iter_used, B * 4); A(&h->o.fwd_passes, B * 4);
-  A(&h->o.infeas_out, B); A(&h->o.line_failed_out, B);
-  A(&h->o.cost, B * r); A(&h->o.costq, B * r); A(&h->o.jerk_cost, B * r); A(&h->o.terminal_norm2, B * r);
-  A(&h->o.opterr, B * r); A(&h->o.mu, B * r);
-  A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
+  if (!packed) {
+    A(&h->o.rtn, B * 4); A(&h->o.iter_used, B * 4); A(&h->o.fwd_passes, B * 4);
+    A(&h->o.infeas_out, B); A(&h->o.line_failed_out, B);
+    A(&h->o.cost, B * r); A(&h->o.costq, B * r); A(&h->o.jerk_cost, B * r); A(&h->o.terminal_norm2, B * r);
+    A(&h->o.opterr, B * r); A(&h->o.mu, B * r);
+    A(&h->o.bez, B * nm * 18 * r); A(&h->o.poly, B * nm * 18 * r); A(&h->o.T, B * nm * r);
+  }
   A(&h->best_idx, 16); A(&h->best_cost, 16);
   A(&h->sched, (B + 2) * sizeof(int));
   A(&h->visits, 4 * sizeof(unsigned long long));  // [0] backward knots, [1] forward trial-knots, [2] knots whose front half a helper computed, [3] accepted line searches
@@ -893,6 +935,9 @@ direct_status_t direct_ddp_destroy(direct_ddp_handle_t h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
+  for (char* q : {h->in_host, h->out_host, h->out0_host})
+    if (q) (void)hipHostFree(q);
+  if (h->in_ev) (void)hipEventDestroy(h->in_ev);
   if (h->filt) (void)hipFree(h->filt);
   for (void* q : {h->g_recs, h->g_blocks, h->g_win, h->g_in})
     if (q) (void)hipFree(q);
@@ -1019,7 +1064,17 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
         if (np < 1 || np > h->pmax) return fail(DIRECT_ERR_INVALID, "n_planes out of range");
       }
     }
-    auto up = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream); };
+    const bool packed = h->in_blob != nullptr;
+    if (packed && h->in_ev_pending) {  // the mirror's previous upload (a call whose outputs stayed on the device never synchronised)
+      HIP_TRY(hipEventSynchronize(h->in_ev));
+      h->in_ev_pending = false;
+    }
+    // packed: the array goes into the pinned mirror at its slice's offset; ONE copy of the whole mirror follows
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+      if (!packed) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+      memcpy(h->in_host + ((char*)dst - h->in_blob), src, bytes);
+      return hipSuccess;
+    };
     HIP_TRY(up(h->n_seg, in->n_seg, B * 4)); d.n_seg = h->n_seg;
     HIP_TRY(up(h->x0, in->x0, B * 9 * r)); d.x0 = h->x0;
     HIP_TRY(up(h->xd, in->xd, B * 9 * r)); d.xd = h->xd;
@@ -1030,6 +1085,11 @@ static direct_status_t stage_inputs(direct_ddp_handle_t h, const direct_ddp_para
     if (in->init_poly) { HIP_TRY(up(h->init_poly, in->init_poly, B * nm * 18 * r)); d.init_poly = h->init_poly; }
     if (in->seeds) { HIP_TRY(up(h->seeds, in->seeds, B * nm * 3 * r)); d.seeds = h->seeds; }
     if (in->infeas_in) { HIP_TRY(up(h->infeas_in, in->infeas_in, B)); d.infeas_in = h->infeas_in; }
+    if (packed) {
+      HIP_TRY(hipMemcpyAsync(h->in_blob, h->in_host, h->in_blob_bytes, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipEventRecord(h->in_ev, h->stream));
+      h->in_ev_pending = true;
+    }
   }
   if (!in->infeas_in) {
     HIP_TRY(hipMemsetAsync(h->infeas_in, p->infeas ? 1 : 0, B, h->stream));
@@ -1093,8 +1153,21 @@ static direct_status_t launch_finish(direct_ddp_handle_t h, direct_ddp_batch_out
   HIP_TRY(hipGetLastError());
   if (out->mem == DIRECT_MEM_HOST) {
     const size_t B = h->B, nm = h->nmax, r = h->rsz;
+    const bool packed = h->out_blob != nullptr;
+    int sched_err_p = 0;
+    if (packed) {  // one copy of every result array into the pinned mirror; the caller's arrays are filled from it
+      HIP_TRY(hipMemcpyAsync(h->out_host, h->out_blob, h->out_blob_bytes, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipMemcpyAsync(&sched_err_p, h->sched + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      h->in_ev_pending = false;
+    }
     auto dn = [&](void* dst, const void* src, size_t bytes) {
-      return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+      if (!dst) return hipSuccess;
+      if (packed) {
+        memcpy(dst, h->out_host + ((const char*)src - h->out_blob), bytes);
+        return hipSuccess;
+      }
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream);
     };
     HIP_TRY(dn(out->rtn, h->o.rtn, B * 4)); HIP_TRY(dn(out->iter_used, h->o.iter_used, B * 4));
     HIP_TRY(dn(out->fwd_passes, h->o.fwd_passes, B * 4));
@@ -1104,9 +1177,12 @@ static direct_status_t launch_finish(direct_ddp_handle_t h, direct_ddp_batch_out
     HIP_TRY(dn(out->opterr, h->o.opterr, B * r)); HIP_TRY(dn(out->mu, h->o.mu, B * r));
     HIP_TRY(dn(out->bez, h->o.bez, B * nm * 18 * r)); HIP_TRY(dn(out->poly, h->o.poly, B * nm * 18 * r));
     HIP_TRY(dn(out->T, h->o.T, B * nm * r));
-    int sched_err = 0;
-    HIP_TRY(hipMemcpyAsync(&sched_err, h->sched + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    int sched_err = sched_err_p;
+    if (!packed) {
+      HIP_TRY(hipMemcpyAsync(&sched_err, h->sched + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      h->in_ev_pending = false;
+    }
     if (sched_err) return fail(DIRECT_ERR_DEVICE, "ticket scheduler of k_iterate hit its spin limit; results are incomplete");
   }
   return DIRECT_OK;
@@ -1165,7 +1241,10 @@ direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_pa
   stage.terminal_norm2 = h->o.terminal_norm2; stage.opterr = h->o.opterr; stage.mu = h->o.mu;
   stage.bez = h->o.bez; stage.poly = h->o.poly; stage.T = h->o.T;
   TRY(launch_finish(h, &stage));
-  if (out0) {  // hand phase-0 results to the caller as well
+  const bool out0_packed = out0 && out0->mem == DIRECT_MEM_HOST && h->out_blob != nullptr;
+  if (out0_packed) {  // one copy into the second pinned mirror now; the caller's arrays are filled after phase 1 has synchronised
+    HIP_TRY(hipMemcpyAsync(h->out0_host, h->out_blob, h->out_blob_bytes, hipMemcpyDeviceToHost, h->stream));
+  } else if (out0) {  // hand phase-0 results to the caller as well
     const size_t B = h->B, nm = h->nmax, r = h->rsz;
     hipMemcpyKind kind = out0->mem == DIRECT_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     auto cp = [&](void* dst, const void* src, size_t bytes) { return dst ? hipMemcpyAsync(dst, src, bytes, kind, h->stream) : hipSuccess; };
@@ -1198,7 +1277,20 @@ direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_pa
   TRY(stage_inputs(h, p1, &in1, false));
   TRY(launch_begin(h));
   TRY(launch_iterate(h, p1->iter_max, 0));
-  return launch_finish(h, out1);
+  const direct_status_t fin = launch_finish(h, out1);
+  if (out0_packed) {
+    if (out1->mem != DIRECT_MEM_HOST) HIP_TRY(hipStreamSynchronize(h->stream));  // (host results of phase 1 have synchronised already)
+    const size_t B = h->B, nm = h->nmax, r = h->rsz;
+    auto sc = [&](void* dst, const void* src, size_t bytes) {
+      if (dst) memcpy(dst, h->out0_host + ((const char*)src - h->out_blob), bytes);
+    };
+    sc(out0->rtn, h->o.rtn, B * 4); sc(out0->iter_used, h->o.iter_used, B * 4); sc(out0->fwd_passes, h->o.fwd_passes, B * 4);
+    sc(out0->infeas_out, h->o.infeas_out, B); sc(out0->line_failed_out, h->o.line_failed_out, B);
+    sc(out0->cost, h->o.cost, B * r); sc(out0->costq, h->o.costq, B * r); sc(out0->jerk_cost, h->o.jerk_cost, B * r);
+    sc(out0->terminal_norm2, h->o.terminal_norm2, B * r); sc(out0->opterr, h->o.opterr, B * r); sc(out0->mu, h->o.mu, B * r);
+    sc(out0->bez, h->o.bez, B * nm * 18 * r); sc(out0->poly, h->o.poly, B * nm * 18 * r); sc(out0->T, h->o.T, B * nm * r);
+  }
+  return fin;
 }
 
 static size_t field_elems(direct_ddp_handle_t h, int field) {

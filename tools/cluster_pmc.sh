@@ -1,7 +1,7 @@
 #!/bin/bash
 # L2 hit rate and HBM bytes of the cluster path's kernels (separate --pmc passes; run through gpurun from the repo root):
 #   writes gpurun_out/rNN_cluster_pmc.json.  usage: tools/cluster_pmc.sh r03
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -5,7 +5,7 @@
 #   gpurun_out/rNN_hbm_calib.json           tools/hbm_calib: counter calibration for dword streams + measured HBM peak
 #   gpurun_out/rNN_sq_counters.json, rNN_hbm_traffic.json   separate --pmc passes over tools/prof_one.py (same workload)
 # Copy the files into profiles/ afterwards.  usage: tools/profile_round.sh r02 [quick]
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
