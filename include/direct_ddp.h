@@ -145,9 +145,13 @@ typedef struct {
  * bitwise-equality test): two line-search steps per forward sweep (batches up to 2 x the resident waves;
  * DIRECT_DDP_PAIR=0|1 forces) and the shared line search, in which waves waiting for a trajectory evaluate later
  * steps of its line search (batches up to 1.5 x the resident waves and n_seg_max >= 80 - shorter trajectories do not
- * pay for the hand-over -, handles of at most 2 x; DIRECT_DDP_HELP=0|1 forces, read at create time: such a handle keeps
- * 12 iterate buffers instead of 3).  With the shared line search the ticket scheduler also serves batches below the
- * resident waves, where the waves left over become helpers (single-trajectory latency: -20 %). */
+ * pay for the hand-over unless the batch is at most an eighth of the resident waves -, handles of at most 2 x;
+ * DIRECT_DDP_HELP=0|1 forces, read at create time: such a handle keeps 12 iterate buffers instead of 3).  With the shared
+ * line search the ticket scheduler also serves batches below the resident waves, where the waves left over become helpers
+ * (single-trajectory latency: -20 %).  A third choice of the same kind: for batches up to an eighth of the resident waves
+ * (row-slot classes of up to 33 planes) the waiting waves also compute the value-independent half of the knots of the
+ * trajectory's BACKWARD sweep and hand it over through records in HBM (DIRECT_DDP_BSHARE=0 off, 1 for every batch with a
+ * shared line search, 2 the same path forced without helpers - the tests' bitwise check; read at create time). */
 #define DIRECT_FLAG_STATIC_SCHEDULE 1
 
 typedef struct direct_ddp_handle_s* direct_ddp_handle_t;
