@@ -20,9 +20,13 @@ OUT = os.path.join(_HERE, "lib", "libdirect_ddp.so")
 # with only the IR vectorizer off the hot kernel still carried ~3000 ds_read2_b64.  Switching the feature off
 # is worth 5 % at B = 4096 and 9 % at B = 16384 (r02).  The feature string also reaches the host compile, which
 # does not know it and says so on stderr: those lines are filtered in build().
+# -amdgpu-sched-strategy=iterative-ilp: the machine scheduler that maximises instruction-level parallelism per region,
+# iterating under the occupancy target (round 5, same-box A/B against the default max-occupancy strategy, identical
+# results: config 2 34.15 -> 33.93 ms, B = 16384 120.6 -> 119.4, f64 corridors 34.8 -> 34.3, the wide real-corridor classes
+# 30.7 -> 29.8; max-ilp and max-memory-clause measured like the default, iterative-minreg 12 % slower).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-DDDP_WAVES_F32=3", "-DDDP_WAVES_F64=3", "-mllvm", "-amdgpu-load-store-vectorizer=0",
-         "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+         "-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
 def hipcc():

@@ -5,7 +5,7 @@
 set -e
 ROOT=$(cd $(dirname $0)/.. && pwd); name=$1; shift
 mkdir -p $ROOT/build_variants
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDDP_WAVES_F32=3 -DDDP_WAVES_F64=3 -mllvm -amdgpu-load-store-vectorizer=0 -Xclang -target-feature -Xclang -load-store-opt"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDDP_WAVES_F32=3 -DDDP_WAVES_F64=3 -mllvm -amdgpu-load-store-vectorizer=0 -Xclang -target-feature -Xclang -load-store-opt -mllvm -amdgpu-sched-strategy=iterative-ilp"
 for m in direct_cluster direct_quad; do
   [ -f $ROOT/build_variants/$m.o ] && [ $ROOT/build_variants/$m.o -nt $ROOT/direct_amd/csrc/$m.hip ] || hipcc $F -c $ROOT/direct_amd/csrc/$m.hip -o $ROOT/build_variants/$m.o 2>&1 | grep -v "not a recognized feature" || true
 done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: asm.sh out.s [extra flags]; prints phase counts, private segment sizes and in-loop scratch ops
 out=$1; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDDP_WAVES_F32=3 -DDDP_WAVES_F64=3 -mllvm -amdgpu-load-store-vectorizer=0 -Xclang -target-feature -Xclang -load-store-opt -DDDP_MARKS -S --cuda-device-only -I/root/repo/include -I/root/repo/direct_amd/csrc "$@" /root/repo/direct_amd/csrc/direct_ddp.hip -o $out 2>&1 | grep -E "error" | head
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDDP_WAVES_F32=3 -DDDP_WAVES_F64=3 -mllvm -amdgpu-load-store-vectorizer=0 -Xclang -target-feature -Xclang -load-store-opt -mllvm -amdgpu-sched-strategy=iterative-ilp -DDDP_MARKS -S --cuda-device-only -I/root/repo/include -I/root/repo/direct_amd/csrc "$@" /root/repo/direct_amd/csrc/direct_ddp.hip -o $out 2>&1 | grep -E "error" | head
 python /root/repo/tools/phase_count.py $out
 python - $out <<'PY'
 import re,sys
