@@ -419,7 +419,13 @@ struct BwdShare {
   unsigned long long claim;  // free knots [low, high): low in bits 0..31 (helpers take from below), high + 2^30 in bits 32..63 (the owner from above)
 };
 constexpr int kRecDoubles = 384;  // one knot's hand-over record: six doubles per lane, stored as three 16-byte halves per lane
-constexpr int kOwnChunk = 2, kHelpChunk = 4;  // knots per claim (the owner takes little: a knot it runs fused costs it twice a knot from a record)
+#ifndef DDP_OWN_CHUNK
+#define DDP_OWN_CHUNK 2
+#endif
+#ifndef DDP_HELP_CHUNK
+#define DDP_HELP_CHUNK 4
+#endif
+constexpr int kOwnChunk = DDP_OWN_CHUNK, kHelpChunk = DDP_HELP_CHUNK;  // knots per claim (the owner takes little: a knot it runs fused costs it twice a knot from a record)
 constexpr unsigned long long kClaimBias = 1ull << 30;
 
 // ---- device-resident batch (all pointers are device memory) -----------------------------------

@@ -16,8 +16,10 @@ def build(force=False):
     srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "../../direct_amd/csrc/ddp_wave.h"),
             os.path.join(_HERE, "../../direct_amd/csrc/ddp_tables.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
+        tmp = "%s.tmp.%d" % (so, os.getpid())   # built aside and renamed: parallel test workers never load a half-written library
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w",
-                               "-o", so, srcs[0]])
+                               "-o", tmp, srcs[0]])
+        os.replace(tmp, so)
     return so
 
 
