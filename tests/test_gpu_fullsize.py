@@ -89,10 +89,15 @@ def test_free_space_full_batch_fp32(built, free_batch):
     r1, _ = refapi.solve_batch(p1, b1.astype(np.float64))
     assert (g1.rtn[idx] == r1.rtn).all()
     dev = np.abs(g1.cost[idx] / r1.cost - 1)
-    # every problem within 1e-3 - except, at most, the knife-edge one (it flips with a 1e-7 change anywhere in the float
-    # storage path; with the r03 build it does not)
-    assert np.median(dev) < 1e-6 and (dev < 1e-3).sum() >= len(dev) - 1, np.sort(dev)[::-1][:5]
-    assert np.sort(np.abs(g1.iter_used[idx] - r1.iter_used))[-2] <= 1
+    # The bulk within 1e-6; the tail - knife-edge problems that flip with a 1e-7 change anywhere in the float path - is
+    # held to the CONTROL: the oracle against itself on these very problems with every input moved by one ulp of a float
+    # (two seeds): as many problems within 1e-3, and iteration counts no further apart, than the controls themselves show
+    from tests import n100_lib
+    ctl = [refapi.solve_batch(p1, n100_lib.perturb_float_ulp(b1.astype(np.float64), 500 + q))[0] for q in range(2)]
+    c_ok = min(int((np.abs(c.cost / r1.cost - 1) < 1e-3).sum()) for c in ctl)
+    c_it = max(int(np.sort(np.abs(c.iter_used - r1.iter_used))[-2]) for c in ctl)
+    assert np.median(dev) < 1e-6 and (dev < 1e-3).sum() >= c_ok, (np.sort(dev)[::-1][:5], c_ok)
+    assert np.sort(np.abs(g1.iter_used[idx] - r1.iter_used))[-2] <= max(1, c_it), (c_it,)
     idx = np.array([0, 777, 2048, 4095])
     r0, r1 = refapi.plan_batch(p0, p1, free_batch.select(idx))
     # at a FIXED iteration count the two precisions follow the same path much more closely

@@ -83,7 +83,13 @@ def test_whole_solve_fp32_tolerance(built, name):
     assert (f1.rtn == g["p1_rtn"].astype(int)).all()
     assert np.abs(f1.cost / g["p1_cost"] - 1).max() < 1e-4, np.abs(f1.cost / g["p1_cost"] - 1).max()
     assert helpers.rel(f1.T, g["p1_T"]) < 1e-3
-    assert np.abs(f1.iter_used - g["p1_iter_used"].astype(int)).max() <= 3
+    # iteration counts: held to what merely STORING the inputs in float does to the oracle itself (every real input moved
+    # by -1 / 0 / +1 ulp of a float, four seeds) - not to a constant
+    from tests import n100_lib
+    c1 = b1.with_init(None, T0=b1.T0, infeas_in=b1.infeas_in, init_poly=g["p0_poly"])
+    ctl = max(int(np.abs(refapi.solve_batch(p1, n100_lib.perturb_float_ulp(c1, 7000 + q))[0].iter_used - g["p1_iter_used"].astype(int)).max())
+              for q in range(4))
+    assert np.abs(f1.iter_used - g["p1_iter_used"].astype(int)).max() <= ctl, (f1.iter_used, g["p1_iter_used"], ctl)
     s.close()
 
 
