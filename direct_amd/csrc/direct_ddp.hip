@@ -91,6 +91,7 @@ struct Sched {
   int* err;           // [1] set to 1 when the spin limit is hit
   int chunk;
   int prio;           // raise the wave priority of chunks that had to wait for their predecessor
+  int tail;           // rounds of help-only tickets behind the last epoch (next_work)
 };
 // The next piece of work for a persistent wave.  `held` < 0: draws the next ticket (epoch, trajectory) = (t / batch,
 // t % batch); else continues to wait with ticket `held` in hand.  Waits for the previous chunk of the ticket's trajectory.
@@ -100,8 +101,12 @@ struct Sched {
 // wait for trajectory b timed out (the chunk is then skipped and b marked finished).  Out of line and free of early
 // exits on purpose: inlined into the (huge) iterate loop the structuriser turned the nested uniform loops into
 // exec-masked ones.
-__device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, BwdShare* sweeps, const int32_t* idx, unsigned nb, unsigned total, int held,
-                                                   int* waited, int* help) {
+// Tickets total .. total_help - 1 are HELP-ONLY: `tail` more rounds over the trajectories behind the last epoch.  A wave that
+// draws one waits for the trajectory's last chunk like any waiter - and so joins its open line searches (and shared
+// sweeps) - but never runs a chunk: -2 once that chunk is done.  Without them the waves leave a fixed-length launch as soon
+// as the tickets run out, and the last iterations of the slowest chains - the launch's tail - search alone on an emptying chip.
+__device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, BwdShare* sweeps, const int32_t* idx, unsigned nb, unsigned total,
+                                                   unsigned total_help, int held, int* waited, int* help) {
   unsigned t = (unsigned)held;
   if (held < 0) {
     unsigned tv = 0;
@@ -110,8 +115,10 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
     *waited = 0;
   }
   *help = 0;
-  if (t >= total) return -1;
-  const int e = (int)(t / nb), bi = (int)(t - (unsigned)e * nb);
+  if (t >= total_help) return -1;
+  const int et = (int)(t / nb), bi = (int)(t - (unsigned)et * nb);
+  const int n_ep = (int)(total / nb);
+  const int e = et < n_ep ? et : n_ep;  // what the ticket waits for
   const int b = idx ? __builtin_amdgcn_readfirstlane(idx[bi]) : bi;  // done_epoch / slots are indexed by the trajectory's own number
   int ready = (e == 0) ? 1 : 0, have = 0, wanted = 0;
   int spins = 0;
@@ -146,7 +153,7 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
     if (threadIdx.x == 0) __hip_atomic_store(S.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return -3 - b;
   }
-  if (have >= kDoneBit) return -2;
+  if (have >= kDoneBit || t >= total) return -2;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return (int)t;
 }
@@ -159,13 +166,14 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
   const unsigned nb = (unsigned)B.B;
   const unsigned n_epochs = (unsigned)((n_iters + S.chunk - 1) / S.chunk);
   const unsigned total = nb * n_epochs;
+  const unsigned total_help = B.help ? total + nb * (unsigned)S.tail : total;
   DDP_MARK("Z_0");
   int held = -1, waited = 0;
 #pragma unroll 1
   for (;;) {
     int help_v = 0;
     DDP_MARK("X_T");
-    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, SHARE ? B.bshare : nullptr, B.idx, nb, total, held, &waited, &help_v));
+    const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, SHARE ? B.bshare : nullptr, B.idx, nb, total, total_help, held, &waited, &help_v));
     const int help = __builtin_amdgcn_readfirstlane(help_v);
     DDP_MARK("X_G");
     held = -1;
@@ -417,6 +425,7 @@ struct direct_ddp_handle_s {
   int sched_chunk = 1;   // outer-loop trips per ticket (DIRECT_DDP_CHUNK at create time; experiments)
   int pair_trials = -1;  // two line-search steps per forward sweep from the second attempt on: -1 auto, DIRECT_DDP_PAIR=0|1 forces
   int sched_prio = 1;    // chunks that had to wait for their predecessor run at raised wave priority (DIRECT_DDP_PRIO=0: off)
+  int sched_tail = 8;    // rounds of help-only tickets behind the last epoch (DIRECT_DDP_TAIL=0: none; next_work)
   bool dynamic = true;
   // current batch
   int B = 0;
@@ -648,6 +657,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.done_epoch = h->sched + 2;
       S.chunk = h->sched_chunk;
       S.prio = h->sched_prio;
+      S.tail = help ? h->sched_tail : 0;
       if (help) {
         Bt.help = h->help;
         Bt.help_early = h->help_early;
@@ -914,6 +924,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->order, B * sizeof(int32_t)); A(&h->cls_dev, B * sizeof(int32_t));
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
   if (const char* ev = getenv("DIRECT_DDP_PRIO")) h->sched_prio = atoi(ev);
+  if (const char* ev = getenv("DIRECT_DDP_TAIL")) h->sched_tail = std::max(0, std::min(atoi(ev), 64));
   if (const char* ev = getenv("DIRECT_DDP_PAIR")) h->pair_trials = atoi(ev);
   h->fieldbuf_bytes = B * nm * (size_t)std::max(ncm, 100) * r + B * 16 * r + B * 9 * r;
   A(&h->fieldbuf, h->fieldbuf_bytes);
