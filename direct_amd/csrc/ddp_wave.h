@@ -471,11 +471,17 @@ struct Batch {
   const void* self;  // this very struct in device memory: what the out-of-line halves of a shared sweep (front_cold, back_cold) are handed
   unsigned long long* bvisits;  // [1] knots whose front half a helper (or the forced split) computed (observability; may be null)
 #if defined(DDP_TIMELINE)  // debug builds (tools/timeline.py): wall-clock stamps per trajectory and outer iteration
-  unsigned long long* tl;  // [B][32][4]: start, end of the backward sweeps, end (100 MHz), knots that came through records
+  unsigned long long* tl;  // [B][kTimelineDepth][4]: start, end of the backward sweeps, end (100 MHz), knots that came through records
 #endif
   SolveConst k;
 };
 
+#if defined(DDP_TIMELINE)
+#ifndef DDP_TIMELINE_DEPTH
+#define DDP_TIMELINE_DEPTH 32
+#endif
+constexpr int kTimelineDepth = DDP_TIMELINE_DEPTH;  // outer iterations stamped per trajectory
+#endif
 constexpr int kXS = 24;  // LDS knot record: x (9), u (10), pad
 // Knot record stride of X in HBM.  With float storage EVERY entry of the iterate (x, u) is an unevaluated hi + lo float
 // pair (words a and 19 + a): the filter line search demands a STRICT decrease of a log-cost of ~2e6 that moves by 1e-10
@@ -3418,7 +3424,7 @@ struct Wave {
     double f_mu = 0.0;
     if (helper == 2 && (bsf == nullptr || !bs_enter(bsf, f_tag, f_cur, f_infeas, f_mu))) return;
 #if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
-    unsigned long long* tl_ = (!helper && B.tl != nullptr && st.fwd_passes < 32) ? B.tl + ((size_t)b * 32 + st.fwd_passes) * 4 : nullptr;
+    unsigned long long* tl_ = (!helper && B.tl != nullptr && st.fwd_passes < kTimelineDepth) ? B.tl + ((size_t)b * kTimelineDepth + st.fwd_passes) * 4 : nullptr;
     if (tl_ != nullptr && threadIdx.x == 0) { tl_[0] = __builtin_amdgcn_s_memrealtime(); tl_[3] = 0; }
     tl_split_ = 0;
 #endif

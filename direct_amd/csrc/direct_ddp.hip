@@ -603,12 +603,12 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     auto Bt = make_batch<Real>(h, h->cur_in, h->params, c);
     Bt.visits = h->visits;
 #if defined(DDP_TIMELINE)
-    if (g_tl_n < (size_t)h->B * 32 * 4) {
+    if (g_tl_n < (size_t)h->B * kTimelineDepth * 4) {
       if (g_tl) (void)hipFree(g_tl);
-      g_tl_n = (size_t)h->B * 32 * 4;
+      g_tl_n = (size_t)h->B * kTimelineDepth * 4;
       (void)hipMalloc((void**)&g_tl, g_tl_n * 8);
     }
-    (void)hipMemsetAsync(g_tl, 0, (size_t)h->B * 32 * 4 * 8, h->stream);
+    (void)hipMemsetAsync(g_tl, 0, (size_t)h->B * kTimelineDepth * 4 * 8, h->stream);
     Bt.tl = g_tl;
 #endif
     hipStream_t st = h->stream;
@@ -1373,7 +1373,7 @@ direct_status_t direct_ddp_last_launch_info(direct_ddp_handle_t h, direct_ddp_la
 #if defined(DDP_TIMELINE)  // debug builds only (tools/timeline.py)
 direct_status_t direct_ddp_debug_timeline(direct_ddp_handle_t h, void* dst) {
   if (!g_tl) return fail(DIRECT_ERR_INVALID, "no timeline");
-  HIP_TRY(hipMemcpy(dst, g_tl, (size_t)h->B * 32 * 4 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dst, g_tl, (size_t)h->B * kTimelineDepth * 4 * 8, hipMemcpyDeviceToHost));
   return DIRECT_OK;
 }
 #endif

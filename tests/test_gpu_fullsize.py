@@ -314,6 +314,43 @@ def test_shared_line_search_other_storage_types_and_chunk_sizes(built, dt, nb, n
     assert res["1"][1].iter_used.max() > 5
 
 
+@pytest.mark.parametrize("dt,nb,kind,chunk", [(np.float32, B, "free", "1"), (np.float64, 3300, "corridor", "1"), (np.float32, 5000, "corridor", "3"),
+                                              (np.float32, 2, "free", "1")])
+def test_help_only_tickets_behind_the_last_epoch_change_no_bit(built, dt, nb, kind, chunk, monkeypatch):
+    """A fixed-length launch hands out DIRECT_DDP_TAIL more rounds of tickets behind its last epoch that never run a
+    chunk: their holders wait for the trajectory's last chunk and join its open line searches meanwhile (direct_ddp.hip,
+    next_work), instead of leaving the kernel while the slowest chains still search.  0, 1 and the default 8 rounds: the
+    fixed-20 launch (twice each: the interleaving differs) and the natural exits are bit-identical, the error flag stays clear
+    (a help-only ticket that waited for an epoch that never comes would raise it)."""
+    batch = problems.make_batch(kind, nb, 60 if chunk == "3" else N, seed=900 + nb).astype(dt)
+    nseg = int(batch.n_seg.max())
+    fields = ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez")
+    monkeypatch.setenv("DIRECT_DDP_CHUNK", chunk)
+    fixed, nat = {}, {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("DIRECT_DDP_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("DIRECT_DDP_TAIL", mode)
+        s = solver.DdpSolver(nb, nseg, batch.p_max, dt)
+        nat[mode] = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=30), batch)
+        assert s.sched_error() == 0
+        g0 = nat[mode][0]
+        b1 = batch.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, batch.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
+        for _ in range(2):
+            fixed.setdefault(mode, []).append(s.solve(abi.phase1_params(iter_max=20, fixed_iters=1), b1))
+            assert s.sched_error() == 0
+        s.close()
+    for mode in ("1", None):
+        for a, b in zip(nat["0"], nat[mode]):
+            for f in fields:
+                assert np.array_equal(getattr(a, f), getattr(b, f)), (mode, f)
+        for g in fixed[mode] + fixed["0"][1:]:
+            for f in fields:
+                assert np.array_equal(getattr(fixed["0"][0], f), getattr(g, f)), (mode, f)
+    assert fixed["0"][0].iter_used.max() == 20
+
+
 @pytest.mark.parametrize("nb,kind,dt", [(1, "corridor", np.float32), (7, "free", np.float64), (300, "corridor", np.float32)])
 def test_small_batches_on_the_ticket_scheduler_match_the_static_launch(built, nb, kind, dt, monkeypatch):
     """Below the resident waves the launch used to be one workgroup per trajectory; with the shared line search the
