@@ -3,7 +3,7 @@ bash tools/fastbuild.sh timeline -DDDP_TIMELINE -DDDP_TIMELINE_DEPTH=64;
 DIRECT_DDP_LIB=direct_amd/lib/dev_timeline.so python tools/natural_timeline.py [B] [out.json]).
 Where the slowest chains spend their time (busy, waiting for their next ticket), how fast an iteration is against the number
 of trajectories still running, and a replay of the measured durations through models of the scheduler: strict tickets
-(what runs), and long chains KEPT by their wave (no wait for the ticket counter), chosen by an oracle or by the phase-0 cost."""
+(what runs), and long chains KEPT by their wave (no wait for the ticket counter), chosen with hindsight (the true iteration counts) or by the phase-0 cost."""
 import ctypes as C, heapq, json, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -97,7 +97,7 @@ for frac in (0.5, 0.25, 0.125):
     k = int(B * frac)
     o = np.zeros(B, bool); o[np.argsort(n)[::-1][:k]] = True
     p = np.zeros(B, bool); p[np.argsort(g0.cost)[::-1][:k]] = True
-    out["model_us"]["keep_oracle_top_%g" % frac] = simulate(o)
+    out["model_us"]["keep_hindsight_top_%g" % frac] = simulate(o)
     out["model_us"]["keep_phase0_cost_top_%g" % frac] = simulate(p)
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 2:
