@@ -420,6 +420,56 @@ __device__ __forceinline__ int ray_walk_lin(const Dev& D, const uint8_t* fl, con
     if (f & F_OBS) return 1;
   }
 }
+// The same walk with the loads taken off its critical path.  Which voxel comes next never depends on what the voxels
+// hold - only WHEN the walk ends does - so a trip of the loop advances kWalkDepth voxels (selects, no branch: a lane whose
+// walk has reached its end voxel or used up its budget stands still on a valid voxel), issues their loads together and then
+// judges them in step order; steps taken past a hit are thrown away.  The loop is uniform over the wave (it runs while any
+// lane is undecided), so there is no exec-mask bookkeeping for the four exits of the serial form either.  Same float
+// sequence, same visiting order, same answer as ray_walk_lin bit for bit (tests/test_gpu_cluster.py).
+#ifndef CLUSTER_WALK_DEPTH
+#define CLUSTER_WALK_DEPTH 4
+#endif
+constexpr int kWalkDepth = CLUSTER_WALK_DEPTH;
+__device__ __forceinline__ int ray_walk_pipe(const Dev& D, const uint8_t* fl, const float* inv, int cx, int cy, int cz, int target, int valid) {
+  const int tg = valid ? target : 0;
+  const int ex = valid ? px(tg) : cx, ey = valid ? py(tg) : cy, ez = valid ? pz(tg) : cz;
+  const int dx = ex - cx, dy = ey - cy, dz = ez - cz;
+  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+  const int ix = dx < 0 ? -D.max_yz : D.max_yz, iy = dy < 0 ? -D.max_z : D.max_z, iz = dz < 0 ? -1 : 1;
+  const float tDX = inv[ax], tDY = inv[ay], tDZ = inv[az];
+  float tMaxX = dx ? 0.5f * tDX : INFINITY, tMaxY = dy ? 0.5f * tDY : INFINITY, tMaxZ = dz ? 0.5f * tDZ : INFINITY;
+  int id = cx * D.max_yz + cy * D.max_z + cz;
+  const int eid = ex * D.max_yz + ey * D.max_z + ez;
+  int budget = ax + ay + az;
+  int res = valid ? -1 : 0;  // -1: walking
+  while (__any(res < 0)) {
+    bool live = res < 0;
+    unsigned f[kWalkDepth];
+    bool lv[kWalkDepth];
+#pragma unroll
+    for (int u = 0; u < kWalkDepth; u++) {
+      const bool xy = tMaxX < tMaxY, xz = tMaxX < tMaxZ, yz = tMaxY < tMaxZ;
+      const bool sx = xy && xz, sy = !xy && yz;
+      const bool sz = !sx && !sy;
+      const int nid = id + (sx ? ix : (sy ? iy : iz));
+      const float nx = tMaxX + tDX, ny = tMaxY + tDY, nz = tMaxZ + tDZ;
+      tMaxX = sx ? nx : tMaxX;  // (what a lane that stands still does to its tMax is never looked at again)
+      tMaxY = sy ? ny : tMaxY;
+      tMaxZ = sz ? nz : tMaxZ;
+      budget -= 1;
+      live = live && nid != eid && budget >= 0;
+      id = live ? nid : eid;  // a walk that is over stands on its end voxel: always a voxel of the map
+      lv[u] = live;
+      f[u] = fl[id];
+    }
+#pragma unroll
+    for (int u = 0; u < kWalkDepth; u++) {
+      const int r = !lv[u] ? 0 : ((f[u] & F_INSIDE) ? 0 : ((f[u] & F_OBS) ? 1 : -1));
+      res = res >= 0 ? res : r;
+    }
+  }
+  return res;
+}
 // the tests in front of a walk as k_convex runs them: the reference's two, then the box test
 // (any_target: the kernel-level entry point takes arbitrary targets; inside polygonGeneration a target is a cluster voxel or
 // a candidate, and neither lies inside the cube: CS:491-494, 301-353)
@@ -484,6 +534,11 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
     __syncthreads();  // the next candidate reuses the workgroup's LDS
   }
 }
+#if defined(CLUSTER_WALK_SERIAL)  // A/B builds: the branching one-voxel-per-trip walk
+#define WALK(D, fl, inv, cx, cy, cz, q, valid) ((valid) ? ray_walk_lin(D, fl, inv, cx, cy, cz, q) : 0)
+#else
+#define WALK ray_walk_pipe
+#endif
 __device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, int i, int full) {
   const int tid = threadIdx.x;
   const uint8_t* fl = D.flags + (size_t)e * D.G;
@@ -541,14 +596,14 @@ __device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, i
     push(need, tgt);
     if (count >= 64) {
       const int q = take(64);
-      bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, q);
+      bad |= WALK(D, fl, inv, cx, cy, cz, q, 1);
       if (!full && __any(bad)) s_bad = 1;  // a rejected candidate's rays towards other candidates are never consulted
     }
     if (!full && *(volatile int*)&s_bad) break;
   }
   if (count > 0 && !(!full && *(volatile int*)&s_bad)) {
     const int q = take(count);
-    if (q >= 0) bad |= ray_walk_lin(D, fl, inv, cx, cy, cz, q);
+    bad |= WALK(D, fl, inv, cx, cy, cz, q, q >= 0);
   }
   bad = __syncthreads_or(bad);
   if (tid == 0) D.can_clu[(size_t)e * D.kcap + i] = bad ? 0 : 1;
@@ -577,12 +632,12 @@ __device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, i
     push(j < i ? ray_needs_walk(D, fl, cx, cy, cz, cd[j], full) : 0, j);
     if (count >= 64) {
       const int jq = take(64);
-      if (ray_walk_lin(D, fl, inv, cx, cy, cz, cd[jq])) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
+      if (WALK(D, fl, inv, cx, cy, cz, cd[jq], 1)) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
     }
   }
   if (count > 0) {
     const int jq = take(count);
-    if (jq >= 0 && ray_walk_lin(D, fl, inv, cx, cy, cz, cd[jq])) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
+    if (WALK(D, fl, inv, cx, cy, cz, jq >= 0 ? cd[jq] : 0, jq >= 0)) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
   }
   __syncthreads();
   int nz = 0;
