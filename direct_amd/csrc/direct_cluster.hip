@@ -449,24 +449,29 @@ __device__ __forceinline__ int ray_walk_pipe(const Dev& D, const uint8_t* fl, co
 #pragma unroll
     for (int u = 0; u < kWalkDepth; u++) {
       const bool xy = tMaxX < tMaxY, xz = tMaxX < tMaxZ, yz = tMaxY < tMaxZ;
-      const bool sx = xy && xz, sy = !xy && yz;
-      const bool sz = !sx && !sy;
+      const bool sx = xy & xz, sy = !xy & yz;  // (bitwise on purpose: three lane masks, no selects of booleans)
+      const bool sz = !(sx | sy);
       const int nid = id + (sx ? ix : (sy ? iy : iz));
       const float nx = tMaxX + tDX, ny = tMaxY + tDY, nz = tMaxZ + tDZ;
       tMaxX = sx ? nx : tMaxX;  // (what a lane that stands still does to its tMax is never looked at again)
       tMaxY = sy ? ny : tMaxY;
       tMaxZ = sz ? nz : tMaxZ;
       budget -= 1;
-      live = live && nid != eid && budget >= 0;
+      live = live & (nid != eid) & (budget >= 0);
       id = live ? nid : eid;  // a walk that is over stands on its end voxel: always a voxel of the map
       lv[u] = live;
-      f[u] = fl[id];
+      f[u] = fl[(unsigned)id];  // (a voxel index is never negative: base + 32-bit offset addressing)
     }
+    // The four flag bytes side by side, a finished step standing in as "inside" (-> 0): the lowest set bit of the word is the
+    // first step that ends the walk, and within a byte F_INSIDE (bit 2) comes before F_OBS (bit 3) as in the serial walk.
+    static_assert(kWalkDepth <= 4 && F_INSIDE == 4 && F_OBS == 8, "one byte per step");
+    unsigned P = 0;
 #pragma unroll
-    for (int u = 0; u < kWalkDepth; u++) {
-      const int r = !lv[u] ? 0 : ((f[u] & F_INSIDE) ? 0 : ((f[u] & F_OBS) ? 1 : -1));
-      res = res >= 0 ? res : r;
-    }
+    for (int u = 0; u < kWalkDepth; u++) P |= (lv[u] ? f[u] : (unsigned)F_INSIDE) << (8 * u);
+    P &= 0x0c0c0c0cu;
+    const int pos = __builtin_ctz(P | 0x80000000u);
+    const int r = P == 0u ? -1 : (((pos & 7) == 3) ? 1 : 0);
+    res = res >= 0 ? res : r;
   }
   return res;
 }
