@@ -112,10 +112,13 @@ __global__ void k_sat_scan(Dev D, int axis) {  // running sums along one axis, o
 }
 // obstacles in the box [lo, hi] (inclusive voxel coordinates)
 __device__ __forceinline__ int box_obstacles(const Dev& D, int x0, int y0, int z0, int x1, int y1, int z1) {
-  const int* S = D.sat;
-  const int a0 = x0 * D.sat_yz, a1 = (x1 + 1) * D.sat_yz, b0 = y0 * D.sat_z, b1 = (y1 + 1) * D.sat_z, c0 = z0, c1 = z1 + 1;
-  return S[a1 + b1 + c1] - S[a0 + b1 + c1] - S[a1 + b0 + c1] - S[a1 + b1 + c0] + S[a0 + b0 + c1] + S[a0 + b1 + c0] +
-         S[a1 + b0 + c0] - S[a0 + b0 + c0];
+  // unsigned BYTE offsets from the table's (wave-uniform) base: one 32-bit add per corner, no 64-bit address arithmetic
+  const char* S = (const char*)D.sat;
+  const unsigned a0 = (unsigned)(x0 * D.sat_yz) << 2, a1 = (unsigned)((x1 + 1) * D.sat_yz) << 2, b0 = (unsigned)(y0 * D.sat_z) << 2,
+                 b1 = (unsigned)((y1 + 1) * D.sat_z) << 2, c0 = (unsigned)z0 << 2, c1 = (unsigned)(z1 + 1) << 2;
+  auto at = [&](unsigned off) { return *(const int*)(S + off); };
+  const unsigned a0b0 = a0 + b0, a0b1 = a0 + b1, a1b0 = a1 + b0, a1b1 = a1 + b1;
+  return at(a1b1 + c1) - at(a0b1 + c1) - at(a1b0 + c1) - at(a1b1 + c0) + at(a0b0 + c1) + at(a0b1 + c0) + at(a1b0 + c0) - at(a0b0 + c0);
 }
 
 // exclusive position of `flag` among the flags of a 256-thread block + the block total (ordered compaction)
@@ -436,7 +439,7 @@ __device__ __forceinline__ int ray_walk_pipe(const Dev& D, const uint8_t* fl, co
   const int dx = ex - cx, dy = ey - cy, dz = ez - cz;
   const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
   const int ix = dx < 0 ? -D.max_yz : D.max_yz, iy = dy < 0 ? -D.max_z : D.max_z, iz = dz < 0 ? -1 : 1;
-  const float tDX = inv[ax], tDY = inv[ay], tDZ = inv[az];
+  const float tDX = inv[(unsigned)ax], tDY = inv[(unsigned)ay], tDZ = inv[(unsigned)az];
   float tMaxX = dx ? 0.5f * tDX : INFINITY, tMaxY = dy ? 0.5f * tDY : INFINITY, tMaxZ = dz ? 0.5f * tDZ : INFINITY;
   int id = cx * D.max_yz + cy * D.max_z + cz;
   const int eid = ex * D.max_yz + ey * D.max_z + ez;
@@ -480,9 +483,9 @@ __device__ __forceinline__ int ray_walk_pipe(const Dev& D, const uint8_t* fl, co
 // a candidate, and neither lies inside the cube: CS:491-494, 301-353)
 __device__ __forceinline__ int ray_needs_walk(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target, int any_target) {
   const int ex = px(target), ey = py(target), ez = pz(target);
-  if (any_target && (fl[ex * D.max_yz + ey * D.max_z + ez] & F_INSIDE)) return 0;
+  if (any_target && (fl[(unsigned)(ex * D.max_yz + ey * D.max_z + ez)] & F_INSIDE)) return 0;
   const int mx = cx / 2 + (ex >> 1), my = cy / 2 + (ey >> 1), mz = cz / 2 + (ez >> 1);
-  if (fl[mx * D.max_yz + my * D.max_z + mz] & F_INSIDE) return 0;
+  if (fl[(unsigned)(mx * D.max_yz + my * D.max_z + mz)] & F_INSIDE) return 0;
   return box_obstacles(D, cx < ex ? cx : ex, cy < ey ? cy : ey, cz < ez ? cz : ez, cx < ex ? ex : cx, cy < ey ? ey : cy,
                        cz < ez ? ez : cz) != 0;
 }
