@@ -441,7 +441,8 @@ __device__ __forceinline__ int ray_walk_pipe(const Dev& D, const uint8_t* fl, co
   const int ix = dx < 0 ? -D.max_yz : D.max_yz, iy = dy < 0 ? -D.max_z : D.max_z, iz = dz < 0 ? -1 : 1;
   const float tDX = inv[(unsigned)ax], tDY = inv[(unsigned)ay], tDZ = inv[(unsigned)az];
   float tMaxX = dx ? 0.5f * tDX : INFINITY, tMaxY = dy ? 0.5f * tDY : INFINITY, tMaxZ = dz ? 0.5f * tDZ : INFINITY;
-  int id = cx * D.max_yz + cy * D.max_z + cz;
+  const int cid = cx * D.max_yz + cy * D.max_z + cz;
+  int id = cid;
   const int eid = ex * D.max_yz + ey * D.max_z + ez;
   int budget = ax + ay + az;
   int res = valid ? -1 : 0;  // -1: walking
@@ -461,8 +462,8 @@ __device__ __forceinline__ int ray_walk_pipe(const Dev& D, const uint8_t* fl, co
       tMaxZ = sz ? nz : tMaxZ;
       budget -= 1;
       live = live & (nid != eid) & (budget >= 0);
-      id = live ? nid : eid;  // a walk that is over stands on its end voxel: always a voxel of the map
-      lv[u] = live;
+      id = live ? nid : cid;  // a walk that is over stands on the candidate's own voxel: the SAME cache line for every such lane
+      lv[u] = live;           // of the wave (k_convex runs at the L1's line rate: a lane parked on a line of its own costs a lookup)
       f[u] = fl[(unsigned)id];  // (a voxel index is never negative: base + 32-bit offset addressing)
     }
     // The four flag bytes side by side, a finished step standing in as "inside" (-> 0): the lowest set bit of the word is the
