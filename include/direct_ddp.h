@@ -151,7 +151,10 @@ typedef struct {
  * (single-trajectory latency: -20 %).  A third choice of the same kind: for batches up to an eighth of the resident waves
  * (row-slot classes of up to 33 planes) the waiting waves also compute the value-independent half of the knots of the
  * trajectory's BACKWARD sweep and hand it over through records in HBM (DIRECT_DDP_BSHARE=0 off, 1 for every batch with a
- * shared line search, 2 the same path forced without helpers - the tests' bitwise check; read at create time). */
+ * shared line search, 2 the same path forced without helpers - the tests' bitwise check; read at create time).  A launch of a
+ * fixed number of iterations with a shared line search also hands out DIRECT_DDP_TAIL (default 8) rounds of help-only
+ * tickets behind its last epoch: waves that would otherwise leave the kernel wait for a trajectory's last chunk and join
+ * its open line searches - the slowest chains end the launch (0: none; bitwise-equality test as for the others). */
 #define DIRECT_FLAG_STATIC_SCHEDULE 1
 
 typedef struct direct_ddp_handle_s* direct_ddp_handle_t;
