@@ -351,6 +351,36 @@ def test_help_only_tickets_behind_the_last_epoch_change_no_bit(built, dt, nb, ki
     assert fixed["0"][0].iter_used.max() == 20
 
 
+def test_help_only_tickets_with_row_slot_classes(built, monkeypatch):
+    """The same with DIRECT_DDP_CLASSES=1 on a batch of two row-slot classes (every other corridor padded to ~40 planes per
+    polytope): each class is a launch of its own over an index list (Batch::idx), side by side on forked streams, with its
+    own ticket counter - help-only tickets index trajectories through that list as well."""
+    base = problems.make_batch("corridor", 400, 30, seed=321)
+    wide = helpers.with_extra_planes(base, 40, seed=5)
+    n_planes = np.where((np.arange(400) % 2 == 0)[:, None], wide.n_planes, base.n_planes)
+    batch = abi.HostBatch(base.n_seg, base.x0, base.xd, base.T0, n_planes, wide.planes, seeds=base.seeds).astype(np.float32)
+    fields = ("rtn", "iter_used", "fwd_passes", "infeas_out", "cost", "costq", "opterr", "mu", "T", "poly", "bez")
+    monkeypatch.setenv("DIRECT_DDP_CLASSES", "1")
+    fixed, nat = {}, {}
+    for mode in ("0", "8"):
+        monkeypatch.setenv("DIRECT_DDP_TAIL", mode)
+        s = solver.DdpSolver(400, 30, 40, np.float32)
+        nat[mode] = s.plan(abi.phase0_params(), abi.phase1_params(iter_max=30), batch)
+        assert s.sched_error() == 0
+        g0 = nat[mode][0]
+        b1 = batch.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, batch.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
+        for _ in range(2):
+            fixed.setdefault(mode, []).append(s.solve(abi.phase1_params(iter_max=20, fixed_iters=1), b1))
+            assert s.sched_error() == 0
+        s.close()
+    for a, b in zip(nat["0"], nat["8"]):
+        for f in fields:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    for g in fixed["8"] + fixed["0"][1:]:
+        for f in fields:
+            assert np.array_equal(getattr(fixed["0"][0], f), getattr(g, f)), f
+
+
 @pytest.mark.parametrize("nb,kind,dt", [(1, "corridor", np.float32), (7, "free", np.float64), (300, "corridor", np.float32)])
 def test_small_batches_on_the_ticket_scheduler_match_the_static_launch(built, nb, kind, dt, monkeypatch):
     """Below the resident waves the launch used to be one workgroup per trajectory; with the shared line search the
