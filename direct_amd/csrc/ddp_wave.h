@@ -381,6 +381,18 @@ struct TrajState {
   int no_upd, fwd_passes, cur, viol;
   int neg_time, nseg, nc0, npos;  // npos: rows with c > 0 in the last evaluation sweep (DDP:255-269)
 };
+// What the gains of a trajectory were formed FROM (one per trajectory, global memory; outside TrajState because the hot
+// kernel's LDS has no 24 bytes to spare at twelve waves per CU).  The reference's forward pass steps slacks and duals with
+// gains stored by the backward pass (DDP:568-572, 611-614 -> 680-703); the kernels regenerate them from the iterate the
+// sweep read (see run_round, phase R) - which is only the CURRENT iterate as long as the sweep completed.  When the retry
+// sequence of DDP:297-310 gives up, knots [0, kreach) still hold the gains of the last sweep that reached them: formed from
+// buffer `buf` with barrier parameter `mu` (Wave::stale_fwd_pass).
+struct GainBase {
+  double mu;   // alg.mu of the last COMPLETED backward sweep
+  int buf;     // the iterate buffer it read; -1: no sweep has completed yet (the reference's gains are still zero, DDP:154-159)
+  int kreach;  // knots [0, kreach) have not been reached by any sweep since then (N right after a completed sweep)
+};
+constexpr int kRtnStuckPending = -40;  // TrajState::rtn between the hot kernel (backward pass stuck, DDP:297-310) and k_stuck
 
 // ---- shared line search (scheduling only, see Wave::fwd_pass) -----------------------------------
 // What one completed line-search trial reports: enough for the filter test and for the state an accepted trial
@@ -457,6 +469,7 @@ struct Batch {
   Real* KY;     // [B][nmax][ncs]
   double* filt; // [B][fcap][2]
   TrajState* st;
+  GainBase* gbase;  // [B]
   HelpSlot* help;  // [B], or null: every line search stays with its owner
   int* sched_err;  // the launch's sticky error flag (spin limits of the shared line search)
   int* live;  // trajectories of the launch still in their outer loop (ticket scheduler; null otherwise): when no more
@@ -1173,6 +1186,18 @@ struct Wave {
     }
     return v;
   }
+  // d val[cr][d] / dT = sum_i Wd[cr][i] T^(i-o-1) C_i[d]: the T column of the constraint Jacobian (DDP:1543-1561, quirk Q1:
+  // Wd holds the MINVO tables whatever basis W holds)
+  DDP_DEV Real ctrl_dval(const Real* zz, const Real* tpw, int cr, int d) const {
+    const int o = ctrl_off(cr);
+    Real v = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      int e = i - o - 1;
+      v += L.WdE[cr * 6 + i] * tpw[e < 0 ? 0 : e] * zz[3 * i + d];
+    }
+    return v;
+  }
   // x+ component a of (F (x) I) x + (G (x) I) u  (DDP:1062-1067)
   DDP_DEV Real next_x(const Real* zz, const Real* tpw, int a) const {
     const int c = a / 3, d = a % 3;
@@ -1487,6 +1512,14 @@ struct Wave {
     st.bp_no_upd = 0;
     st.no_upd = 0;
     st.fwd_passes = 0;
+    LANES {
+      if (lane == 0) {  // no gains yet: bp.ku .. bp.Ky are zero (DDP:154-159)
+        GainBase* g = &B.gbase[b];
+        g->mu = 0.0;
+        g->buf = -1;
+        g->kreach = N;
+      }
+    }
   }
 
   // ---- backward sweep (DDP:440-644).  Returns 1 on success, 0 when the LLT failed. ---------------
@@ -1712,6 +1745,14 @@ struct Wave {
 #endif
 
   DDP_DEV int bwd_sweep() { return bwd_sweep_t<false>(); }
+  // one backwardpass() of the stepwise interface (direct_ddp_backward_pass): with the slack / dual gains ks, ky
+  // (DIRECT_FIELD_KS / KY), which the hot kernels never form, and the GainBase bookkeeping of iterate_once / fwd_pass
+  DDP_DEV int backward_pass_stepwise() {
+    const int ok = bwd_sweep_t<true>();
+    if (ok) note_completed_sweep(st.cur);
+    else note_failed_sweep();
+    return ok;
+  }
 
   // ---- one knot of the backward sweep (see above for MODE) -----------------------------------------------------
   // INF: the mode of the sweep as a compile-time constant (0 feasible, 1 infeasible; -1: read from the context).  The fused
@@ -2658,6 +2699,7 @@ struct Wave {
       st.bp_failed = 1;
       st.opterr = INFINITY;
       count_visits(0, N - kfail);
+      kfail_last = kfail;  // (note_failed_sweep)
       return 0;
     }
     DDP_MARK("B_END");
@@ -3392,6 +3434,37 @@ struct Wave {
       return;
     }
     if (opened) share_close(hs);
+    note_completed_sweep(cur);
+    commit_search(A);
+  }
+
+  // GainBase bookkeeping (see the struct): a sweep that failed leaves knots kfail .. 0 with the gains they had (DDP:548-550
+  // returns before 568-572 / 630-631) ...
+  int kfail_last = 0;
+  DDP_DEV void note_failed_sweep() {
+    LANES {
+      if (lane == 0) {
+        GainBase* g = &B.gbase[b];
+        if (kfail_last + 1 < g->kreach) g->kreach = kfail_last + 1;
+      }
+    }
+  }
+  // ... and a forward pass that runs at all follows a completed sweep (iterate_once parks the trajectory otherwise): every
+  // knot's gains belong to the iterate the trials started from and to the barrier parameter of now - recorded at the end of
+  // fwd_pass, once per iteration and outside the sweeps
+  DDP_DEV void note_completed_sweep(int buf) {
+    LANES {
+      if (lane == 0) {
+        GainBase* g = &B.gbase[b];
+        g->mu = st.mu;
+        g->buf = buf;
+        g->kreach = N;
+      }
+    }
+  }
+
+  // the end of forwardpass() (DDP:760-776)
+  DDP_DEV void commit_search(const Accept& A) {
     if (!A.accepted) {  // DDP:760-762
       st.fp_failed = 1;
       st.stepsize = 0.0;
@@ -3411,6 +3484,204 @@ struct Wave {
       st.fp_failed = 0;
       st.cur = A.buf;
     }
+  }
+
+  // ---- forwardpass() with the gains AS THE REFERENCE'S MEMBERS HOLD THEM (DDP:647-778 after DDP:297-310 gave up) --------
+  // run_round regenerates the slack / dual gains of a knot from the iterate the trial starts from - the iterate every
+  // gain was formed from as long as the last backward sweep completed.  After an aborted retry sequence that is only
+  // true of the knots some sweep of the sequence reached (k >= kreach); knots [0, kreach) still carry bp.ku .. bp.Ky of
+  // the last COMPLETED sweep (DDP:568-572, 611-614, 630-631 are never reached for them), formed from the iterate in
+  // buffer gb.buf with barrier parameter gb.mu - or the zeros of DDP:154-159 when no sweep has ever completed.  With
+  // (s_g, y_g, c_g, A_g = [cx | cu], mu_g) of THAT iterate and du = alpha ku + Ku dx the stored gains give
+  //   feasible    s+ = s - alpha s_g - alpha mu_g / c_g - (s_g / c_g) A_g [dx; du]
+  //   infeasible  y+ = y - alpha (c_g + y_g) - A_g [dx; du],   s+ = s + (alpha rhat_g + s_g A_g [dx; du]) / y_g
+  // while the fraction-to-boundary tests (DDP:684-688, 698-702) compare with the CURRENT s, y, c.  The buffer the gains
+  // were formed from is intact: the trials of a line search never write the buffer they start from, and nothing has
+  // written a buffer since.  One trial at a time, no prefetch, no helpers: this runs at most once per solve (k_stuck,
+  // and the stepwise direct_ddp_forward_pass after a failed direct_ddp_backward_pass).
+  DDP_DEV void stale_fwd_pass() {
+    const int cur = DDP_UNIFORM_I(st.cur), infeas = DDP_UNIFORM_I(st.infeas);
+    const GainBase gb = B.gbase[b];
+    const int gbuf = DDP_UNIFORM_I(gb.buf), kst = DDP_UNIFORM_I(gb.kreach);
+    const double mu_d = st.mu;
+    const double tau_d = fmax(0.99, 1.0 - mu_d);
+    const Real omt = (Real)(1.0 - tau_d), mu_r = (Real)mu_d, gmu_r = (Real)gb.mu;
+    int wb = 0;  // the trial buffer: neither the iterate nor the gains' iterate (nbuf >= 3)
+    while (wb == cur || wb == gbuf) wb++;
+    const int nfilter = DDP_UNIFORM_I(st.nfilter);
+    double* filt = B.filt + (size_t)b * B.fcap * 2;
+    Accept A;
+    A.accepted = 0; A.nkeep = 0; A.step = 0; A.neg = 0; A.buf = cur; A.viol = 0;
+    A.stepsize = 0.0; A.cost = 0.0; A.costq = 0.0; A.logcost = 0.0; A.err = 0.0; A.sumlog = 0.0; A.errsum = 0.0;
+    typename Lds::FwdT& F = L.ft[0];
+    typename Lds::FwdT& Gb = L.ft[1];  // zn, tpn: the knot record of the gains' iterate and the powers of its T
+#pragma unroll 1
+    for (int step = 0; step < 11 && !A.accepted; step++) {  // DDP:666-670
+      double stepsize = 1.0;
+      for (int q = 0; q < step; q++) stepsize *= 0.5;
+      const Real alpha = (Real)stepsize;
+      PLV(LogProd<Real>, plog);
+      PLV(Real, serr);
+      PLV(int, nviol);
+      LANES {
+        LV(plog).init(); LV(serr) = 0; LV(nviol) = 0;
+        if (lane < 9) F.xn[lane] = ldx(Xp(cur, 0), lane);
+      }
+      WSYNC();
+      double qsum = 0.0;
+      int neg = 0, alive = 1, n_visits = 0;
+#pragma unroll 1
+      for (int k = 0; k < N && alive; k++) {
+        const int P = np_(k);
+        const bool nogain = k < kst && gbuf < 0;
+        const int pb = (k < kst && !nogain) ? gbuf : cur;  // the iterate this knot's gains were formed from
+        const Real gmu = k < kst ? gmu_r : mu_r;
+        n_visits++;
+        PLA(Real, sq, RPL);
+        PLA(Real, yq, RPL);
+        PLA(Real, sg, RPL);
+        PLA(Real, yg, RPL);
+        LANES {
+          if (lane < 19) {
+            L.z[lane] = ldx(Xp(cur, k), lane);
+            Gb.zn[lane] = ldx(Xp(pb, k), lane);
+          }
+          for (int e = lane; e < 4 * P; e += 64) L.pl[e] = (Real)planes_(k)[e];
+          for (int e = lane; e < 100; e += 64) L.KUr[e] = nogain ? (Real)0 : (Real)KUp(k)[e];
+          for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
+            const int r = (row_pack(i, lane, P) & kRMask) - 1;
+            const int rc = r >= 0 ? r : 0;
+            LV(sq)[i] = (Real)Sp_(B.S[cur], k)[rc];
+            LV(sg)[i] = (Real)Sp_(B.S[pb], k)[rc];
+            LV(yq)[i] = infeas ? (Real)Sp_(B.Y[cur], k)[rc] : (Real)1;
+            LV(yg)[i] = infeas ? (Real)Sp_(B.Y[pb], k)[rc] : (Real)1;
+          }
+        }
+        WSYNC();
+        LANES {  // dx (DDP:681 / 695)
+          if (lane < 9) {
+            F.dz[lane] = F.xn[lane] - L.z[lane];
+            F.zn[lane] = F.xn[lane];
+          }
+        }
+        WSYNC();
+        LANES {  // du = alpha ku + Ku dx, u+ = u + du (DDP:689 / 696)
+          if (lane < 10) {
+            Real acc = 0;
+            for (int c = 0; c < 9; c++) acc = fma(L.KUr[10 + lane * 9 + c], F.dz[c], acc);
+            const Real du = fma(alpha, L.KUr[lane], acc);
+            F.dz[9 + lane] = du;
+            F.zn[9 + lane] = pair_round(L.z[9 + lane] + du);
+          }
+        }
+        WSYNC();
+        const Real Tq = L.z[18], Tg = Gb.zn[18], Tn = F.zn[18];
+        if (Tn < 0) neg = 1;
+        LANES {
+          if (lane < 8) {
+            L.tp[lane] = powi(Tq, lane);
+            Gb.tpn[lane] = powi(Tg, lane);
+            F.tpn[lane] = powi(Tn, lane);
+          }
+        }
+        WSYNC();
+        LANES {
+          if (lane < 45) {
+            const int cr = lane / 3, d = lane % 3;
+            L.val[lane] = ctrl_val(L.z, L.tp, cr, d);       // c of the current iterate (DDP:663 cold)
+            L.G[lane] = ctrl_val(Gb.zn, Gb.tpn, cr, d);     // c of the gains' iterate
+            F.valn[lane] = ctrl_val(F.zn, F.tpn, cr, d);    // c+ (DDP:696)
+            // A_g [dx; du]: the x and u-bar columns act on [dx; du-bar], the T column (d val / dT at the gains' iterate) on dT
+            F.G[lane] = ctrl_val(F.dz, Gb.tpn, cr, d) + ctrl_dval(Gb.zn, Gb.tpn, cr, d) * F.dz[18];
+          } else if (lane < 54) {
+            F.xnx[lane - 45] = next_x(F.zn, F.tpn, lane - 45);
+          } else if (lane < 63) {
+            F.qp[lane - 54] = jerk_part(F.zn, F.tpn, lane - 54);
+          } else {
+            L.val[45] = Tq;
+            L.G[45] = Tg;
+            F.valn[45] = Tn;
+            F.G[45] = F.dz[18];
+          }
+        }
+        WSYNC();
+        qsum += knot_cost(Tn, F.qp);
+        PLV(int, bad);
+        St* sn = Sp_(B.S[wb], k);
+        St* yn = Sp_(B.Y[wb], k);
+        LANES {
+          LV(bad) = 0;
+          for (int i = 0; i < RPL; i++) {
+            if (!slot_on(i, P)) continue;
+            const RowK<Real> rk = row_slot(i, lane, P);
+            const int r = rk.r;
+            if (r < 0) continue;
+            const Real cq = row_c(L.val, rk), cg = row_c(L.G, rk), cn = row_c(F.valn, rk), az = row_lin(F.G, rk);
+            const Real s = LV(sq)[i], s_g = LV(sg)[i];
+            Real snew = s;
+            if (infeas) {  // DDP:680-687
+              const Real y = LV(yq)[i], y_g = LV(yg)[i];
+              Real ynew = y;
+              if (!nogain) {
+                ynew = (Real)(St)(fma(-alpha, cg + y_g, y) - az);
+                const Real rhat = s_g * (cg + y_g) - (s_g * y_g - gmu);  // DDP:536-537
+                snew = (Real)(St)fma(frcp(y_g), fma(alpha, rhat, s_g * az), s);
+              }
+              LV(bad) |= (int)((ynew < omt * y) | (snew < omt * s));
+              LV(plog).mul(ynew);
+              LV(serr) += fabs(cn + ynew);
+              yn[r] = (St)ynew;
+              sn[r] = (St)snew;
+            } else {  // DDP:694-703
+              if (!nogain) {
+                const Real w1 = frcp(cg);
+                snew = (Real)(St)(fma(-s_g, fma(w1, az, alpha), s) - alpha * gmu * w1);
+              }
+              LV(bad) |= (int)((cn > omt * cq) | (snew < omt * s));
+              LV(plog).mul(-cn);
+              sn[r] = (St)snew;
+            }
+            LV(nviol) += (int)(cn >= (Real)2.0e-4);
+          }
+          LV(plog).norm();
+          if (lane < 19) stx(Xp(wb, k), lane, F.zn[lane]);
+          if (lane < 9) F.xn[lane] = F.xnx[lane];
+        }
+        if (WAVE_ANY(bad)) alive = 0;  // DDP:684-688, 698-702
+        WSYNC();
+      }
+      count_visits(1, n_visits);
+      if (!alive) continue;
+      PLV(Real, slog);
+      LANES {
+        if (lane < 9) {
+          stx(Xp(wb, N), lane, F.xn[lane]);
+          L.z[lane] = F.xn[lane] - (Real)B.xd[(size_t)b * 9 + lane];
+        }
+      }
+      WSYNC();
+      const double pterm = terminal_sq();
+      WSYNC();
+      LANES { LV(slog) = LV(plog).value(); }
+      TrialRes res;
+      res.alive = 1; res.step = step; res.neg = neg; res.stepsize = stepsize; res.qsum = qsum;
+      res.cost = qsum + 0.5 * B.k.w_term * pterm;  // DDP:716-717
+      res.sumlog = WAVE_SUM_D(slog);
+      res.errsum = WAVE_SUM_D(serr);
+      res.viol = WAVE_SUM_I(nviol);
+      consider(res, cur, infeas, mu_d, nfilter, filt, A);
+      A.buf = wb;
+    }
+    commit_search(A);
+  }
+
+  // k_stuck: the last trip of the outer loop of a trajectory whose backward pass got stuck (DDP:311-396; see iterate_once)
+  DDP_DEV void stuck_tail() {
+    st.rtn = 0;
+    st.done = 0;
+    stale_fwd_pass();
+    exit_rules();  // ends the solve: -3, 2, the line-init exit, or -4 (DDP:392-396)
   }
 
   // ---- one trip of the outer loop (DDP:295-412).  Sets st.done when the loop breaks. ------------
@@ -3446,9 +3717,21 @@ struct Wave {
           return;
         }
         if (bwd_sweep()) break;
+        note_failed_sweep();
         if (st.reg == 24 && st.bp_failed) st.bp_no_upd++;
         else st.bp_no_upd = 0;
-        if (st.bp_no_upd > 20) break;
+        if (st.bp_no_upd > 20) {
+          // The backward pass is stuck (DDP:297-310).  The reference still runs forwardpass() - with the gains its members
+          // hold: those of this iterate for the knots some sweep of the retry sequence reached, those of the LAST COMPLETED
+          // sweep (another iterate, another mu) for the others.  That pass does not fit the rounds of fwd_pass (they
+          // regenerate the slack / dual gains from the current iterate alone) and it always ends the solve (DDP:392-396 at
+          // the latest): the trajectory leaves the hot kernel here and k_stuck (stuck_tail) finishes it.
+          // (A return from INSIDE the loop: the same test in front of fwd_pass costs the hot kernel 4 %, wave-uniform or
+          // not - same-box A/B, round 6.)
+          st.rtn = kRtnStuckPending;
+          st.done = 1;
+          return;
+        }
       }
     }
 #if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
@@ -3460,6 +3743,11 @@ struct Wave {
     if (tl_ != nullptr && threadIdx.x == 0) tl_[2] = __builtin_amdgcn_s_memrealtime();
 #endif
     DDP_MARK("X_A");
+    exit_rules();
+  }
+
+  // what follows forwardpass() in one trip of the outer loop (DDP:312-410): bookkeeping and the exit rules
+  DDP_DEV void exit_rules() {
     st.fwd_passes++;
     if (st.neg_time) {  // DDP:317-326
       st.rtn = -3;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
   DDP_MARK("Z_E");
 }
 
-// stepwise interface: mode 1 = one backwardpass(), 2 = one forwardpass()
+// stepwise interface: mode 1 = one backwardpass(), 2 = one forwardpass(), 3 = one forwardpass() through the stored-gain form
 template <typename St, int RPL>
 __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
   __shared__ WaveLds<Cmp, St, RPL> lds;
@@ -228,10 +228,27 @@ __global__ __launch_bounds__(64) void k_pass(Batch<St> B, int mode) {
   if (__builtin_amdgcn_readfirstlane(lds.st.done)) return;
   W.init_tables();
   if (mode == 1) {
-    W.template bwd_sweep_t<true>();  // with the slack / dual gains ks, ky (DIRECT_FIELD_KS / KY): the hot kernels never form them
+    W.backward_pass_stepwise();
+  } else if (mode == 3 || __builtin_amdgcn_readfirstlane(lds.st.bp_failed)) {
+    // after a backwardpass() that gave up the reference's forwardpass() runs with the gains its members still hold
+    W.stale_fwd_pass();
   } else {
     W.fwd_pass();
   }
+  W.store_state();
+}
+
+// The last trip of the outer loop of the trajectories whose backward pass got stuck in the hot kernel (ddp_optimizer.cpp:297-311,
+// 392-396; Wave::iterate_once leaves them with rtn = kRtnStuckPending): launched behind every hot-kernel launch, returns at
+// once for every other trajectory.
+template <typename St, int RPL>
+__global__ __launch_bounds__(64) void k_stuck(Batch<St> B) {
+  __shared__ WaveLds<Cmp, St, RPL> lds;
+  Wave<Cmp, St, RPL> W(B, lds, traj_of(B, blockIdx.x));
+  W.load_state();
+  if (__builtin_amdgcn_readfirstlane(lds.st.rtn) != kRtnStuckPending) return;
+  W.init_tables();
+  W.stuck_tail();
   W.store_state();
 }
 
@@ -402,6 +419,7 @@ struct direct_ddp_handle_s {
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
   double* filt = nullptr;
   TrajState* st = nullptr;
+  GainBase* gbase = nullptr;   // [max_batch] what each trajectory's gains were formed from (Wave::stale_fwd_pass)
   void* fieldbuf = nullptr;
   size_t fieldbuf_bytes = 0;
   // staged outputs (when the caller's buffers are host memory)
@@ -479,6 +497,7 @@ static Batch<Real> make_batch(direct_ddp_handle_t h, const direct_ddp_batch_in_t
   B.visits = nullptr;  // set by launch_iterate_t (the hot-kernel launch only)
   B.live = nullptr;    // set by the ticket-scheduled launch with a shared line search
   B.KU = (Real*)h->KU; B.KS = (Real*)h->KS; B.KY = (Real*)h->KY; B.filt = h->filt; B.st = h->st;
+  B.gbase = h->gbase;
   SolveConst& k = B.k;
   k.max_vel = p.max_vel; k.max_acc = p.max_acc; k.w_snap = p.w_snap; k.w_term = p.w_terminal;
   k.w_time = p.w_time;
@@ -695,6 +714,12 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       if (is_big && li.shared_sweep) li.shared_sweep = 0;
       RPL_LAUNCH(c.rpl, st, k_iterate, Real, c.cnt, Bt, n);
     }
+    static const bool no_stuck = getenv("DIRECT_DDP_NO_STUCK") != nullptr;  // timing probes only: rtn = -4 solves stay parked
+    if (!no_stuck) {  // trajectories whose backward pass got stuck finish their last trip here (rare; every other workgroup returns at once)
+      auto Bs = make_batch<Real>(h, h->cur_in, h->params, c);
+      Bs.visits = h->visits;
+      RPL_LAUNCH(c.rpl, st, k_stuck, Real, c.cnt, Bs);
+    }
     if (forked && st != h->stream) {
       (void)hipEventRecord(h->cev[ci], st);
       (void)hipStreamWaitEvent(h->stream, h->cev[ci], 0);
@@ -909,6 +934,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   }
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
   A(&h->st, B * sizeof(TrajState));
+  A(&h->gbase, B * sizeof(GainBase));
   if (!packed) {
     A(&h->o.rtn, B * 4); A(&h->o.iter_used, B * 4); A(&h->o.fwd_passes, B * 4);
     A(&h->o.infeas_out, B); A(&h->o.line_failed_out, B);
@@ -1210,6 +1236,10 @@ direct_status_t direct_ddp_backward_pass(direct_ddp_handle_t h) {
 direct_status_t direct_ddp_forward_pass(direct_ddp_handle_t h) {
   if (!h) return fail(DIRECT_ERR_INVALID, "null handle");
   return launch_iterate(h, 1, 2);
+}
+direct_status_t direct_ddp_forward_pass_stored(direct_ddp_handle_t h) {
+  if (!h) return fail(DIRECT_ERR_INVALID, "null handle");
+  return launch_iterate(h, 1, 3);
 }
 direct_status_t direct_ddp_iterate(direct_ddp_handle_t h, int32_t n_iters) {
   if (!h) return fail(DIRECT_ERR_INVALID, "null handle");

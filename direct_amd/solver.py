@@ -21,7 +21,7 @@ _LIB = None
 EXPORTS = (
     "direct_ddp_abi_version", "direct_ddp_last_error", "direct_ddp_create", "direct_ddp_destroy",
     "direct_ddp_set_stream", "direct_ddp_solve_batch", "direct_ddp_plan_batch", "direct_time_allocation",
-    "direct_ddp_begin", "direct_ddp_backward_pass", "direct_ddp_forward_pass", "direct_ddp_iterate",
+    "direct_ddp_begin", "direct_ddp_backward_pass", "direct_ddp_forward_pass", "direct_ddp_forward_pass_stored", "direct_ddp_iterate",
     "direct_ddp_finish", "direct_ddp_get_field", "direct_ddp_set_field", "direct_ddp_last_kernel_ms",
     "direct_ddp_best_cost", "direct_ddp_sched_error", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
     "direct_rccl_unique_id", "direct_rccl_comm_create", "direct_rccl_comm_destroy", "direct_ddp_gather_best",
@@ -55,6 +55,8 @@ def lib():
         L.direct_ddp_begin.argtypes = [C.c_void_p] * 3
         L.direct_ddp_backward_pass.argtypes = [C.c_void_p]
         L.direct_ddp_forward_pass.argtypes = [C.c_void_p]
+        if hasattr(L, "direct_ddp_forward_pass_stored"):  # absent from libraries of earlier rounds (tools/ab_libs.sh A/B runs)
+            L.direct_ddp_forward_pass_stored.argtypes = [C.c_void_p]
         L.direct_ddp_iterate.argtypes = [C.c_void_p, C.c_int32]
         L.direct_ddp_finish.argtypes = [C.c_void_p, C.c_void_p]
         L.direct_ddp_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -160,6 +162,10 @@ class DdpSolver:
 
     def forward(self):
         _check(lib().direct_ddp_forward_pass(self.h))
+
+    def forward_stored(self):
+        """forwardpass() in the stored-gain form (what the solver runs after its backward pass got stuck, rtn = -4)"""
+        _check(lib().direct_ddp_forward_pass_stored(self.h))
 
     def iterate(self, n):
         _check(lib().direct_ddp_iterate(self.h, int(n)))

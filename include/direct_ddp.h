@@ -281,8 +281,14 @@ direct_status_t direct_ddp_begin(direct_ddp_handle_t h, const direct_ddp_params_
                                  const direct_ddp_batch_in_t* in);
 /* one backwardpass() (ddp_optimizer.cpp:440-644), no retry loop */
 direct_status_t direct_ddp_backward_pass(direct_ddp_handle_t h);
-/* one forwardpass() (ddp_optimizer.cpp:647-778) */
+/* one forwardpass() (ddp_optimizer.cpp:647-778).  After a direct_ddp_backward_pass that failed (LLT, ddp_optimizer.cpp:546-551,
+ * 595-600) it runs as the reference's does: with the gains the knots below the failure still hold from the last
+ * completed backward pass (ddp_optimizer.cpp:568-572, 611-614, 630-631 were not reached for them). */
 direct_status_t direct_ddp_forward_pass(direct_ddp_handle_t h);
+/* The same forwardpass() evaluated in the stored-gain form whatever the state of the backward pass (the form the solver
+ * itself only uses after ddp_optimizer.cpp:297-310 gave up, rtn = -4): with every gain current it must agree with
+ * direct_ddp_forward_pass to rounding - a test hook, no reference counterpart of its own. */
+direct_status_t direct_ddp_forward_pass_stored(direct_ddp_handle_t h);
 /* n trips of the outer loop (ddp_optimizer.cpp:295-412) for every unfinished problem */
 direct_status_t direct_ddp_iterate(direct_ddp_handle_t h, int32_t n_iters);
 /* finalroll + conversions (ddp_optimizer.cpp:414-437) */

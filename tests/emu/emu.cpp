@@ -25,6 +25,7 @@ struct Emu {
   std::vector<uint8_t> infeas_in;
   std::vector<double> filt;
   std::vector<TrajState> st;
+  std::vector<GainBase> gbase;
   // forced split of the backward sweep (DIRECT_EMU_BSPLIT=1): front halves through hand-over records, as helper waves would
   std::vector<BwdShare> bshare;
   std::vector<int> bflag;
@@ -94,6 +95,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   E->KU.assign((size_t)B * nm * 100, 0); E->KS.assign(ns, 0); E->KY.assign(ns, 0);
   E->filt.assign((size_t)B * Bt.fcap * 2, 0.0);
   E->st.assign(B, TrajState());
+  E->gbase.assign(B, GainBase());
   Bt.n_seg = E->n_seg.data(); Bt.x0 = E->x0.data(); Bt.xd = E->xd.data(); Bt.T0 = E->T0.data();
   Bt.n_planes = E->n_planes.data(); Bt.planes = E->planes.data();
   Bt.init_bez = in->init_bez ? E->init_bez.data() : nullptr;
@@ -104,6 +106,7 @@ static Emu<Real>* emu_begin_t(const direct_ddp_params_t* p, const direct_ddp_bat
   Bt.S[0] = E->S0.data(); Bt.S[1] = E->S1.data(); Bt.S[2] = E->S2.data();
   Bt.Y[0] = E->Y0.data(); Bt.Y[1] = E->Y1.data(); Bt.Y[2] = E->Y2.data(); Bt.KU = E->KU.data(); Bt.KS = E->KS.data();
   Bt.KY = E->KY.data(); Bt.filt = E->filt.data(); Bt.st = E->st.data();
+  Bt.gbase = E->gbase.data();
   Bt.nbuf = 3; Bt.help = nullptr; Bt.sched_err = nullptr; Bt.visits = nullptr;
   if (getenv("DIRECT_EMU_BSPLIT") && atoi(getenv("DIRECT_EMU_BSPLIT")) != 0) {
     E->bshare.assign(B, BwdShare());
@@ -171,9 +174,22 @@ void* emu_begin(int dtype, const direct_ddp_params_t* p, const direct_ddp_batch_
   if (h->dtype == DIRECT_F64) { auto& E = *(Emu<double>*)h->p; typedef double Real; (void)sizeof(Real); body; } \
   else { auto& E = *(Emu<float>*)h->p; typedef float Real; (void)sizeof(Real); body; }
 
-void emu_backward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.template bwd_sweep_t<true>(); })) }
-void emu_forward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.fwd_pass(); })) }
-void emu_iterate(void* hv, int n) { EMU_CALL(with_state(E, [n](auto& W) { W.iterate(n); })) }
+void emu_backward(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.backward_pass_stepwise(); })) }
+// (as k_pass / k_stuck of direct_ddp.hip do)
+void emu_forward(void* hv) {
+  EMU_CALL(with_state(E, [](auto& W) {
+    if (W.st.done) return;
+    if (W.st.bp_failed) W.stale_fwd_pass();
+    else W.fwd_pass();
+  }))
+}
+void emu_forward_stored(void* hv) { EMU_CALL(with_state(E, [](auto& W) { if (!W.st.done) W.stale_fwd_pass(); })) }
+void emu_iterate(void* hv, int n) {
+  EMU_CALL(with_state(E, [n](auto& W) {
+    W.iterate(n);
+    if (W.st.rtn == kRtnStuckPending) W.stuck_tail();
+  }))
+}
 void emu_get_field(void* hv, int field, void* dst) {
   EMU_CALL(with_state(E, [&](auto& W) { get_field_wave(W, field, (Real*)dst); }))
 }

@@ -29,7 +29,7 @@ def lib():
         L = C.CDLL(build())
         L.emu_begin.restype = C.c_void_p
         L.emu_begin.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
-        for n in ("emu_backward", "emu_forward", "emu_end"):
+        for n in ("emu_backward", "emu_forward", "emu_forward_stored", "emu_end"):
             getattr(L, n).argtypes = [C.c_void_p]
             getattr(L, n).restype = None
         L.emu_iterate.argtypes = [C.c_void_p, C.c_int]
@@ -64,6 +64,9 @@ class EmuSolver:
 
     def forward(self):
         lib().emu_forward(self.h)
+
+    def forward_stored(self):
+        lib().emu_forward_stored(self.h)
 
     def iterate(self, n):
         lib().emu_iterate(self.h, n)

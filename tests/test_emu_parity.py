@@ -7,7 +7,7 @@ import pytest
 
 from direct_amd import abi, problems
 from oracle import refapi
-from tests import helpers
+from tests import helpers, stuck_lib
 from tests.emu import emuapi
 
 
@@ -171,9 +171,9 @@ def test_emulated_begin_rejects_bad_sizes_row_by_row():
 
 
 def test_backward_pass_stuck_exit_matches_oracle():
-    """rtn = -4 (DDP:392-396): the backward pass fails 21 times at the largest regulariser and the reference still
-    runs its forward pass.  In feasible mode the kernels then rebuild the per-row values the forward trials read
-    (Wave::refresh_row_cache) instead of trusting a sweep that never completed."""
+    """rtn = -4 (DDP:392-396) in the FIRST iteration of feasible-mode solves from an infeasible start: the backward pass
+    fails 21 times at the largest regulariser and the reference still runs its forward pass - with the zero gains of
+    DDP:154-159 for the knots no sweep reached (Wave::stale_fwd_pass, the `nogain` rows)."""
     b = problems.make_batch("corridor", 32, 8, seed=1)
     bb = b.with_init(np.zeros((32, 8, 18)), T0=b.T0 * 3.0, infeas_in=np.zeros(32, np.uint8))
     p = abi.phase1_params(iter_max=60)
@@ -183,6 +183,53 @@ def test_backward_pass_stuck_exit_matches_oracle():
     assert (e.rtn == r.rtn).all() and (e.iter_used == r.iter_used).all() and (e.fwd_passes == r.fwd_passes).all()
     ok = np.isfinite(r.cost)
     assert np.abs(e.cost[ok] / r.cost[ok] - 1).max() < 1e-8
+
+
+@pytest.mark.parametrize("scenario", range(len(stuck_lib.scenarios())))
+def test_forward_pass_after_a_stuck_backward_pass_uses_the_stored_gains(scenario):
+    """The reference's forwardpass() after DDP:297-310 gave up runs with the gains its members hold: knots the retry
+    sequence never reached keep those of the last COMPLETED sweep - another iterate, another barrier parameter
+    (DDP:568-572, 611-614, 630-631 -> 680-703).  Forced a few iterations into well-conditioned solves (tests/stuck_lib.py),
+    both storage types: every decision of the last trip and the iterate it leaves."""
+    name, p, kind, K, y_inject, zero_bez = stuck_lib.scenarios()[scenario]
+    batch = problems.make_batch(kind, 8, 10, seed=77)
+    if zero_bez:
+        batch = batch.with_init(np.zeros((8, 10, 18)))
+    sc = stuck_lib.Scenario(p, batch, K, y_inject)
+    if name == "phase0":
+        assert sc.accepted().sum() >= 3   # the stale pass really moves the iterate
+    if name.startswith("infeas_w100"):
+        assert sc.barrier_moved().sum() >= 1   # the stale gains were formed with another barrier parameter
+    for dtype, c64, tol in ((np.float64, False, 1e-9), (np.float32, True, 1e-3)):
+        e = emuapi.EmuSolver(p, batch, dtype, c64)
+        sc.check(sc.run(e), tol)
+        e.close()
+    sc.close()
+
+
+@pytest.mark.parametrize("params", [abi.phase0_params(), abi.phase1_params()], ids=["infeasible", "feasible"])
+def test_stored_gain_forward_pass_equals_the_regular_one_when_every_gain_is_current(params):
+    """With a completed backward sweep every gain belongs to the current iterate, and the stored-gain form of the forward
+    pass (Wave::stale_fwd_pass: s+, y+ from the iterate the gains were formed from) must reproduce the regular pass
+    (run_round: the same iterate by construction) - both modes of DDP:678-706."""
+    g, batch = helpers.load_case("corridor_n8")
+    b = batch if params.zero_init else helpers.phase1_batch(g, batch)
+    for warm in (0, 2):
+        a, c = emuapi.EmuSolver(params, b), emuapi.EmuSolver(params, b)
+        for s in (a, c):
+            s.iterate(warm)
+            s.backward()
+        a.forward()
+        c.forward_stored()
+        sa, sc_ = a.scalars(), c.scalars()
+        for n in ("step", "fp_failed", "filter_n"):
+            assert (sa[n] == sc_[n]).all(), n
+        assert (sa["fp_failed"] == 0).all()
+        assert np.abs(sa["cost"] / sc_["cost"] - 1).max() < 1e-12 and np.abs(sa["logcost"] / sc_["logcost"] - 1).max() < 1e-12
+        for f in (abi.FIELD_X, abi.FIELD_U, abi.FIELD_S) + ((abi.FIELD_Y,) if params.infeas else ()):
+            assert helpers.rel(a.get(f), c.get(f)) < 1e-11, f
+        a.close()
+        c.close()
 
 
 @pytest.mark.parametrize("name", ["corridor_n8", "free_n5"] if "free_n5" in helpers.CASES else list(helpers.CASES)[:2])

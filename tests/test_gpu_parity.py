@@ -9,7 +9,7 @@ import pytest
 
 from direct_amd import abi, problems, solver
 from oracle import refapi
-from tests import helpers
+from tests import helpers, stuck_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -387,3 +387,83 @@ def test_forward_pass_after_a_backward_pass_that_failed_part_way(built, dtype, t
         assert max(helpers.rel(s.get(f)[i], r[i].get(f)) for i in range(3)) < tol, f
     assert max(helpers.rel(s.get(abi.FIELD_S)[i][:, :ncm], r[i].get(abi.FIELD_S)) for i in range(3)) < 20 * tol
     s.close()
+
+
+@pytest.mark.parametrize("scenario", range(len(stuck_lib.scenarios())))
+def test_forward_pass_after_a_stuck_backward_pass_uses_the_stored_gains(built, scenario):
+    """rtn = -4 with the reference's own last forward pass (DDP:297-311 -> 647-778 -> 392-396): the knots the retry sequence
+    never reached keep the gains of the last COMPLETED sweep (another iterate, another barrier parameter), the hot kernel
+    parks the trajectory and k_stuck / Wave::stale_fwd_pass finishes it.  Forced a few iterations into well-conditioned
+    solves (tests/stuck_lib.py) through the C-ABI's stepwise calls, both storage types: every decision of the last
+    trip and the iterate it leaves; the round-5 kernels left the oracle by 3 - 8 % in cost on the problems that accept a
+    step.  The twin of tests/test_emu_parity.py's test of the same name."""
+    name, p, kind, K, y_inject, zero_bez = stuck_lib.scenarios()[scenario]
+    batch = problems.make_batch(kind, 8, 10, seed=77)
+    if zero_bez:
+        batch = batch.with_init(np.zeros((8, 10, 18)))
+    sc = stuck_lib.Scenario(p, batch, K, y_inject)
+    if name == "phase0":
+        assert sc.accepted().sum() >= 3
+    for dtype, tol in ((np.float64, 1e-9), (np.float32, 1e-3)):
+        s = make_solver(batch, dtype)
+        s.begin(p, batch)
+        out = sc.run(s)
+        sc.check(out, tol)
+        # ... and what the caller sees: the getters after finish (cost 1e-8, control points 1e-6 for double storage)
+        res = s.finish()
+        assert (res.rtn == -4).all() and (res.iter_used == K).all() and (res.fwd_passes == K + 1).all()
+        u = sc.usable
+        ctol, btol = (1e-8, 1e-6) if dtype == np.float64 else (1e-3, 1e-2)
+        assert np.abs(res.cost[u] / np.array([q["cost"] for q in sc.sc])[u] - 1).max() < ctol
+        for i in np.where(u)[0]:
+            U = sc.oracle[i].get(abi.FIELD_U)
+            assert helpers.rel(res.T[i], U[:, 9]) < btol and helpers.rel(res.poly[i][:, 9:], U[:, :9]) < btol
+        s.close()
+    sc.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_backward_pass_stuck_in_the_first_iteration(built, dtype):
+    """rtn = -4 at iteration 0 of feasible-mode solves from an infeasible start (natural, no forcing): no sweep ever
+    completed, the stale gains are the zeros of DDP:154-159, every trial dies at the fraction-to-boundary rule and the
+    iterate is the initial roll.  Whole solves against the oracle: return codes, iteration counts, cost, control points."""
+    b = problems.make_batch("corridor", 32, 8, seed=1)
+    bb = b.with_init(np.zeros((32, 8, 18)), T0=b.T0 * 3.0, infeas_in=np.zeros(32, np.uint8)).astype(dtype).astype(np.float64)
+    p = abi.phase1_params(iter_max=60)
+    r, _ = refapi.solve_batch(p, bb)
+    stuck = r.rtn == -4
+    assert stuck.sum() >= 1
+    s = make_solver(bb, dtype)
+    g = s.solve(p, bb)
+    s.close()
+    assert (g.rtn[stuck] == -4).all() and (g.iter_used[stuck] == r.iter_used[stuck]).all() and (g.fwd_passes[stuck] == r.fwd_passes[stuck]).all()
+    tol = 1e-8 if dtype == np.float64 else 1e-5
+    assert np.abs(g.cost[stuck] / r.cost[stuck] - 1).max() < tol
+    assert helpers.rel(g.bez[stuck], r.bez[stuck]) < 100 * tol and helpers.rel(g.T[stuck], r.T[stuck]) < 100 * tol
+
+
+@pytest.mark.parametrize("mode", ["infeasible", "feasible"])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 1e-5)])
+def test_stored_gain_forward_pass_equals_the_regular_one_when_every_gain_is_current(built, mode, dtype, tol):
+    """direct_ddp_forward_pass_stored after a COMPLETED backward pass: every gain belongs to the current iterate, the
+    stored-gain form (Wave::stale_fwd_pass) must reproduce the regular forward pass (run_round) - both modes."""
+    g, batch = helpers.load_case("corridor_n8")
+    params = abi.phase0_params() if mode == "infeasible" else abi.phase1_params()
+    b = batch if params.zero_init else helpers.phase1_batch(g, batch)
+    for warm in (0, 2):
+        a, c = make_solver(b, dtype), make_solver(b, dtype)
+        for s in (a, c):
+            s.begin(params, b)
+            s.iterate(warm)
+            s.backward()
+        a.forward()
+        c.forward_stored()
+        sa, sc_ = a.scalars(), c.scalars()
+        for n in ("step", "fp_failed", "filter_n"):
+            assert (sa[n] == sc_[n]).all(), n
+        assert (sa["fp_failed"] == 0).all()
+        assert np.abs(sa["cost"] / sc_["cost"] - 1).max() < max(tol, 1e-7 * (dtype == np.float32))
+        for f in (abi.FIELD_X, abi.FIELD_U, abi.FIELD_S) + ((abi.FIELD_Y,) if params.infeas else ()):
+            assert helpers.rel(a.get(f), c.get(f)) < tol, f
+        a.close()
+        c.close()
