@@ -425,11 +425,18 @@ constexpr int kMaxBuf = 12;  // iterate buffers: `cur` + one per concurrently ev
 // own, from knot 0 upwards, into hand-over records in HBM, while the owner sweeps down from knot N - 1; where the two
 // meet the owner goes on with the value-dependent rest ("back") alone.
 struct BwdShare {
-  unsigned word;             // (tag << 8) | helpers inside the protocol; tag 0: no sweep open.  Only ever changed by atomic RMWs
+  unsigned word;             // (tag << kBsCountBits) | helpers inside the protocol; tag 0: no sweep open.  Only ever changed by atomic RMWs
   int cur, infeas, seq;      // the sweep's iterate buffer and mode; seq: sweeps opened so far (owner only: the tag source)
   double mu;
   unsigned long long claim;  // free knots [low, high): low in bits 0..31 (helpers take from below), high + 2^30 in bits 32..63 (the owner from above)
 };
+// The count field holds every wave that can be resident at once (13 bits: 8191; a device holds 4096 waves of 64 lanes at
+// most), so entrants that are about to back out can never carry into the tag - and only kBsMaxHelpers are let in at all: a
+// sweep of N knots has N / kHelpChunk claims to hand out, while with few trajectories on many waves EVERY waiting wave polls
+// the one open sweep (iter_max of a few hundred at B = 1 used to overflow an 8-bit count: ADVICE r05).
+constexpr int kBsCountBits = 13;
+constexpr unsigned kBsCountMask = (1u << kBsCountBits) - 1u, kBsTagMask = (1u << (32 - kBsCountBits)) - 1u;
+constexpr int kBsMaxHelpers = 64;
 constexpr int kRecDoubles = 384;  // one knot's hand-over record: six doubles per lane, stored as three 16-byte halves per lane
 #ifndef DDP_OWN_CHUNK
 #define DDP_OWN_CHUNK 2
@@ -1563,8 +1570,8 @@ struct Wave {
   static constexpr bool kSplit = DDP_KSPLIT;  // the helper-assisted sweep is built for the narrow classes only (long trajectories: N >= 80)
 
   // -- the share protocol (wave-uniform; lane 0 performs the atomics).  Every transition of BwdShare::word is an atomic
-  // RMW, so owner and helpers need no fences between them: open = add (tag << 8), enter = add 1 and look at the old tag,
-  // close = and 0xff and look at the old count.  Records and flags are written through (sc1) and drained (vmcnt(0))
+  // RMW, so owner and helpers need no fences between them: open = add (tag << kBsCountBits), enter = add 1 and look at the
+  // old tag (and back out when kBsMaxHelpers are inside already), close = and kBsCountMask and look at the old count.  Records and flags are written through (sc1) and drained (vmcnt(0))
   // before the flag, and read with sc1 loads issued only after the flag has been seen (MI355X_MICROARCH.md, hand-off forms).
   DDP_DEV BwdShare* bshare_slot() const { return (kSplit && B.bshare && B.self) ? &B.bshare[b] : nullptr; }
   DDP_DEV double* rec_ptr(int k) const { return B.brec + ((size_t)(unsigned)DDP_UNIFORM_I(b * B.nmax + k)) * kRecDoubles; }
@@ -1625,34 +1632,35 @@ struct Wave {
       __hip_atomic_store((unsigned long long*)&bs->mu, (unsigned long long)__double_as_longlong(mu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&bs->claim, ((kClaimBias + (unsigned long long)kfloor) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    seq = __builtin_amdgcn_readfirstlane(seq) & 0xffffff;
+    seq = __builtin_amdgcn_readfirstlane(seq) & (int)kBsTagMask;
     if (seq == 0) seq = 1;
     drain_stores();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&bs->word, (unsigned)seq << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&bs->word, (unsigned)seq << kBsCountBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return seq;
   }
   // owner: close it and wait until no helper is inside (they finish the chunk they hold; nothing of theirs is awaited)
   DDP_DEV void bs_close(BwdShare* bs) {
     unsigned o = 0;
-    if (threadIdx.x == 0) o = __hip_atomic_fetch_and(&bs->word, 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int inside = __builtin_amdgcn_readfirstlane((int)(o & 0xffu));
+    if (threadIdx.x == 0) o = __hip_atomic_fetch_and(&bs->word, kBsCountMask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int inside = __builtin_amdgcn_readfirstlane((int)(o & kBsCountMask));
     int spins = 0;
     while (inside) {
       __builtin_amdgcn_s_sleep(2);
-      inside = a_load((int*)&bs->word) & 0xff;
+      inside = a_load((int*)&bs->word) & (int)kBsCountMask;
       if (++spins > (1 << 22)) {
         proto_error();
         break;
       }
     }
   }
-  DDP_DEV int bs_tag(BwdShare* bs) const { return (int)((unsigned)a_load((int*)&bs->word) >> 8); }
+  DDP_DEV int bs_tag(BwdShare* bs) const { return (int)((unsigned)a_load((int*)&bs->word) >> kBsCountBits); }
   // helper: join the open sweep of trajectory b, if there is one
   DDP_DEV int bs_enter(BwdShare* bs, int& tag, int& cur, int& infeas, double& mu) {
     unsigned o = 0;
     if (threadIdx.x == 0) o = __hip_atomic_fetch_add(&bs->word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tag = __builtin_amdgcn_readfirstlane((int)(o >> 8));
-    if (!tag) {
+    tag = __builtin_amdgcn_readfirstlane((int)(o >> kBsCountBits));
+    if (!tag || __builtin_amdgcn_readfirstlane((int)(o & kBsCountMask)) >= kBsMaxHelpers) {  // closed, or full
+      tag = 0;
       if (threadIdx.x == 0) __hip_atomic_fetch_add(&bs->word, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return 0;
     }
@@ -1718,11 +1726,11 @@ struct Wave {
     bs->infeas = infeas;
     bs->mu = mu;
     bs->claim = (kClaimBias + (unsigned long long)kfloor) << 32;
-    bs->word += (unsigned)bs->seq << 8;
+    bs->word += (unsigned)bs->seq << kBsCountBits;
     return bs->seq;
   }
-  DDP_DEV void bs_close(BwdShare* bs) { bs->word &= 0xffu; }
-  DDP_DEV int bs_tag(BwdShare* bs) const { return (int)(bs->word >> 8); }
+  DDP_DEV void bs_close(BwdShare* bs) { bs->word &= kBsCountMask; }
+  DDP_DEV int bs_tag(BwdShare* bs) const { return (int)(bs->word >> kBsCountBits); }
   DDP_DEV int bs_enter(BwdShare*, int&, int&, int&, double&) { return 0; }
   DDP_DEV void bs_leave(BwdShare*) {}
   DDP_DEV void bs_claim_low(BwdShare* bs, int& k0, int& k1) {

@@ -134,7 +134,8 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
       if (sweeps) {  // the predecessor's backward sweep is open and has knots nobody has claimed yet
         const unsigned w = __hip_atomic_load(&sweeps[b].word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long c = __hip_atomic_load(&sweeps[b].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sw = ((w >> 8) != 0 && (long long)(c & 0xffffffffull) < (long long)(c >> 32) - (long long)kClaimBias) ? 1 : 0;
+        sw = ((w >> kBsCountBits) != 0 && (int)(w & kBsCountMask) < kBsMaxHelpers &&
+              (long long)(c & 0xffffffffull) < (long long)(c >> 32) - (long long)kClaimBias) ? 1 : 0;
       }
     }
     have = __builtin_amdgcn_readfirstlane(hv);

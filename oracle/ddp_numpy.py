@@ -121,8 +121,10 @@ class DDP:
             self.c.append(np.zeros(nc))
             self.s.append(0.1 * np.ones(nc))
             self.y.append(0.01 * np.ones(nc))
-        self.ku = [None] * N; self.Ku = [None] * N; self.ks = [None] * N
-        self.Ks = [None] * N; self.ky = [None] * N; self.Ky = [None] * N
+        # DDP:154-159: the gains start as zeros (what a forwardpass() after a stuck first backwardpass() steps with)
+        self.ku = [np.zeros(10) for _ in range(N)]; self.Ku = [np.zeros((10, 9)) for _ in range(N)]
+        self.ks = [np.zeros(ci.size) for ci in self.c]; self.Ks = [np.zeros((ci.size, 9)) for ci in self.c]
+        self.ky = [np.zeros(ci.size) for ci in self.c]; self.Ky = [np.zeros((ci.size, 9)) for ci in self.c]
         self.PolyTime = np.array(durations, float)
         if not zero_init:
             if not line_init:
@@ -507,8 +509,10 @@ class DDP:
 
     # ---- outer loop ----------------------------------------------------------------------
     def iterate_once(self):  # DDP:295-412 body; True when the loop breaks
+        n_sweeps = 0
         while True:
             self.backwardpass()
+            n_sweeps += 1
             if not self.bp_failed:
                 break
             if self.reg == 24 and self.bp_failed:
@@ -520,7 +524,7 @@ class DDP:
         self.forwardpass()
         self.fwd_passes += 1
         self.trace.append((self.cost, self.costq, self.logcost, self.err, self.mu, self.reg, self.step,
-                           self.opterr, self.stepsize, float(self.fp_failed)))
+                           self.opterr, self.stepsize, float(self.fp_failed), float(n_sweeps), float(self.bp_failed)))
         if any(u[9] < 0 for u in self.u):
             self.rtn = -3
             return True
@@ -581,6 +585,20 @@ class DDP:
                     costq=self.costq, jerk_cost=jerk, terminal_norm2=float(d @ d), opterr=self.opterr,
                     mu=self.mu, bez=bez, poly=poly, T=T, infeas_out=self.infeas_ref,
                     line_failed_out=self.line_failed)
+
+
+def make_problem(batch, b, params):
+    """The solver object of one problem of an abi.HostBatch, set up (DDP:5-286) but not run: for stepping."""
+    N = int(batch.n_seg[b])
+    planes = [batch.planes[b, k, :batch.n_planes[b, k]] for k in range(N)]
+    pos = np.stack([batch.x0[b, :3], batch.xd[b, :3]])
+    vel = np.stack([batch.x0[b, 3:6], batch.xd[b, 3:6]])
+    acc = np.stack([batch.x0[b, 6:9], batch.xd[b, 6:9]])
+    infeas = batch.infeas_in[b] if batch.infeas_in is not None else params.infeas
+    return DDP(planes, batch.T0[b, :N], pos, vel, acc, params.max_vel, params.max_acc,
+               None if batch.init_bez is None else batch.init_bez[b, :N], params.w_snap, params.w_terminal,
+               params.w_time, params.iter_max, infeas, params.zero_init, params.line_init, params.time_power,
+               params.minvo, None if batch.seeds is None else batch.seeds[b], bool(params.fixed_iters))
 
 
 def solve_problem(batch, b, params):

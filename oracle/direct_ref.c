@@ -120,12 +120,12 @@ typedef struct {
   double prev_cost, prev_costq;
   /* scratch for forwardpass / backwardpass */
   double *xn, *un, *cn, *sn, *yn, *qn, *bw_scratch;
-  /* optional per-iteration trace: cost, costq, logcost, err, mu, reg, step, opterr, stepsize, fp_failed */
+  /* optional per-iteration trace: cost, costq, logcost, err, mu, reg, step, opterr, stepsize, fp_failed, n_sweeps, bp_failed */
   double* trace;
   int trace_cap;
 } ref_t;
 
-#define TRACE_W 10
+#define TRACE_W 12
 
 /* ---- small dense helpers (row-major) ---------------------------------------------------- */
 static void mat_zero(double* a, int n) { memset(a, 0, sizeof(double) * (size_t)n); }
@@ -1095,6 +1095,9 @@ static ref_t* ref_begin(const ref_problem_t* pb, const direct_ddp_params_t* pr, 
     if (!pr->line_init && pb->init_poly) { /* C-ABI extension: monomial warm start (no reference counterpart) */
       for (int i = 0; i < N; i++)
         for (int a = 0; a < 9; a++) r->u[(size_t)i * 10 + a] = pb->init_poly[(size_t)i * 18 + 9 + a];
+    } else if (!pr->line_init && !pb->init_bez) {
+      /* no warm start handed over: the controls stay zero, as direct_ddp_batch_in_t defines it (the reference's caller
+       * always passes initbezCoeff, TRP:918-921) */
     } else if (!pr->line_init) {
       for (int i = 0; i < N; i++) {
         double il[18], poly[18];
@@ -1174,8 +1177,10 @@ static ref_t* ref_begin(const ref_problem_t* pb, const direct_ddp_params_t* pr, 
 /* One trip of the outer loop, DDP:295-412.  Returns 1 when the loop breaks. */
 static int ref_iterate_once(ref_t* r) {
   int N = r->N, ncm = r->ncmax;
+  int n_sweeps = 0;
   while (1) { /* DDP:297-310 */
     backwardpass(r);
+    n_sweeps++;
     if (!r->bp_failed) break;
     if (r->reg == 24 && r->bp_failed)
       r->bp_no_upd_count++;
@@ -1189,6 +1194,7 @@ static int ref_iterate_once(ref_t* r) {
     double* t = r->trace + (size_t)r->iter * TRACE_W;
     t[0] = r->cost; t[1] = r->costq; t[2] = r->logcost; t[3] = r->err; t[4] = r->mu;
     t[5] = r->reg; t[6] = r->step; t[7] = r->opterr; t[8] = r->stepsize; t[9] = r->fp_failed;
+    t[10] = n_sweeps; t[11] = r->bp_failed; /* backward sweeps of the retry loop; did it give up (DDP:306-309) */
   }
   /* DDP:314-326 negative time */
   int timePosiInd = 1;
@@ -1338,7 +1344,7 @@ static void write_out(ref_t* r, const direct_ddp_batch_in_t* in, direct_ddp_batc
 }
 
 /* Batched polyCurveGeneration, one problem per OpenMP task.  fp64 host arrays only.
- * trace (may be NULL): [batch][trace_cap][10] per-iteration record. */
+ * trace (may be NULL): [batch][trace_cap][12] per-iteration record. */
 int direct_ref_solve_batch(const direct_ddp_params_t* pr, const direct_ddp_batch_in_t* in,
                            direct_ddp_batch_out_t* out, int n_threads, double* trace, int trace_cap) {
   if (!pr || !in || !out) return DIRECT_ERR_INVALID;

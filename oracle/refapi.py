@@ -52,7 +52,7 @@ def lib():
     return _LIB
 
 
-TRACE_COLS = ("cost", "costq", "logcost", "err", "mu", "reg", "step", "opterr", "stepsize", "fp_failed")
+TRACE_COLS = ("cost", "costq", "logcost", "err", "mu", "reg", "step", "opterr", "stepsize", "fp_failed", "n_sweeps", "bp_failed")
 
 
 def _f64(batch):

@@ -75,3 +75,55 @@ def with_extra_planes(batch, p_max, seed=0):
                 j += 1
             n_planes[b, k] = j
     return abi.HostBatch(batch.n_seg, batch.x0, batch.xd, batch.T0, n_planes, planes, seeds=batch.seeds, dtype=batch.dtype)
+
+
+# ---- fixtures of tests/golden/make_exit_golden.py: one per exit / failure branch of the outer loop (DDP:295-412) -------
+EXIT_CASES = ("exit_iter_max", "exit_neg_time", "exit_stuck_first", "exit_llt_retry", "exit_line_ok", "exit_line_no_update")
+_PARAM_FIELDS = ("max_vel", "max_acc", "w_snap", "w_terminal", "w_time", "iter_max", "time_power", "zero_init", "line_init",
+                 "minvo", "infeas", "fixed_iters", "exact_dt")
+_INT_PARAMS = ("iter_max", "time_power", "zero_init", "line_init", "minvo", "infeas", "fixed_iters", "exact_dt")
+
+
+def load_exit_case(name):
+    """-> (npz, HostBatch, Params) of one exit fixture"""
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    batch = abi.HostBatch(g["n_seg"], g["x0"], g["xd"], g["T0"], g["n_planes"], g["planes"], seeds=g["seeds"],
+                          init_bez=g["init_bez"] if "init_bez" in g.files else None,
+                          infeas_in=g["infeas_in"] if "infeas_in" in g.files else None)
+    kw = {f: (int(g["param_" + f]) if f in _INT_PARAMS else float(g["param_" + f])) for f in _PARAM_FIELDS}
+    return g, batch, abi.Params(**kw)
+
+
+def check_exit_result(res, g, tol, bez_tol=None, discrete=True):
+    """a HostResult against the getter outputs of an exit fixture (the NumPy restatement's)"""
+    bez_tol = 100 * tol if bez_tol is None else bez_tol
+    if discrete:
+        for f in ("rtn", "iter_used", "fwd_passes", "infeas_out", "line_failed_out"):
+            assert (np.asarray(getattr(res, f)).astype(int) == g["out_" + f].astype(int)).all(), (f, getattr(res, f), g["out_" + f])
+    assert np.abs(res.cost / g["out_cost"] - 1).max() < tol, np.abs(res.cost / g["out_cost"] - 1).max()
+    assert rel(res.T, g["out_T"]) < bez_tol and rel(res.bez, g["out_bez"]) < bez_tol and rel(res.poly, g["out_poly"]) < bez_tol
+    assert rel(res.jerk_cost, g["out_jerk_cost"]) < 10 * bez_tol
+
+
+def run_forced_stuck(impl, g, tol):
+    """the stepwise scenario of exit_forced_stuck.npz on an implementation that has begun (iterate / get / set / scalars):
+    K iterations, one dual entry per problem made negative, the stuck trip - against the NumPy restatement's iterate"""
+    K, knot, rows, y_inject = int(g["K"]), int(g["knot"]), g["rows"], float(g["y_inject"])
+    B, N = g["n_seg"].shape[0], int(g["n_seg"][0])
+    impl.iterate(K)
+    Y = impl.get(abi.FIELD_Y)
+    for i, r in enumerate(rows):
+        Y[i, knot, r] = y_inject
+    impl.set(abi.FIELD_Y, Y)
+    impl.iterate(1)
+    sc = impl.scalars()
+    u = g["sc_usable"] == 1
+    assert (sc["rtn"].astype(int) == -4).all() and (sc["reg"].astype(int) == 24).all()
+    assert (sc["step"].astype(int)[u] == g["sc_step"].astype(int)[u]).all() and (sc["fp_failed"].astype(int)[u] == g["sc_fp_failed"].astype(int)[u]).all()
+    assert np.abs(np.asarray(sc["cost"], np.float64)[u] / g["sc_cost"][u] - 1).max() < tol
+    for f, n in ((abi.FIELD_X, "X"), (abi.FIELD_U, "U"), (abi.FIELD_S, "S"), (abi.FIELD_Y, "Y")):
+        got = np.asarray(impl.get(f), np.float64)
+        want = g["post_" + n]
+        assert got.shape == want.shape, (n, got.shape, want.shape)
+        for i in np.where(u)[0]:
+            assert rel(got[i], want[i]) < tol, (n, i, rel(got[i], want[i]))

@@ -185,6 +185,20 @@ def test_backward_pass_stuck_exit_matches_oracle():
     assert np.abs(e.cost[ok] / r.cost[ok] - 1).max() < 1e-8
 
 
+@pytest.mark.parametrize("name", helpers.EXIT_CASES)
+def test_emulated_kernels_match_exit_goldens(name):
+    """every way out of the outer loop (DDP:295-412) against the NumPy restatement's vectors (make_exit_golden.py)"""
+    g, batch, p = helpers.load_exit_case(name)
+    helpers.check_exit_result(emuapi.solve_batch(p, batch), g, 1e-8)
+
+
+def test_emulated_kernels_match_forced_stuck_golden():
+    g, batch, p = helpers.load_exit_case("exit_forced_stuck")
+    e = emuapi.EmuSolver(p, batch)
+    helpers.run_forced_stuck(e, g, 1e-9)
+    e.close()
+
+
 @pytest.mark.parametrize("scenario", range(len(stuck_lib.scenarios())))
 def test_forward_pass_after_a_stuck_backward_pass_uses_the_stored_gains(scenario):
     """The reference's forwardpass() after DDP:297-310 gave up runs with the gains its members hold: knots the retry

@@ -295,6 +295,32 @@ def test_shared_backward_sweep_is_bitwise_equal_to_the_owner_only_sweep(built, d
         assert knots["1"][1] > 0, knots
 
 
+def test_a_lone_trajectory_with_hundreds_of_waiters_on_its_shared_sweep(built, monkeypatch):
+    """B = 1, N = 100, 320 fixed iterations: the ticket scheduler hands out n_epochs + tail tickets for the ONE trajectory and
+    every holder polls its open sweep - far more than the 255 an 8-bit helper count could hold (the carry went
+    into the sweep's tag, the owner's flag wait ran into its spin limit and every row came back -101).  The count field now
+    holds every resident wave and kBsMaxHelpers are let in: no scheduler error, helpers really used, every output bit
+    identical to the owner-only launch."""
+    batch = problems.make_batch("free", 1, N, seed=4242).astype(np.float32)
+    p = abi.phase1_params(iter_max=320, fixed_iters=1)
+    fields = ("rtn", "iter_used", "fwd_passes", "cost", "costq", "opterr", "mu", "T", "poly", "bez")
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIRECT_DDP_BSHARE", mode)
+        s = solver.DdpSolver(1, N, batch.p_max, np.float32)
+        g0 = s.solve(abi.phase0_params(), batch)
+        b1 = batch.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, batch.T0), infeas_in=g0.infeas_out, init_poly=g0.poly)
+        res[mode] = s.solve(p, b1)
+        assert s.sched_error() == 0
+        li = s.launch_info()
+        if mode == "1":
+            assert li["shared_sweep"] == 1 and li["helper_front_knots"] > 0, li
+        s.close()
+    assert res["1"].rtn[0] != -101 and res["1"].fwd_passes[0] == 320
+    for f in fields:
+        assert np.array_equal(getattr(res["0"], f), getattr(res["1"], f)), f
+
+
 @pytest.mark.parametrize("dt,nb,nseg,chunk", [(np.float64, 3300, 40, "1"), (np.float32, 3500, 60, "3")])
 def test_shared_line_search_other_storage_types_and_chunk_sizes(built, dt, nb, nseg, chunk, monkeypatch):
     """The same bitwise equality for double storage, an awkward batch size, shorter trajectories and tickets of three

@@ -389,6 +389,44 @@ def test_forward_pass_after_a_backward_pass_that_failed_part_way(built, dtype, t
     s.close()
 
 
+@pytest.mark.parametrize("name", helpers.EXIT_CASES)
+def test_whole_solve_matches_exit_goldens_fp64(built, name):
+    """Every way out of the outer loop and every failure branch inside it (DDP:295-412) through the C-ABI, against the
+    vectors of the NumPy restatement (tests/golden/make_exit_golden.py): the loop running out, rtn -3 (negative input
+    duration), rtn -4 in the first iteration, LLT failures with recovery at a larger regulariser, both line-init exits."""
+    g, batch, p = helpers.load_exit_case(name)
+    s = make_solver(batch, np.float64)
+    helpers.check_exit_result(s.solve(p, batch), g, 1e-8)
+    s.close()
+
+
+@pytest.mark.parametrize("name", helpers.EXIT_CASES)
+def test_whole_solve_matches_exit_goldens_float_storage(built, name):
+    """the same with float storage on float-rounded inputs: identical return codes, iteration counts within what the
+    oracle itself shows between double and float-rounded inputs, cost 1e-3"""
+    g, batch, p = helpers.load_exit_case(name)
+    b32 = batch.astype(np.float32).astype(np.float64)
+    ctl, _ = refapi.solve_batch(p, b32)
+    s = make_solver(batch, np.float32)
+    r = s.solve(p, b32)
+    s.close()
+    assert (r.rtn == ctl.rtn).all() and (r.line_failed_out == ctl.line_failed_out).all()
+    slack = np.abs(ctl.iter_used - g["out_iter_used"]).max()
+    assert np.abs(r.iter_used - ctl.iter_used).max() <= slack
+    same = r.iter_used == ctl.iter_used
+    assert np.abs(r.cost[same] / ctl.cost[same] - 1).max() < 1e-3
+
+
+def test_forced_stuck_golden(built):
+    """exit_forced_stuck.npz: the backward pass stuck mid-solve and the stale-gain forward pass that follows, as the
+    NumPy restatement ran it - the second witness of the rtn = -4 path next to the C oracle (tests/stuck_lib.py)."""
+    g, batch, p = helpers.load_exit_case("exit_forced_stuck")
+    s = make_solver(batch, np.float64)
+    s.begin(p, batch)
+    helpers.run_forced_stuck(s, g, 1e-9)
+    s.close()
+
+
 @pytest.mark.parametrize("scenario", range(len(stuck_lib.scenarios())))
 def test_forward_pass_after_a_stuck_backward_pass_uses_the_stored_gains(built, scenario):
     """rtn = -4 with the reference's own last forward pass (DDP:297-311 -> 647-778 -> 392-396): the knots the retry sequence

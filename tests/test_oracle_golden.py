@@ -31,6 +31,55 @@ def test_oracle_matches_golden(name):
                 assert np.abs(a[:, col] - e[:, col]).max() <= 1e-7 * np.abs(e[:, col]).max() + 1e-12
 
 
+@pytest.mark.parametrize("name", helpers.EXIT_CASES)
+def test_oracle_matches_exit_goldens(name):
+    """Every way out of the outer loop and every failure branch inside it (DDP:295-412; tests/golden/make_exit_golden.py):
+    the loop running out, rtn -3, rtn -4 in the first iteration, LLT failures with recovery, both line-init exits - the C
+    oracle against the NumPy restatement's vectors, decision by decision: regulariser, step index, line-search failure,
+    the number of backward sweeps of every retry loop and whether it gave up."""
+    g, batch, p = helpers.load_exit_case(name)
+    r, tr = refapi.solve_batch(p, batch, trace_cap=p.iter_max + 1)
+    helpers.check_exit_result(r, g, 1e-9)
+    gt = g["out_trace"]
+    for b in range(batch.batch):
+        n = int(r.fwd_passes[b])
+        a, e = tr[b, :n], gt[b, :n]
+        for col in (5, 6, 9, 10, 11):   # reg, step, fp_failed, n_sweeps, bp_failed
+            assert np.array_equal(a[:, col], e[:, col]), (b, refapi.TRACE_COLS[col])
+        for col in (0, 1, 4):           # cost, costq, mu (the log-cost is NaN where the start is infeasible in feasible mode)
+            assert np.abs(a[:, col] - e[:, col]).max() <= 1e-7 * np.abs(e[:, col]).max() + 1e-12
+    if name == "exit_llt_retry":
+        assert (np.nan_to_num(gt[:, :, 10]) > 1).any(axis=1).all() and (np.nan_to_num(gt[:, :, 11]) == 0).all()
+    if name == "exit_stuck_first":
+        assert gt[1, 0, 10] == 45 and gt[1, 0, 11] == 1   # reg 1 .. 24, 21 sweeps at 24, given up
+
+
+def test_oracle_matches_forced_stuck_golden():
+    """The backward pass stuck mid-solve and the stale-gain forward pass that follows (tests/stuck_lib.py), as the NumPy
+    restatement ran it (its stored ks, Ks, ky, Ky are Eigen-literal): the C oracle's iterate after the last trip."""
+    g, batch, p = helpers.load_exit_case("exit_forced_stuck")
+
+    class Impl:
+        def __init__(self):
+            self.st = [refapi.Stepper(p, batch, i) for i in range(batch.batch)]
+
+        def iterate(self, n):
+            for s in self.st:
+                s.iterate(n)
+
+        def get(self, f):
+            return np.stack([s.get(f) for s in self.st])
+
+        def set(self, f, a):
+            for i, s in enumerate(self.st):
+                s.set(f, a[i])
+
+        def scalars(self):
+            rows = [s.scalars() for s in self.st]
+            return {n: np.array([r[n] for r in rows]) for n in abi.SCALAR_NAMES}
+    helpers.run_forced_stuck(Impl(), g, 1e-9)
+
+
 def test_plan_batch_equals_two_calls():
     g, batch = helpers.load_case("corridor_n8")
     p0, p1 = helpers.case_params("corridor_n8")
