@@ -487,6 +487,10 @@ def main():
     ap.add_argument("--dtype", default="", choices=["", "f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the natural-exit run and the HBM copy microbench")
+    ap.add_argument("--with-secondary", action="store_true",
+                    help="N > 1 ranks: run the secondary blocks as well (by default a multi-GPU run times the headline step, "
+                         "runs the gather, and leaves: ~1 min of single-plan / label-model / cluster blocks on rank 0 would "
+                         "keep N - 1 leased GPUs waiting in a barrier)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of the same workload in a "
                          "subprocess, ~30 s); the newest committed profile of the workload is quoted instead")
@@ -535,6 +539,8 @@ def main():
     # broadcast, the library's communicator) runs at world size 1 too - so that each of its lines has executed on a GPU
     # before the first multi-GPU run (tests/test_gpu_configs.py); the timed region is the same
     dist_on = world > 1 or os.environ.get("DIRECT_BENCH_FORCE_DIST", "0") not in ("", "0")
+    if world > 1 and not args.with_secondary:
+        args.no_secondary = True
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
@@ -549,8 +555,7 @@ def main():
 
     # phase 0 once (untimed) to obtain the warm start of the timed phase-1 workload
     g0 = s.solve(abi.phase0_params(), batch)
-    batch1 = batch.with_init(None, T0=np.where((g0.rtn == 2)[:, None], g0.T, batch.T0), infeas_in=g0.infeas_out,
-                             init_poly=g0.poly)  # monomial hand-off: well conditioned in float (include/direct_ddp.h)
+    batch1 = batch.phase1_inputs(g0)  # TRP:911-921 as direct_ddp_plan_batch chains it (monomial hand-off: include/direct_ddp.h)
     params = abi.phase1_params(iter_max=FIXED_ITERS, fixed_iters=1)
     workload = {"kind": cfg["kind"], "batch": B, "nseg": N, "dtype": cfg["dtype"], "fixed_iters": FIXED_ITERS}
 
@@ -810,6 +815,7 @@ def main():
                          "traffic_bytes_per_executed_knot_visit": None if traffic is None else
                          traffic["traffic_bytes_per_launch"] / max(1, launch["bwd_knot_visits"] + launch["fwd_knot_visits"])},
             "kernel_ms_per_rank": rank_kernel_ms,
+            "kernel_ms_rank_spread": (float(max(rank_kernel_ms) - min(rank_kernel_ms)) / float(np.mean(rank_kernel_ms))) if rank_kernel_ms else None,
             "iters_per_step_rank0": iters_step, "gather": gather,
         }
         if sq is not None and "f64_flops_per_ddp_iteration" in sq["derived"] and "f64_arith_frac_of_valu" in sq["derived"]:

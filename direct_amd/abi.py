@@ -174,6 +174,28 @@ class HostBatch:
         return HostBatch(self.n_seg, self.x0, self.xd, self.T0 if T0 is None else T0, self.n_planes,
                          self.planes, self.seeds, init_bez, infeas_in, dtype=self.dtype, init_poly=init_poly)
 
+    def phase1_inputs(self, res0, monomial=True):
+        """The second polyCurveGeneration call of fastTrajPlanning from a phase-0 result (teach_repeat_planner.cpp:911-921),
+        as direct_ddp_plan_batch chains it on the device: UpdateTime where phase 0 returned 2, and the warm start
+        getBezCoeff() -> initbezCoeff.  monomial: the same warm start as getPolyCoeff rows (what float storage needs,
+        include/direct_ddp.h): where phase 0 did NOT return 2 the reference converts its control points back with the
+        caller's durations T_1 instead of phase 0's T_0 (ddp_optimizer.cpp:167-193 after 799-812), i.e. coefficient c_i
+        becomes c_i (T_0 / T_1)^(i-1) - applied here in double (k_chain of direct_ddp.hip does the same)."""
+        found = (np.asarray(res0.rtn) == 2)[:, None]
+        T1 = np.where(found, res0.T, self.T0)
+        infeas = np.asarray(res0.infeas_out).astype(np.uint8)
+        if not monomial:
+            return self.with_init(res0.bez, T0=T1, infeas_in=infeas)
+        T0d, T1d = np.asarray(res0.T, np.float64), np.asarray(T1, np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = np.where(found | (T1d == 0.0), 1.0, T0d / T1d)
+        poly = np.asarray(res0.poly, np.float64).reshape(self.batch, self.n_seg_max, 6, 3).copy()
+        f = 1.0 / q
+        for c in range(6):
+            poly[:, :, c, :] = np.where(found[:, :, None], poly[:, :, c, :], poly[:, :, c, :] * f[:, :, None])
+            f = f * q
+        return self.with_init(None, T0=T1, infeas_in=infeas, init_poly=poly.reshape(self.batch, self.n_seg_max, 18))
+
     def c_struct(self):
         s = BatchIn()
         s.batch, s.n_seg_max, s.p_max, s.mem = self.batch, self.n_seg_max, self.p_max, MEM_HOST

@@ -1004,6 +1004,9 @@ direct_status_t direct_cluster_create(const direct_cluster_config_t* cfg, direct
   if (cfg->max_x > kDimLimit || cfg->max_y > kDimLimit || cfg->max_z > kDimLimit)
     return cfail(DIRECT_ERR_UNSUPPORTED, "map dimensions above 1024 voxels per axis");
   if ((long long)cfg->max_x * cfg->max_y * cfg->max_z > 0x7fffffffLL / 2) return cfail(DIRECT_ERR_UNSUPPORTED, "map too large");
+  // the summed-area table has (X+1)(Y+1)(Z+1) int entries and box_obstacles addresses it with unsigned 32-bit BYTE offsets
+  if ((long long)(cfg->max_x + 1) * (cfg->max_y + 1) * (cfg->max_z + 1) >= (1LL << 30))
+    return cfail(DIRECT_ERR_UNSUPPORTED, "map too large: the summed-area table would exceed 4 GiB");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return cfail(DIRECT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");

@@ -277,15 +277,32 @@ __global__ __launch_bounds__(64) void k_field(Batch<St> B, int field, St* buf, i
   }
 }
 
-// UpdateTime + warm start between the two phases (teach_repeat_planner.cpp:911-918), on device
+// UpdateTime + warm start between the two phases (teach_repeat_planner.cpp:911-921), on device.
+// The reference hands phase 0's getBezCoeff() to phase 1 as initbezCoeff: control points scaled by 1 / T_0 (ddp_optimizer.cpp:799-812),
+// which phase 1 converts back with ITS durations T_1 (ddp_optimizer.cpp:167-193, 782-796):  c'_i = (T_1 / T_0) c_i T_0^i / T_1^i.
+// Where phase 0 found a feasible trajectory (rtn 2) UpdateTime makes T_1 = T_0 and the round trip is the identity; everywhere
+// else T_1 is the caller's duration again and the warm start is the phase-0 curve in NORMALISED time, its coefficients
+// scaled by (T_0 / T_1)^(i-1).  The same thing is handed over here as monomial coefficients (getPolyCoeff rows) with exactly
+// that factor applied in double: float storage cannot afford the Bezier detour, and phase 1 only reads
+// the u part, [c3; c4; c5].
 template <typename Real>
 __global__ void k_chain(int B, int nmax, const int32_t* rtn0, const Real* T_phase0, const Real* T_in,
-                        const uint8_t* infeas0, Real* T_next, uint8_t* infeas_next) {
+                        const uint8_t* infeas0, const Real* poly0, Real* T_next, uint8_t* infeas_next, Real* init_poly) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nmax) return;
   int b = i / nmax;
-  T_next[i] = (rtn0[b] == 2) ? T_phase0[i] : T_in[i];
+  const bool found = rtn0[b] == 2;
+  const Real T1 = found ? T_phase0[i] : T_in[i];
+  T_next[i] = T1;
   if (i % nmax == 0) infeas_next[b] = infeas0[b];
+  const double q = (found || (double)T1 == 0.0) ? 1.0 : (double)T_phase0[i] / (double)T1;
+  const Real* src = poly0 + (size_t)i * 18;
+  Real* dst = init_poly + (size_t)i * 18;
+  double f = 1.0 / q;  // q^(c - 1) for coefficient c = 0 .. 5
+  for (int c = 0; c < 6; c++) {
+    for (int d = 0; d < 3; d++) dst[3 * c + d] = found ? src[3 * c + d] : (Real)((double)src[3 * c + d] * f);
+    f *= q;
+  }
 }
 
 // initTimeAllocation (teach_repeat_planner.cpp:583-639, v0 = 0) on the device: one thread per (corridor, segment), double
@@ -414,7 +431,14 @@ struct direct_ddp_handle_s {
   hipEvent_t in_ev = nullptr;   // the last upload from in_host (the mirror is not rewritten before it has completed)
   bool in_ev_pending = false;
   char* batch_dev = nullptr;   // [16][1024]: device copies of the class launches' Batch structs (Batch::self)
-  std::vector<char> batch_host; // their staging copies (a copy must outlive the asynchronous upload)
+  // their staging copies: PINNED, a ring of kBatchRing slots per class with an event each - a slot is not rewritten before the
+  // upload that read it has completed (phase 1 of a plan follows phase 0 at once with other SolveConst values)
+  static constexpr int kBatchRing = 4;
+  char* batch_pin = nullptr;   // [16][kBatchRing][1024]
+  hipEvent_t batch_ev[16][kBatchRing] = {};
+  bool batch_ev_used[16][kBatchRing] = {};
+  unsigned batch_seq[16] = {};
+  int bshare_cap = 0;          // trajectories the shared-sweep arrays (bshare, bflag, brec) are allocated for
   int bshare_mode = -1;        // -1 auto (wherever the line search is shared), DIRECT_DDP_BSHARE=0 off, 1 on, 2 forced split: every
                                // owner runs the helpers' half itself first (tests: the hand-over path without any helper)
   void *KU = nullptr, *KS = nullptr, *KY = nullptr;
@@ -608,8 +632,9 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
     (void)hipMemsetAsync(h->sched + 2, 0, (size_t)h->B * sizeof(int), h->stream);  // done_epoch; the error flag [1] is sticky: cleared in stage_inputs
     if (h->help) (void)hipMemsetAsync(h->help, 0, (size_t)h->B * sizeof(HelpSlot), h->stream);
     if (h->bshare && h->bshare_mode != 0) {  // sweep tags restart with every launch: no flag of an earlier one may survive
-      (void)hipMemsetAsync(h->bshare, 0, (size_t)h->B * sizeof(BwdShare), h->stream);
-      (void)hipMemsetAsync(h->bflag, 0, (size_t)h->B * h->nmax * sizeof(int), h->stream);
+      const size_t nb = (size_t)(h->B < h->bshare_cap ? h->B : h->bshare_cap);
+      (void)hipMemsetAsync(h->bshare, 0, nb * sizeof(BwdShare), h->stream);
+      (void)hipMemsetAsync(h->bflag, 0, nb * h->nmax * sizeof(int), h->stream);
     }
   }
   bool forked = false;
@@ -654,14 +679,25 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       li.shared_sweep = 0;
     }
     // backward sweeps shared with helpers wherever the line search is; the forced split needs no helper (any launch form)
-    const bool sweep_ok = h->bshare != nullptr && c.rpl <= 4;
+    // (the arrays are indexed by the trajectory's own number: the whole current batch must fit what was allocated)
+    const bool sweep_ok = h->bshare != nullptr && c.rpl <= 4 && h->B <= h->bshare_cap;
     static_assert(sizeof(Batch<Real>) <= 1024, "Batch grew past its device-copy slot");
     auto publish = [&](Batch<Real>& Bb) {  // the struct itself in device memory, for the out-of-line halves of a shared sweep
-      if (ci >= 16) { Bb.bshare = nullptr; return; }
-      if (h->batch_host.size() < 16 * 1024) h->batch_host.resize(16 * 1024);
+      if (ci >= 16 || h->batch_pin == nullptr) { Bb.bshare = nullptr; return; }
+      const int slot = (int)(h->batch_seq[ci]++ % direct_ddp_handle_s::kBatchRing);
+      if (h->batch_ev_used[ci][slot]) (void)hipEventSynchronize(h->batch_ev[ci][slot]);  // the upload that last read this slot
+      char* stage = h->batch_pin + ((size_t)ci * direct_ddp_handle_s::kBatchRing + slot) * 1024;
       Bb.self = h->batch_dev + ci * 1024;
-      memcpy(h->batch_host.data() + ci * 1024, &Bb, sizeof(Bb));
-      (void)hipMemcpyAsync(h->batch_dev + ci * 1024, h->batch_host.data() + ci * 1024, sizeof(Bb), hipMemcpyHostToDevice, st);
+      memcpy(stage, &Bb, sizeof(Bb));
+      (void)hipMemcpyAsync(h->batch_dev + ci * 1024, stage, sizeof(Bb), hipMemcpyHostToDevice, st);
+      if (h->batch_ev[ci][slot] == nullptr && hipEventCreateWithFlags(&h->batch_ev[ci][slot], hipEventDisableTiming) != hipSuccess) {
+        h->batch_ev[ci][slot] = nullptr;
+        (void)hipStreamSynchronize(st);  // no event: the slot is free again once the stream has drained
+        h->batch_ev_used[ci][slot] = false;
+      } else {
+        (void)hipEventRecord(h->batch_ev[ci][slot], st);
+        h->batch_ev_used[ci][slot] = true;
+      }
     };
     if (sweep_ok && h->bshare_mode == 2) {
       Bt.bshare = h->bshare; Bt.bflag = h->bflag; Bt.brec = h->brec; Bt.bforce = 1; Bt.bvisits = h->visits + 2;
@@ -930,8 +966,17 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   }
   if (h->nbuf == kMaxBuf) A(&h->help, B * sizeof(HelpSlot));
   if (h->rpl <= 4 && h->bshare_mode != 0 && (h->nbuf == kMaxBuf || h->bshare_mode == 2)) {
-    A(&h->bshare, B * sizeof(BwdShare)); A(&h->bflag, B * nm * sizeof(int)); A(&h->brec, B * nm * (size_t)kRecDoubles * 8);
+    // 3 KB per knot (brec): in auto mode sweeps are only shared by batches of up to an eighth of the resident waves
+    // (launch_iterate_t), so that is all the arrays are sized for; forced on (1 / 2) they cover the handle's whole batch
+    const size_t auto_cap = h->sched_slots / 8 > 0 ? (size_t)h->sched_slots / 8 : 1;
+    const size_t nb = (h->bshare_mode > 0 || B < auto_cap) ? B : auto_cap;
+    h->bshare_cap = (int)nb;
+    A(&h->bshare, nb * sizeof(BwdShare)); A(&h->bflag, nb * nm * sizeof(int)); A(&h->brec, nb * nm * (size_t)kRecDoubles * 8);
     A(&h->batch_dev, 16 * 1024);
+    if (st == DIRECT_OK && hipHostMalloc((void**)&h->batch_pin, (size_t)16 * direct_ddp_handle_s::kBatchRing * 1024) != hipSuccess) {
+      h->batch_pin = nullptr;
+      st = fail(DIRECT_ERR_DEVICE, "pinned staging of the launch descriptors");
+    }
   }
   A(&h->KU, B * nm * 100 * r); A(&h->KS, B * nm * h->ncs * r); A(&h->KY, B * nm * h->ncs * r);
   A(&h->st, B * sizeof(TrajState));
@@ -973,8 +1018,11 @@ direct_status_t direct_ddp_destroy(direct_ddp_handle_t h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
-  for (char* q : {h->in_host, h->out_host, h->out0_host})
+  for (char* q : {h->in_host, h->out_host, h->out0_host, h->batch_pin})
     if (q) (void)hipHostFree(q);
+  for (auto& row : h->batch_ev)
+    for (hipEvent_t e : row)
+      if (e) (void)hipEventDestroy(e);
   if (h->in_ev) (void)hipEventDestroy(h->in_ev);
   if (h->filt) (void)hipFree(h->filt);
   for (void* q : {h->g_recs, h->g_blocks, h->g_win, h->g_in})
@@ -1301,16 +1349,16 @@ direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_pa
   }
   // UpdateTime where rtn0 == 2, warm start from the phase-0 Bezier coefficients (TRP:911-918)
   const int n = h->B * h->nmax;
+  // (TRP:918 hands over Bezier control points; the same warm start goes over as monomial coefficients, see k_chain)
   if (h->dtype == DIRECT_F64)
     hipLaunchKernelGGL(k_chain<double>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->B, h->nmax, h->o.rtn,
-                       (const double*)h->o.T, (const double*)h->cur_in.T0, h->o.infeas_out, (double*)h->T_next, h->infeas_next);
+                       (const double*)h->o.T, (const double*)h->cur_in.T0, h->o.infeas_out, (const double*)h->o.poly,
+                       (double*)h->T_next, h->infeas_next, (double*)h->init_poly);
   else
     hipLaunchKernelGGL(k_chain<float>, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->B, h->nmax, h->o.rtn,
-                       (const float*)h->o.T, (const float*)h->cur_in.T0, h->o.infeas_out, (float*)h->T_next, h->infeas_next);
+                       (const float*)h->o.T, (const float*)h->cur_in.T0, h->o.infeas_out, (const float*)h->o.poly,
+                       (float*)h->T_next, h->infeas_next, (float*)h->init_poly);
   HIP_TRY(hipGetLastError());
-  // TRP:918 hands over Bezier control points; the same trajectory is handed over here as its monomial
-  // coefficients (getPolyCoeff), which is exact in double and well conditioned in float
-  HIP_TRY(hipMemcpyAsync(h->init_poly, h->o.poly, (size_t)h->B * h->nmax * 18 * h->rsz, hipMemcpyDeviceToDevice, h->stream));
   direct_ddp_batch_in_t in1 = h->cur_in;  // device pointers
   in1.T0 = h->T_next;
   in1.init_bez = nullptr;
@@ -1321,7 +1369,9 @@ direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_pa
   TRY(launch_iterate(h, p1->iter_max, 0));
   const direct_status_t fin = launch_finish(h, out1);
   if (out0_packed) {
-    if (out1->mem != DIRECT_MEM_HOST) HIP_TRY(hipStreamSynchronize(h->stream));  // (host results of phase 1 have synchronised already)
+    // (host results of phase 1 have synchronised already - unless that call failed before its synchronisation: the copy
+    // into out0_host may then still be in flight)
+    if (out1->mem != DIRECT_MEM_HOST || fin != DIRECT_OK) HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t B = h->B, nm = h->nmax, r = h->rsz;
     auto sc = [&](void* dst, const void* src, size_t bytes) {
       if (dst) memcpy(dst, h->out0_host + ((const char*)src - h->out_blob), bytes);

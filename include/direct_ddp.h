@@ -190,7 +190,11 @@ direct_status_t direct_ddp_sched_error(direct_ddp_handle_t h, int32_t* flag);
 
 /* fastTrajPlanning's protocol (teach_repeat_planner.cpp:886-921) for a batch: phase 0
  * (params0: zero init, infeasible start), UpdateTime where rtn0 == 2, phase 1 (params1) from
- * the phase-0 Bezier coefficients.  out0 may be NULL. */
+ * the phase-0 Bezier coefficients: where phase 0 did not return 2 the reference converts them back
+ * with the CALLER's durations (ddp_optimizer.cpp:167-193 after 799-812), i.e. the warm start is the
+ * phase-0 curve in normalised time - reproduced on the device (coefficient c_i scaled by
+ * (T_0 / T_1)^(i-1), handed over as monomial coefficients).  out0 may be NULL; when the call fails
+ * in phase 1 the contents of out0 are undefined. */
 direct_status_t direct_ddp_plan_batch(direct_ddp_handle_t h, const direct_ddp_params_t* params0,
                                       const direct_ddp_params_t* params1,
                                       const direct_ddp_batch_in_t* in, direct_ddp_batch_out_t* out0,

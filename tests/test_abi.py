@@ -113,6 +113,18 @@ def test_create_rejects_bad_configs(built):
         assert len(lib.direct_ddp_last_error()) > 0
 
 
+def test_cluster_create_rejects_maps_whose_summed_area_table_passes_4_gib(built):
+    """box_obstacles addresses the (X+1)(Y+1)(Z+1)-entry summed-area table with unsigned 32-bit BYTE offsets: a map that
+    large must be refused at create time, not read wrong entries.  Sizes are validated before the device."""
+    from direct_amd import cluster
+    lib = solver.lib()
+    h = C.c_void_p()
+    for dims, want in (((1024, 1024, 1023), abi.DIRECT_ERR_UNSUPPORTED), ((1024, 1024, 1030), abi.DIRECT_ERR_UNSUPPORTED),
+                       ((0, 10, 10), abi.DIRECT_ERR_INVALID)):
+        cfg = cluster.Config(0, dims[0], dims[1], dims[2], 4, 4096, 4096, 0)
+        assert lib.direct_cluster_create(C.addressof(cfg), C.addressof(h)) == want, dims
+
+
 def test_time_allocation_through_the_abi(built):
     """initTimeAllocation (teach_repeat_planner.cpp:583-639) is host code in the library."""
     batch = problems.make_batch("free", 5, 9, seed=4)

@@ -155,8 +155,25 @@ def test_fp64_sample_of_full_size_problems(built, corridor_batch):
     assert (g1.rtn == r1.rtn).all()
     same = g1.iter_used == r1.iter_used
     assert same.all()
-    assert np.abs(g1.cost / r1.cost - 1).max() < 1e-5   # Bezier vs monomial hand-off between the phases
-    assert helpers.rel(g1.T, r1.T) < 1e-3
+    # phase 1 alone from the ORACLE's phase-0 result, through the reference's own hand-off (Bezier, TRP:918-921) and as the
+    # monomial coefficients the fused plan hands over: cost 1e-8, durations 1e-6
+    q1 = s.solve(p1, sub.phase1_inputs(r0, monomial=False))
+    assert (q1.rtn == r1.rtn).all() and (q1.iter_used == r1.iter_used).all()
+    assert np.abs(q1.cost / r1.cost - 1).max() < 1e-8 and helpers.rel(q1.T, r1.T) < 1e-6
+    m1 = s.solve(p1, sub.phase1_inputs(r0, monomial=True))
+    assert (m1.rtn == r1.rtn).all() and (m1.iter_used == r1.iter_used).all()
+    # the fused plan starts phase 1 from the device's phase-0 result (1e-13 from the oracle's), which 100 knots x 20 .. 100
+    # iterations amplify like any input perturbation: bounded by the oracle against itself, inputs moved by one ulp
+    from tests import soak_lib
+    devs = []
+    for cs in (3, 4, 5):
+        c0, c1 = refapi.plan_batch(p0, p1, soak_lib.perturb_ulp(sub, cs))
+        ok = (c1.rtn == r1.rtn) & (c1.iter_used == r1.iter_used)
+        devs.append((np.abs(c1.cost[ok] / r1.cost[ok] - 1).max() if ok.any() else 1.0, helpers.rel(c1.T[ok], r1.T[ok]) if ok.any() else 1.0))
+    ctl_cost, ctl_T = max(d[0] for d in devs), max(d[1] for d in devs)
+    assert np.abs(m1.cost / r1.cost - 1).max() < max(1e-8, 30 * ctl_cost), (np.abs(m1.cost / r1.cost - 1).max(), ctl_cost)
+    assert np.abs(g1.cost / r1.cost - 1).max() < max(1e-8, 30 * ctl_cost), (np.abs(g1.cost / r1.cost - 1).max(), ctl_cost)
+    assert helpers.rel(g1.T, r1.T) < max(1e-6, 30 * ctl_T), (helpers.rel(g1.T, r1.T), ctl_T)
     s.close()
 
 

@@ -9,7 +9,7 @@ import pytest
 
 from direct_amd import abi, problems, solver
 from oracle import refapi
-from tests import helpers, stuck_lib
+from tests import helpers, soak_lib, stuck_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -89,6 +89,7 @@ def test_whole_solve_fp32_tolerance(built, name):
     c1 = b1.with_init(None, T0=b1.T0, infeas_in=b1.infeas_in, init_poly=g["p0_poly"])
     ctl = max(int(np.abs(refapi.solve_batch(p1, n100_lib.perturb_float_ulp(c1, 7000 + q))[0].iter_used - g["p1_iter_used"].astype(int)).max())
               for q in range(4))
+    assert ctl <= 3, ctl   # (the control itself is bounded: a change of the oracle that made it drift would show here, not loosen the line below)
     assert np.abs(f1.iter_used - g["p1_iter_used"].astype(int)).max() <= ctl, (f1.iter_used, g["p1_iter_used"], ctl)
     s.close()
 
@@ -102,12 +103,52 @@ def test_random_batch_against_oracle_fp64(built):
     g0, g1 = s.plan(p0, p1, batch)
     assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
     assert (g1.rtn == r1.rtn).all() and (g1.iter_used == r1.iter_used).all()
-    # the fused plan hands the warm start over as monomial coefficients, the oracle as Bezier points:
-    # identical in exact arithmetic, ~1e-7 apart after 10-20 ill-conditioned iterations
-    assert np.abs(g1.cost / r1.cost - 1).max() < 1e-6
-    assert helpers.rel(g1.bez, r1.bez) < 1e-4 and helpers.rel(g1.T, r1.T) < 1e-4
-    assert helpers.rel(g1.terminal_norm2, r1.terminal_norm2) < 1e-4
+    # Phase 1 alone, from the ORACLE's phase-0 result through the reference's own hand-off (Bezier control points,
+    # TRP:918-921): SURVEY's whole-solve bound, cost 1e-8, control points and durations 1e-6
+    q1 = s.solve(p1, batch.phase1_inputs(r0, monomial=False))
+    assert (q1.rtn == r1.rtn).all() and (q1.iter_used == r1.iter_used).all()
+    assert np.abs(q1.cost / r1.cost - 1).max() < 1e-8
+    assert helpers.rel(q1.bez, r1.bez) < 1e-6 and helpers.rel(q1.T, r1.T) < 1e-6
+    # ... and the same warm start as monomial coefficients (what the fused plan hands over, k_chain): another rounding of the
+    # same numbers, i.e. an input perturbation of one ulp (bounded below with the fused plan)
+    m1 = s.solve(p1, batch.phase1_inputs(r0, monomial=True))
+    assert (m1.rtn == r1.rtn).all() and (m1.iter_used == r1.iter_used).all()
+    # The FUSED plan starts phase 1 from the DEVICE's phase-0 result, 1e-13 from the oracle's, and phase 1 amplifies that
+    # like any other perturbation of its inputs (measured on the emulator: 3e-8 with either hand-off form, 3e-9 from the
+    # oracle's own control points): bounded by what the oracle shows against itself with inputs moved by one ulp
+    c0, c1 = refapi.plan_batch(p0, p1, soak_lib.perturb_ulp(batch, 11))
+    ok = (c1.rtn == r1.rtn) & (c1.iter_used == r1.iter_used)
+    ctl_cost = np.abs(c1.cost[ok] / r1.cost[ok] - 1).max()
+    ctl_bez = max(helpers.rel(c1.bez[ok], r1.bez[ok]), helpers.rel(c1.T[ok], r1.T[ok]))
+    assert np.abs(m1.cost / r1.cost - 1).max() < max(1e-8, 30 * ctl_cost), (np.abs(m1.cost / r1.cost - 1).max(), ctl_cost)
+    assert np.abs(g1.cost / r1.cost - 1).max() < max(1e-8, 30 * ctl_cost), (np.abs(g1.cost / r1.cost - 1).max(), ctl_cost)
+    assert max(helpers.rel(g1.bez, r1.bez), helpers.rel(g1.T, r1.T)) < max(1e-6, 30 * ctl_bez), ctl_bez
+    assert helpers.rel(g1.terminal_norm2, r1.terminal_norm2) < max(1e-6, 100 * ctl_bez)
     s.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-8), (np.float32, 2e-3)])
+def test_plan_where_phase_0_does_not_find_a_feasible_trajectory(built, dtype, tol):
+    """Where phase 0 does not return 2 UpdateTime is skipped and phase 1 converts phase 0's control points back with the
+    CALLER's durations (TRP:911-921; ddp_optimizer.cpp:799-812 then 167-193): the warm start is the phase-0 curve in normalised time,
+    coefficient c_i scaled by (T_0 / T_1)^(i-1).  direct_ddp_plan_batch applies that factor to the monomial coefficients it
+    hands over (k_chain); until round 6 it handed them over unscaled - 80 x off in cost on these problems.  Phase 0 is cut
+    short (4 iterations) so that NO problem returns 2."""
+    batch = problems.make_batch("corridor", 32, 12, seed=123).astype(dtype).astype(np.float64)
+    p0, p1 = abi.phase0_params(iter_max=4), abi.phase1_params(infeas=1)
+    r0, r1 = refapi.plan_batch(p0, p1, batch)
+    assert (r0.rtn != 2).all()
+    s = make_solver(batch, dtype)
+    g0, g1 = s.plan(p0, p1, batch)
+    s.close()
+    assert (g0.rtn == r0.rtn).all() and (g0.iter_used == r0.iter_used).all()
+    assert (g1.rtn == r1.rtn).all()
+    if dtype == np.float64:
+        assert (g1.iter_used == r1.iter_used).all()
+    same = g1.iter_used == r1.iter_used
+    assert same.mean() > 0.8
+    assert np.abs(g1.cost[same] / r1.cost[same] - 1).max() < tol
+    assert helpers.rel(g1.T[same], r1.T[same]) < 100 * tol
 
 
 def test_ragged_batch_and_handle_reuse(built):
@@ -290,10 +331,10 @@ def check_against_controls(r, n):
                     assert pp["same"][i], (ph, i, pp)
                     assert pp["cost_dev"][i] < 1e-6 and pp["T_dev"][i] < 1e-6 and pp["bez_dev"][i] < 1e-5, (ph, i, pp)
         # float storage: SURVEY 8(c)'s fp32 tolerances wherever the float-ulp control keeps them
-        assert d32["same_feasibility"] >= min(c["same_feasibility"] for c in c32) - 1, (ph, d32, c32)
-        assert d32["same_rtn"] >= min(c["same_rtn"] for c in c32) - 1, (ph, d32, c32)
-        assert d32["same_outcome"] >= min(c["same_outcome"] for c in c32) - 1, (ph, d32, c32)
-        assert d32["n_cost_dev_below_1e_3"] >= min(c["n_cost_dev_below_1e_3"] for c in c32) - 1, (ph, d32, c32)
+        assert d32["same_feasibility"] >= min(c["same_feasibility"] for c in c32), (ph, d32, c32)
+        assert d32["same_rtn"] >= min(c["same_rtn"] for c in c32), (ph, d32, c32)
+        assert d32["same_outcome"] >= min(c["same_outcome"] for c in c32), (ph, d32, c32)
+        assert d32["n_cost_dev_below_1e_3"] >= min(c["n_cost_dev_below_1e_3"] for c in c32), (ph, d32, c32)
         assert d32["cost_dev_q50_q90_max"][0] < 1e-5, (ph, d32)
         assert d32["cost_dev_q50_q90_max"][2] <= max(1e-3, 3 * cmax(c32)), (ph, d32, c32)
 
