@@ -443,6 +443,52 @@ def single_plan_line(dev, with_cpu):
     return out
 
 
+def pipelined_line(torch, dev, batch1, np_dt, params_fixed, batches=8):
+    """Secondary: back-to-back independent batches on TWO handles with DIRECT_FLAG_YIELD, a stream each, against the same
+    batches on one handle (the reference's contract: an independent optimiser object per call, TRP:853-854).  The second
+    handle's persistent waves become resident as the first's leave: launch i + 1's first epochs fill the CUs that launch
+    i's slowest chains leave idle (natural exits: the chip empties while 48-iteration chains finish alone).  Results are
+    checked bit for bit against a serial launch.  Never `value`."""
+    from direct_amd import abi, devmem, solver
+    B, N = batch1.batch, batch1.n_seg_max
+    hs = [solver.DdpSolver(B, N, batch1.p_max, np_dt, device=dev.index or 0, flags=abi.FLAG_YIELD) for _ in range(2)]
+    one = solver.DdpSolver(B, N, batch1.p_max, np_dt, device=dev.index or 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for h, st in zip(hs + [one], streams):
+        h.set_stream(st.cuda_stream)
+    din = devmem.DeviceBatch(batch1, dev)
+    outs = [devmem.DeviceResult(B, N, np_dt, dev) for _ in range(2)]
+    ref = devmem.DeviceResult(B, N, np_dt, dev)
+    out = {"handles": 2, "batches": batches, "flag": "DIRECT_FLAG_YIELD"}
+    same_all = True
+    for name, p in (("fixed", params_fixed), ("natural_exit", abi.phase1_params())):
+        one.solve_device(p, din.cin, ref.cout)
+        torch.cuda.synchronize()
+        want = {k: v.clone() for k, v in ref.t.items()}
+        its = int(want["fwd_passes"].sum().item())
+        rec = {}
+        for mode in ("serial", "pipelined"):
+            pick = (lambda i: hs[i % 2]) if mode == "pipelined" else (lambda i: one)
+            for i in range(2):
+                pick(i).solve_device(p, din.cin, outs[i].cout)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(batches):
+                pick(i).solve_device(p, din.cin, outs[i % 2].cout)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            same = all(torch.equal(outs[j].t[k], want[k]) for j in range(2) for k in want)
+            same_all = same_all and same
+            rec[mode] = {"iter_per_s": its * batches / dt, "ms_per_batch": dt * 1e3 / batches}
+        rec["iterations_per_batch"] = its
+        out[name] = rec
+    out["bit_identical_to_serial"] = bool(same_all)
+    out["sched_error"] = int(any(h.sched_error() for h in hs + [one]))
+    for h in hs + [one]:
+        h.close()
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -715,8 +761,12 @@ def main():
                    "iterations_max": int(fp.max()), "iterations_min": int(fp.min()),
                    "rtn_histogram": {str(int(v)): int(c) for v, c in zip(*np.unique(rt, return_counts=True))}}
         hbm_copy = hbm_copy_gbs(torch, dev)
-    label, clusters, single = None, None, None
+    label, clusters, single, pipelined = None, None, None, None
     if not args.no_secondary and rank == 0:
+        try:
+            pipelined = pipelined_line(torch, dev, batch1, np_dt, params)
+        except Exception as ex:  # a secondary block never takes the line down
+            pipelined = {"error": str(ex)[:200]}
         try:
             single = single_plan_line(dev, not args.no_cpu_baseline and world == 1)
         except Exception as ex:  # a secondary block never takes the line down
@@ -836,6 +886,8 @@ def main():
             line["e2e_host_buffers"] = e2e
         if natural is not None:
             line["natural_exit"] = natural
+        if pipelined is not None:
+            line["pipelined"] = pipelined
         if single is not None:
             line["single_plan_latency"] = single
         if label is not None:

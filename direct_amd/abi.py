@@ -102,6 +102,9 @@ class Config(C.Structure):
 
 # Launch-file values that reach polyCurveGeneration
 # (global_planner/launch/global_planner.launch:11-13, 61-70; teach_repeat_planner.cpp:895-897, 919-921)
+FLAG_STATIC_SCHEDULE, FLAG_YIELD = 1, 2   # direct_ddp_config_t.reserved (include/direct_ddp.h)
+
+
 def phase0_params(**kw):
     """Phase 0: zero init, infeasible start, w = 1/1/1, iter_max_zero = 50."""
     d = dict(max_vel=2.0, max_acc=2.0, w_snap=1.0, w_terminal=1.0, w_time=1.0, iter_max=50,

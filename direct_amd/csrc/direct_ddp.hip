@@ -92,6 +92,15 @@ struct Sched {
   int chunk;
   int prio;           // raise the wave priority of chunks that had to wait for their predecessor
   int tail;           // rounds of help-only tickets behind the last epoch (next_work)
+  // Yielding (DIRECT_FLAG_YIELD: another handle's launch is queued behind this one): a wave that is about to draw a ticket
+  // leaves the kernel instead when more than max(yield_min, yield_k x unfinished trajectories) waves are still inside - a
+  // trajectory needs ONE wave to advance and at most eleven more to help with its line search, the rest only park in
+  // next_work() on tickets of epochs to come and keep the other launch's workgroups off the CUs.  Scheduling only: which
+  // wave runs a ticket never shows in the results (the holder of the earliest unfinished ticket is always among those
+  // that stay).  0: off.
+  int* waves;         // [1] waves of this launch still inside the kernel
+  int* alive;         // [1] trajectories still in their outer loop (Batch::live when the line search is shared)
+  int yield_k, yield_min;
 };
 // The next piece of work for a persistent wave.  `held` < 0: draws the next ticket (epoch, trajectory) = (t / batch,
 // t % batch); else continues to wait with ticket `held` in hand.  Waits for the previous chunk of the ticket's trajectory.
@@ -173,6 +182,20 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
 #pragma unroll 1
   for (;;) {
     int help_v = 0;
+    if (S.yield_k > 0 && held < 0) {
+      int go = 0;
+      if (threadIdx.x == 0) {
+        const int lv = __hip_atomic_load(S.alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int wv = __hip_atomic_load(S.waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int keep = S.yield_k * lv;
+        if (keep < S.yield_min) keep = S.yield_min;
+        if (wv > keep) {
+          if (__hip_atomic_fetch_add(S.waves, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > keep) go = 1;
+          else __hip_atomic_fetch_add(S.waves, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (__builtin_amdgcn_readfirstlane(go)) break;
+    }
     DDP_MARK("X_T");
     const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, SHARE ? B.bshare : nullptr, B.idx, nb, total, total_help, held, &waited, &help_v));
     const int help = __builtin_amdgcn_readfirstlane(help_v);
@@ -209,8 +232,9 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
     if (!help) {
       if (run) W.store_state();
       const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
-      if (run && fin && B.live != nullptr && threadIdx.x == 0)  // this chunk took the trajectory out of its outer loop
-        __hip_atomic_fetch_add(B.live, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int* const alive = B.live != nullptr ? B.live : S.alive;
+      if (run && fin && alive != nullptr && threadIdx.x == 0)  // this chunk took the trajectory out of its outer loop
+        __hip_atomic_fetch_add(alive, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       // max, not store: done_epoch only ever grows, and a trajectory that a timed-out waiter has retired
       // (kDoneBit | n_epochs, below) stays retired when its straggling chunk completes afterwards
@@ -469,6 +493,8 @@ struct direct_ddp_handle_s {
   int pair_trials = -1;  // two line-search steps per forward sweep from the second attempt on: -1 auto, DIRECT_DDP_PAIR=0|1 forces
   int sched_prio = 1;    // chunks that had to wait for their predecessor run at raised wave priority (DIRECT_DDP_PRIO=0: off)
   int sched_tail = 8;    // rounds of help-only tickets behind the last epoch (DIRECT_DDP_TAIL=0: none; next_work)
+  int yield_k = 0;       // DIRECT_FLAG_YIELD / DIRECT_DDP_YIELD=k: surplus waves leave the hot kernel (Sched::yield_k); 0 = off
+  int* nwaves = nullptr; // device [16]: waves inside the kernel, per class launch
   bool dynamic = true;
   // current batch
   int B = 0;
@@ -714,6 +740,15 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.chunk = h->sched_chunk;
       S.prio = h->sched_prio;
       S.tail = help ? h->sched_tail : 0;
+      S.waves = h->nwaves + (ci < 16 ? ci : 15);
+      S.alive = h->live + (ci < 16 ? ci : 15);
+      S.yield_k = h->yield_k;
+      S.yield_min = 64;
+      if (h->yield_k > 0) {
+        S.tail = 0;  // help-only tickets would keep every wave inside until the last chunk
+        (void)hipMemsetD32Async((hipDeviceptr_t)S.waves, slots, 1, st);
+        (void)hipMemsetD32Async((hipDeviceptr_t)S.alive, c.cnt, 1, st);
+      }
       if (help) {
         Bt.help = h->help;
         Bt.help_early = h->help_early;
@@ -940,6 +975,10 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   }
   A(&h->T_next, B * nm * r); A(&h->infeas_next, B);
   h->dynamic = !(cfg->reserved & DIRECT_FLAG_STATIC_SCHEDULE);
+  // measured (two handles, B = 4096, N = 100, natural exits; M iter/s): k = 12: 1.96, 6: 2.05, 3: 2.15, 2: 2.24, 1: 2.37 (serial 1.76);
+  // three or four handles in rotation are no better (2.26 / 2.08): tools/pipeline_bench.py, profiles/r06_pipeline.json
+  if (cfg->reserved & DIRECT_FLAG_YIELD) h->yield_k = 1;
+  if (const char* ev = getenv("DIRECT_DDP_YIELD")) h->yield_k = std::max(0, std::min(atoi(ev), 64));
   if (const char* ev = getenv("DIRECT_DDP_SCHED")) h->dynamic = std::string(ev) != "static";
   h->n_cu = prop.multiProcessorCount;
   if (const char* ev = getenv("DIRECT_DDP_SLOTS")) h->slots_cap = atoi(ev) > 0 ? atoi(ev) : 0;  // experiments: fewer persistent waves than fit
@@ -992,6 +1031,7 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->sched, (B + 2) * sizeof(int));
   A(&h->visits, 4 * sizeof(unsigned long long));  // [0] backward knots, [1] forward trial-knots, [2] knots whose front half a helper computed, [3] accepted line searches
   A(&h->live, 16 * sizeof(int));
+  A(&h->nwaves, 16 * sizeof(int));
   A(&h->tickets, 16 * sizeof(int));
   A(&h->order, B * sizeof(int32_t)); A(&h->cls_dev, B * sizeof(int32_t));
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;

@@ -103,11 +103,11 @@ def time_allocation(n_seg, start, goal, seeds, max_vel=2.0, max_acc=2.0):
 class DdpSolver:
     """One handle = one GPU; reusable across calls (the reference object is single-use, quirk Q9)."""
 
-    def __init__(self, max_batch, n_seg_max, p_max, dtype=np.float32, device=0):
+    def __init__(self, max_batch, n_seg_max, p_max, dtype=np.float32, device=0, flags=0):
         self.np_dtype = np.dtype(dtype)
         self.dtype = abi.F64 if self.np_dtype == np.float64 else abi.F32
         self.max_batch, self.n_seg_max, self.p_max = int(max_batch), int(n_seg_max), int(p_max)
-        cfg = abi.Config(self.dtype, device, self.max_batch, self.n_seg_max, self.p_max, 0)
+        cfg = abi.Config(self.dtype, device, self.max_batch, self.n_seg_max, self.p_max, int(flags))  # DIRECT_FLAG_* of include/direct_ddp.h
         h = C.c_void_p()
         _check(lib().direct_ddp_create(C.addressof(cfg), C.addressof(h)))
         self.h = h

@@ -156,6 +156,15 @@ typedef struct {
  * tickets behind its last epoch: waves that would otherwise leave the kernel wait for a trajectory's last chunk and join
  * its open line searches - the slowest chains end the launch (0: none; bitwise-equality test as for the others). */
 #define DIRECT_FLAG_STATIC_SCHEDULE 1
+/* Pipelined batches (the reference's contract: an independent optimiser object per call, teach_repeat_planner.cpp:853-854):
+ * create TWO handles with this flag, give each a stream of its own (direct_ddp_set_stream) and alternate device-memory
+ * direct_ddp_solve_batch / direct_ddp_plan_batch calls between them - each call returns once its kernels are enqueued.
+ * The hot kernel is a grid of persistent waves that normally stay until the launch's last chunk (parked on tickets of epochs
+ * to come, or as helpers); with the flag the waves a launch no longer needs (more than one per unfinished trajectory, 64 at
+ * least) leave as soon as they would draw their next ticket and no help-only tickets are handed out, so that the OTHER handle's next
+ * launch fills the CUs this launch's slowest chains leave idle.  Results are bit-identical to serial launches
+ * (tests/test_gpu_fullsize.py); DIRECT_DDP_YIELD=k sets the waves kept per unfinished trajectory (0: off). */
+#define DIRECT_FLAG_YIELD 2
 
 typedef struct direct_ddp_handle_s* direct_ddp_handle_t;
 

@@ -312,6 +312,41 @@ def test_shared_backward_sweep_is_bitwise_equal_to_the_owner_only_sweep(built, d
         assert knots["1"][1] > 0, knots
 
 
+@pytest.mark.parametrize("dt,nb,kind", [(np.float32, B, "free"), (np.float64, 1500, "corridor"), (np.float32, 9000, "corridor")])
+def test_pipelined_batches_on_two_yielding_handles_are_bit_identical_to_serial_launches(built, dt, nb, kind):
+    """DIRECT_FLAG_YIELD: two handles with a stream each, device-memory calls alternating between them - the waves a launch
+    no longer needs leave the hot kernel early so that the other handle's launch fills the CUs (include/direct_ddp.h).  Which
+    wave runs which ticket, and next to which other launch, must not show: natural exits and the fixed-20 launch of six
+    pipelined batches against one serial launch of an ordinary handle, every output bit for bit, no scheduler error."""
+    import torch
+    from direct_amd import devmem
+    dev = torch.device("cuda:0")
+    batch = problems.make_batch(kind, nb, N, seed=700 + nb).astype(dt)
+    one = solver.DdpSolver(nb, N, batch.p_max, dt)
+    g0 = one.solve(abi.phase0_params(), batch)
+    b1 = batch.phase1_inputs(g0)
+    din = devmem.DeviceBatch(b1, dev)
+    ref = devmem.DeviceResult(nb, N, dt, dev)
+    hs = [solver.DdpSolver(nb, N, batch.p_max, dt, flags=abi.FLAG_YIELD) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for h, st in zip(hs, streams):
+        h.set_stream(st.cuda_stream)
+    outs = [devmem.DeviceResult(nb, N, dt, dev) for _ in range(6)]
+    for p in (abi.phase1_params(iter_max=20, fixed_iters=1), abi.phase1_params(iter_max=40)):
+        one.solve_device(p, din.cin, ref.cout)
+        torch.cuda.synchronize()
+        for i in range(6):
+            hs[i % 2].solve_device(p, din.cin, outs[i].cout)
+        torch.cuda.synchronize()
+        assert one.sched_error() == 0 and all(h.sched_error() == 0 for h in hs)
+        for i in range(6):
+            for k in ref.t:
+                assert torch.equal(outs[i].t[k], ref.t[k]), (i, k, p.fixed_iters)
+        assert int(ref.t["fwd_passes"].sum().item()) > 10 * nb
+    for h in hs + [one]:
+        h.close()
+
+
 def test_a_lone_trajectory_with_hundreds_of_waiters_on_its_shared_sweep(built, monkeypatch):
     """B = 1, N = 100, 320 fixed iterations: the ticket scheduler hands out n_epochs + tail tickets for the ONE trajectory and
     every holder polls its open sweep - far more than the 255 an 8-bit helper count could hold (the carry went
