@@ -482,11 +482,23 @@ __device__ __forceinline__ int ray_walk_pipe(const Dev& D, const uint8_t* fl, co
 // the tests in front of a walk as k_convex runs them: the reference's two, then the box test
 // (any_target: the kernel-level entry point takes arbitrary targets; inside polygonGeneration a target is a cluster voxel or
 // a candidate, and neither lies inside the cube: CS:491-494, 301-353)
-__device__ __forceinline__ int ray_needs_walk(const Dev& D, const uint8_t* fl, int cx, int cy, int cz, int target, int any_target) {
+// Inside polygonGeneration inside_data is the strict interior of the inflated cube and nothing else (k_inflate writes it
+// once, CS:441-494; no later kernel touches the bit): the midpoint test is three range compares on the cube's corners instead
+// of a scattered byte load per ray - a third of the loads in front of the walks (12 G rays per 64-seed call).  The kernel-level
+// entry point (FULL) takes an arbitrary inside_data array and keeps the load.
+struct CubeBox {
+  int x0, x1, y0, y1, z0, z1;  // inside <=> x0 < x < x1 && y0 < y < y1 && z0 < z < z1
+};
+template <bool FULL>
+__device__ __forceinline__ int ray_needs_walk(const Dev& D, const uint8_t* fl, const CubeBox& cb, int cx, int cy, int cz, int target) {
   const int ex = px(target), ey = py(target), ez = pz(target);
-  if (any_target && (fl[(unsigned)(ex * D.max_yz + ey * D.max_z + ez)] & F_INSIDE)) return 0;
+  if (FULL && (fl[(unsigned)(ex * D.max_yz + ey * D.max_z + ez)] & F_INSIDE)) return 0;
   const int mx = cx / 2 + (ex >> 1), my = cy / 2 + (ey >> 1), mz = cz / 2 + (ez >> 1);
-  if (fl[(unsigned)(mx * D.max_yz + my * D.max_z + mz)] & F_INSIDE) return 0;
+  if (FULL) {
+    if (fl[(unsigned)(mx * D.max_yz + my * D.max_z + mz)] & F_INSIDE) return 0;
+  } else if ((mx > cb.x0) & (mx < cb.x1) & (my > cb.y0) & (my < cb.y1) & (mz > cb.z0) & (mz < cb.z1)) {
+    return 0;
+  }
   return box_obstacles(D, cx < ex ? cx : ex, cy < ey ? cy : ey, cz < ez ? cz : ez, cx < ex ? ex : cx, cy < ey ? ey : cy,
                        cz < ez ? ez : cz) != 0;
 }
@@ -528,18 +540,20 @@ __global__ __launch_bounds__(256) void k_chunk_box(Dev D) {
 }
 
 // one workgroup per candidate.  full = 1 (kernel-level parity entry point): no early exit, every row is complete
-__device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, int i, int full);
+template <bool FULL>
+__device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, int i);
 // A workgroup takes the candidates blockIdx.x, blockIdx.x + gridDim.x, ... of its seed: the grid is sized for the
 // typical shell (a few thousand candidates), not for the candidate CAPACITY - one workgroup per capacity slot meant
 // 640 k workgroups per round for 64 seeds, nine in ten of which only looked at n_cand and left (44 M wave launches per
 // call, ~10 % of the kernel's time).
-__global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_convex(Dev D) {
   const int e = blockIdx.y;
   const Elem* E = &D.el[e];
   if (!E->live) return;
   const int n_cand = E->n_cand;
   for (int i = blockIdx.x; i < n_cand; i += gridDim.x) {
-    convex_one(D, E, e, i, full);
+    convex_one<FULL>(D, E, e, i);
     __syncthreads();  // the next candidate reuses the workgroup's LDS
   }
 }
@@ -548,8 +562,13 @@ __global__ __launch_bounds__(256) void k_convex(Dev D, int full) {
 #else
 #define WALK ray_walk_pipe
 #endif
-__device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, int i, int full) {
+template <bool FULL>
+__device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, int i) {
+  constexpr int full = FULL ? 1 : 0;
   const int tid = threadIdx.x;
+  // the inflated cube (k_inflate: E->vertex; corner 7 is its low, corner 1 / 9 / 17 its high end per axis)
+  CubeBox cb;
+  cb.x0 = E->vertex[7]; cb.x1 = E->vertex[1]; cb.y0 = E->vertex[15]; cb.y1 = E->vertex[9]; cb.z0 = E->vertex[23]; cb.z1 = E->vertex[17];
   const uint8_t* fl = D.flags + (size_t)e * D.G;
   const int* cl = D.cluster + (size_t)e * D.ccap;
   const int* cd = D.cand + (size_t)e * D.kcap;
@@ -600,7 +619,7 @@ __device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, i
     int tgt = 0, need = 0;
     if (t < n_clu) {
       tgt = cl[t];
-      need = ray_needs_walk(D, fl, cx, cy, cz, tgt, full);
+      need = ray_needs_walk<FULL>(D, fl, cb, cx, cy, cz, tgt);
     }
     push(need, tgt);
     if (count >= 64) {
@@ -638,7 +657,7 @@ __device__ __forceinline__ void convex_one(const Dev& D, const Elem* E, int e, i
   __syncthreads();
   for (int base = 0; base < i; base += 256) {
     const int j = base + tid;
-    push(j < i ? ray_needs_walk(D, fl, cx, cy, cz, cd[j], full) : 0, j);
+    push(j < i ? ray_needs_walk<FULL>(D, fl, cb, cx, cy, cz, cd[j]) : 0, j);
     if (count >= 64) {
       const int jq = take(64);
       if (WALK(D, fl, inv, cx, cy, cz, cd[jq], 1)) atomicOr(&srow[jq >> 6], 1ull << (jq & 63));
@@ -1136,7 +1155,7 @@ direct_status_t direct_cluster_polygon_generation_batch(direct_cluster_handle_t 
       // 1.6 - 2 x slower: thousands of short workgroups balance the seeds' very different loads better, and the flag
       // bytes of a round's rays live in L2 anyway)
       hipLaunchKernelGGL(k_chunk_box, dim3(D.nchunk, batch), dim3(256), 0, h->stream, D);
-      hipLaunchKernelGGL(k_convex, dim3(std::min(D.kcap, h->convex_grid), batch), dim3(256), 0, h->stream, D, 0);
+      hipLaunchKernelGGL(k_convex<false>, dim3(std::min(D.kcap, h->convex_grid), batch), dim3(256), 0, h->stream, D);
       if (D.kwords <= 256) {
         hipLaunchKernelGGL(k_resolve_fast, dim3(batch), dim3(64), 0, h->stream, D);
         hipLaunchKernelGGL(k_apply, dim3((D.kcap + 255) / 256, batch), dim3(256), 0, h->stream, D);
@@ -1212,7 +1231,7 @@ direct_status_t direct_cluster_convex_test(direct_cluster_handle_t h, const uint
   CHIP_TRY(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(k_flags_init, dim3(std::min((D.G + 255) / 256, 4096), 1), dim3(256), 0, h->stream, D, (const uint8_t*)h->inside_tmp);
   hipLaunchKernelGGL(k_chunk_box, dim3(D.nchunk, 1), dim3(256), 0, h->stream, D);
-  hipLaunchKernelGGL(k_convex, dim3(n_candidate, 1), dim3(256), 0, h->stream, D, 1);
+  hipLaunchKernelGGL(k_convex<true>, dim3(n_candidate, 1), dim3(256), 0, h->stream, D);
   hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), (size_t)D.kwords * 8, h->stream, D, 1);
   CHIP_TRY(hipGetLastError());
   CHIP_TRY(hipEventRecord(h->ev1, h->stream));
