@@ -1,4 +1,4 @@
-"""N = 100 parity report (tests/n100_lib.py) -> gpurun_out/r05_n100_parity.json.  Run on the GPU box:
+"""N = 100 parity report (tests/n100_lib.py) -> gpurun_out/<ROUND>_n100_parity.json (environment ROUND, default r06).  Run on the GPU box:
 python tests/soak/n100_report.py [n_sample].  The bounded form of the same comparisons is tests/test_gpu_n100.py."""
 import json
 import os
@@ -63,4 +63,4 @@ for name, kind in (("timed_launch_config2", "free"), ("timed_launch_config3", "c
     rep[name] = rec
     print(name, "%.0f s" % (time.time() - t0), json.dumps(rec), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rep, open("gpurun_out/r05_n100_parity.json", "w"), indent=1)
+json.dump(rep, open("gpurun_out/%s_n100_parity.json" % os.environ.get("ROUND", "r06"), "w"), indent=1)

@@ -1,5 +1,5 @@
 """Randomised parity soak REPORT (GPU): the full protocol of tests/soak_lib.py on 36 batches (2304 solves), device vs
-oracle next to the oracle-vs-itself control, plus the float-storage distribution.  Writes gpurun_out/r05_parity_soak.json
+oracle next to the oracle-vs-itself control, plus the float-storage distribution.  Writes gpurun_out/<ROUND>_parity_soak.json (environment ROUND, default r06)
 (copy into profiles/).  usage: python tests/soak/parity_soak.py [n_batches]"""
 import json
 import os
@@ -30,5 +30,5 @@ rep = dict(protocol="tests/soak_lib.py: %d batches x 32 problems x 2 phases, fp6
                             max_dev_after_first_iteration=early),
            float_storage_vs_fp64_oracle=soak_lib.float_storage_distribution(plan, nb))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rep, open("gpurun_out/r05_parity_soak.json", "w"), indent=1)
+json.dump(rep, open("gpurun_out/%s_parity_soak.json" % os.environ.get("ROUND", "r06"), "w"), indent=1)
 print(json.dumps(rep, indent=1))
