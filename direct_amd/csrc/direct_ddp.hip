@@ -786,8 +786,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       if (is_big && li.shared_sweep) li.shared_sweep = 0;
       RPL_LAUNCH(c.rpl, st, k_iterate, Real, c.cnt, Bt, n);
     }
-    static const bool no_stuck = getenv("DIRECT_DDP_NO_STUCK") != nullptr;  // timing probes only: rtn = -4 solves stay parked
-    if (!no_stuck) {  // trajectories whose backward pass got stuck finish their last trip here (rare; every other workgroup returns at once)
+    {  // trajectories whose backward pass got stuck finish their last trip here (rare; every other workgroup returns at once)
       auto Bs = make_batch<Real>(h, h->cur_in, h->params, c);
       Bs.visits = h->visits;
       RPL_LAUNCH(c.rpl, st, k_stuck, Real, c.cnt, Bs);

@@ -288,3 +288,25 @@ def test_emulated_split_backward_sweep_is_bitwise_the_fused_one(kind, N, B, seed
             assert knots[0] == 0 and knots[1] == B * max(N - 2, 0), knots
             for f in ("rtn", "iter_used", "fwd_passes", "cost", "costq", "opterr", "mu", "T", "poly", "bez"):
                 assert np.array_equal(getattr(res[0], f), getattr(res[1], f)), (f, dtype, params.zero_init)
+
+
+def test_phase1_inputs_reproduce_the_callers_hand_off_where_phase_0_fails():
+    """HostBatch.phase1_inputs (the host twin of k_chain): where phase 0 does not return 2 the reference converts its control
+    points back with the CALLER's durations (TRP:911-921; DDP:799-812 then 167-193), i.e. coefficient c_i scaled by
+    (T_0 / T_1)^(i-1).  Phase 0 cut short so that no problem returns 2; emulated phase 1 from the monomial and from the
+    Bezier form of the hand-off against the oracle's fused plan; the unscaled monomials (what round 5 handed over) are far off."""
+    batch = problems.make_batch("corridor", 8, 12, seed=123)
+    p0, p1 = abi.phase0_params(iter_max=4), abi.phase1_params(infeas=1)
+    r0, r1 = refapi.plan_batch(p0, p1, batch)
+    assert (r0.rtn != 2).all()
+    e0 = emuapi.solve_batch(p0, batch)
+    for mono in (True, False):
+        e1 = emuapi.solve_batch(p1, batch.phase1_inputs(e0, monomial=mono))
+        assert (e1.rtn == r1.rtn).all() and (e1.iter_used == r1.iter_used).all()
+        assert np.abs(e1.cost / r1.cost - 1).max() < 1e-8, mono
+    old = emuapi.solve_batch(p1, batch.with_init(None, T0=batch.T0, infeas_in=e0.infeas_out.astype(np.uint8), init_poly=e0.poly))
+    assert np.abs(old.cost / r1.cost - 1).max() > 1e-2
+    # where phase 0 succeeds the factor is exactly one
+    q0 = emuapi.solve_batch(abi.phase0_params(), batch)
+    ok = q0.rtn == 2
+    assert ok.any() and np.array_equal(batch.phase1_inputs(q0).init_poly[ok], q0.poly[ok])
