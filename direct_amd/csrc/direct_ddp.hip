@@ -98,6 +98,7 @@ struct Sched {
   // next_work() on tickets of epochs to come and keep the other launch's workgroups off the CUs.  Scheduling only: which
   // wave runs a ticket never shows in the results (the holder of the earliest unfinished ticket is always among those
   // that stay).  0: off.
+  int* dbg;           // [12] what a wait that ran into the spin limit saw (direct_ddp_sched_debug)
   int* waves;         // [1] waves of this launch still inside the kernel
   int* alive;         // [1] trajectories still in their outer loop (Batch::live when the line search is shared)
   int yield_k, yield_min;
@@ -131,7 +132,21 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
   const int b = idx ? __builtin_amdgcn_readfirstlane(idx[bi]) : bi;  // done_epoch / slots are indexed by the trajectory's own number
   int ready = (e == 0) ? 1 : 0, have = 0, wanted = 0;
   int spins = 0;
+  const unsigned long long wait_t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz (diagnostics of a timeout only)
+#if defined(DDP_SCHED_DEBUG)  // development builds: how many waves wait / run, and a snapshot a quarter of a second into a long wait
+  if (!ready && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[12], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int was_waiting = !ready;
+#endif
   for (; !ready && !wanted && spins < (1 << 22); spins++) {
+#if defined(DDP_SCHED_DEBUG)
+    if (spins == (1 << 18) && threadIdx.x == 0 && __hip_atomic_exchange(&S.dbg[23], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      S.dbg[16] = (int)t; S.dbg[17] = e; S.dbg[18] = S.done_epoch[b];
+      S.dbg[19] = (int)__hip_atomic_load(S.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      S.dbg[20] = __hip_atomic_load(&S.dbg[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      S.dbg[21] = __hip_atomic_load(&S.dbg[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      S.dbg[22] = (int)((__builtin_amdgcn_s_memrealtime() - wait_t0) / 100000ull);
+    }
+#endif
     int hv = 0, g = 0, r = 0, lr = 0, sw = 0;
     if (threadIdx.x == 0) {
       hv = __hip_atomic_load(&S.done_epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -153,6 +168,9 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
     if (!ready && !wanted && __builtin_amdgcn_readfirstlane(sw)) wanted = 2;
     if (!ready && !wanted) __builtin_amdgcn_s_sleep(32);
   }
+#if defined(DDP_SCHED_DEBUG)
+  if (was_waiting && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[12], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   if (spins > 1 || wanted) *waited = 1;
   if (wanted) {
     *help = wanted;
@@ -160,7 +178,21 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
   }
   if (!ready) {  // a scheduling bug: never a hang, and never a chunk run on a trajectory whose previous chunk
                  // may still be in flight elsewhere.  The flag is sticky until the next solve (direct_ddp.h).
-    if (threadIdx.x == 0) __hip_atomic_store(S.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(S.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (S.dbg != nullptr && __hip_atomic_exchange(&S.dbg[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {  // the first one only
+        S.dbg[0] = (int)t; S.dbg[1] = e; S.dbg[2] = b; S.dbg[3] = have;
+        S.dbg[4] = (int)__hip_atomic_load(S.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.dbg[5] = S.waves ? __hip_atomic_load(S.waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        S.dbg[6] = S.alive ? __hip_atomic_load(S.alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        S.dbg[8] = (int)((__builtin_amdgcn_s_memrealtime() - wait_t0) / 100000ull);  // the wait in milliseconds
+        S.dbg[9] = (int)nb; S.dbg[10] = (int)total; S.dbg[11] = spins;
+#if defined(DDP_SCHED_DEBUG)
+        S.dbg[14] = __hip_atomic_load(&S.dbg[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // waves waiting / running chunks at the timeout
+        S.dbg[15] = __hip_atomic_load(&S.dbg[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      }
+    }
     return -3 - b;
   }
   if (have >= kDoneBit || t >= total) return -2;
@@ -228,7 +260,13 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
       const int left = n_iters - e * S.chunk;
       n = left < S.chunk ? left : S.chunk;
     }
+#if defined(DDP_SCHED_DEBUG)
+    if (!help && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[13], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     if (run) W.iterate(n, help);
+#if defined(DDP_SCHED_DEBUG)
+    if (!help && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[13], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     if (!help) {
       if (run) W.store_state();
       const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
@@ -495,6 +533,7 @@ struct direct_ddp_handle_s {
   int sched_tail = 8;    // rounds of help-only tickets behind the last epoch (DIRECT_DDP_TAIL=0: none; next_work)
   int yield_k = 0;       // DIRECT_FLAG_YIELD / DIRECT_DDP_YIELD=k: surplus waves leave the hot kernel (Sched::yield_k); 0 = off
   int* nwaves = nullptr; // device [16]: waves inside the kernel, per class launch
+  int* sched_dbg = nullptr;  // device [8]: Sched::dbg
   bool dynamic = true;
   // current batch
   int B = 0;
@@ -740,6 +779,7 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.chunk = h->sched_chunk;
       S.prio = h->sched_prio;
       S.tail = help ? h->sched_tail : 0;
+      S.dbg = h->sched_dbg;
       S.waves = h->nwaves + (ci < 16 ? ci : 15);
       S.alive = h->live + (ci < 16 ? ci : 15);
       S.yield_k = h->yield_k;
@@ -1031,6 +1071,8 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->visits, 4 * sizeof(unsigned long long));  // [0] backward knots, [1] forward trial-knots, [2] knots whose front half a helper computed, [3] accepted line searches
   A(&h->live, 16 * sizeof(int));
   A(&h->nwaves, 16 * sizeof(int));
+  A(&h->sched_dbg, 24 * sizeof(int));
+  if (st == DIRECT_OK && hipMemset(h->sched_dbg, 0, 24 * sizeof(int)) != hipSuccess) st = fail(DIRECT_ERR_DEVICE, "hipMemset");
   A(&h->tickets, 16 * sizeof(int));
   A(&h->order, B * sizeof(int32_t)); A(&h->cls_dev, B * sizeof(int32_t));
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
@@ -1509,6 +1551,12 @@ direct_status_t direct_ddp_last_counters(direct_ddp_handle_t h, uint64_t* out4) 
   return DIRECT_OK;
 }
 
+direct_status_t direct_ddp_sched_debug(direct_ddp_handle_t h, int32_t* out24) {
+  if (!h || !out24) return fail(DIRECT_ERR_INVALID, "null argument");
+  HIP_TRY(hipMemcpyAsync(out24, h->sched_dbg, 24 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DIRECT_OK;
+}
 direct_status_t direct_ddp_sched_error(direct_ddp_handle_t h, int32_t* flag) {
   if (!h || !flag) return fail(DIRECT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(h->device));

@@ -23,7 +23,7 @@ EXPORTS = (
     "direct_ddp_set_stream", "direct_ddp_solve_batch", "direct_ddp_plan_batch", "direct_time_allocation",
     "direct_ddp_begin", "direct_ddp_backward_pass", "direct_ddp_forward_pass", "direct_ddp_forward_pass_stored", "direct_ddp_iterate",
     "direct_ddp_finish", "direct_ddp_get_field", "direct_ddp_set_field", "direct_ddp_last_kernel_ms",
-    "direct_ddp_best_cost", "direct_ddp_sched_error", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
+    "direct_ddp_best_cost", "direct_ddp_sched_error", "direct_ddp_sched_debug", "direct_traj_sample_batch", "direct_traj_sample_last_ms",
     "direct_rccl_unique_id", "direct_rccl_comm_create", "direct_rccl_comm_destroy", "direct_ddp_gather_best",
     "direct_corridor_wire_size", "direct_corridor_pack", "direct_corridor_unpack", "direct_corridor_replay_batch",
     "direct_ddp_last_launch_info", "direct_ddp_last_counters",
@@ -65,6 +65,8 @@ def lib():
         L.direct_ddp_best_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p]
         L.direct_ddp_sched_error.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "direct_ddp_sched_debug"):
+            L.direct_ddp_sched_debug.argtypes = [C.c_void_p, C.c_void_p]
         if hasattr(L, "direct_ddp_last_launch_info"):  # absent from libraries of earlier rounds (tools/ab_libs.sh A/B runs)
             L.direct_ddp_last_launch_info.argtypes = [C.c_void_p, C.c_void_p]
         if hasattr(L, "direct_ddp_last_counters"):
@@ -307,6 +309,15 @@ class DdpSolver:
         v = C.c_int32()
         _check(lib().direct_ddp_sched_error(self.h, C.addressof(v)))
         return v.value
+
+    def sched_debug(self):
+        """what the first wait that ran into the spin limit saw (include/direct_ddp.h, direct_ddp_sched_debug)"""
+        v = (C.c_int32 * 24)()
+        _check(lib().direct_ddp_sched_debug(self.h, v))
+        return dict(zip(("ticket", "epoch", "trajectory", "done_epoch", "ticket_counter", "waves", "alive", "set", "wait_ms", "batch",
+                         "tickets", "spins", "dbg_waiting_now", "dbg_running_now", "dbg_waiting_at_timeout", "dbg_running_at_timeout",
+                         "dbg_early_ticket", "dbg_early_epoch", "dbg_early_done_epoch", "dbg_early_counter", "dbg_early_waiting",
+                         "dbg_early_running", "dbg_early_ms", "dbg_early_set"), list(v)))
 
     def best_cost(self, cost, rtn, mem=abi.MEM_HOST, batch=None):
         """(index, cost) of the cheapest trajectory with rtn >= 0.  cost/rtn: numpy arrays or raw pointers."""

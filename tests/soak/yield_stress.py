@@ -1,0 +1,51 @@
+"""Stress of DIRECT_FLAG_YIELD (not a pytest test): for several batch sizes R pipelined launches on two yielding handles must
+reproduce one serial launch of an ordinary handle bit for bit, natural exits and fixed-20, scheduler error flags clear.
+usage: python tests/soak/yield_stress.py [launches per size]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from direct_amd import abi, devmem, problems, solver  # noqa: E402
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda:0")
+total = 0
+SIZES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None
+for B, kind, dt in ((1, "corridor", np.float32), (33, "free", np.float32), (700, "corridor", np.float64), (3100, "free", np.float32),
+                    (4096, "corridor", np.float32), (4600, "free", np.float32), (9000, "corridor", np.float32)):
+    if SIZES is not None and B not in SIZES:
+        continue
+    b = problems.make_batch(kind, B, 100, seed=6000 + B).astype(dt)
+    one = solver.DdpSolver(B, 100, b.p_max, dt)
+    g0 = one.solve(abi.phase0_params(), b)
+    din = devmem.DeviceBatch(b.phase1_inputs(g0), dev)
+    ref = devmem.DeviceResult(B, 100, dt, dev)
+    hs = [solver.DdpSolver(B, 100, b.p_max, dt, flags=abi.FLAG_YIELD) for _ in range(2)]
+    st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for h, s in zip(hs, st):
+        h.set_stream(s.cuda_stream)
+    outs = [devmem.DeviceResult(B, 100, dt, dev) for _ in range(4)]
+    for p in (abi.phase1_params(iter_max=20, fixed_iters=1), abi.phase1_params(iter_max=40)):
+        one.solve_device(p, din.cin, ref.cout)
+        torch.cuda.synchronize()
+        for base in range(0, R, 4):
+            for i in range(4):
+                hs[i % 2].solve_device(p, din.cin, outs[i].cout)
+            torch.cuda.synchronize()
+            for i in range(4):
+                for k in ref.t:
+                    if not torch.equal(outs[i].t[k], ref.t[k]):
+                        d = torch.nonzero((outs[i].t[k] != ref.t[k]).reshape(B, -1).any(dim=1)).flatten()
+                        idx = d[:5].cpu().numpy()
+                        raise SystemExit("MISMATCH B=%d %s fixed=%d launch %d field %s: %d trajectories, first %s; rtn %s vs %s, fwd_passes %s vs %s, sched_error %s"
+                                         % (B, kind, p.fixed_iters, base + i, k, len(d), idx, outs[i].t["rtn"][idx].cpu().numpy(), ref.t["rtn"][idx].cpu().numpy(),
+                                            outs[i].t["fwd_passes"][idx].cpu().numpy(), ref.t["fwd_passes"][idx].cpu().numpy(), [(h.sched_error(), h.sched_debug()) for h in hs])
+                                         + " fwd_passes min %d" % int(outs[i].t["fwd_passes"].min().item()))
+            total += 4
+        assert one.sched_error() == 0 and all(h.sched_error() == 0 for h in hs)
+    for h in hs + [one]:
+        h.close()
+    print("B = %d (%s, %s): %d pipelined launches per workload reproduce the serial launch" % (B, kind, np.dtype(dt).name, R), flush=True)
+print("ok: %d launches" % total)
