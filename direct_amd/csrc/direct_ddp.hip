@@ -85,6 +85,9 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
 // (agent-scope release / acquire).  The holder of an earlier ticket is always resident and running, so
 // the wait cannot deadlock; a spin limit turns a scheduling bug into an error code instead of a hang.
 constexpr int kDoneBit = 1 << 30;  // in done_epoch[b]: the trajectory has left the outer loop
+#ifndef DDP_POLL_SLEEP
+#define DDP_POLL_SLEEP 32  // s_sleep units (64 clocks) between two polls of a waiting wave (next_work)
+#endif
 struct Sched {
   unsigned* ticket;   // [1] next ticket
   int* done_epoch;    // [batch] chunks completed per trajectory
@@ -166,7 +169,7 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
     ready = (have >= e) ? 1 : 0;
     wanted = (!ready && __builtin_amdgcn_readfirstlane((g != 0 && r <= lr) ? 1 : 0)) ? 1 : 0;
     if (!ready && !wanted && __builtin_amdgcn_readfirstlane(sw)) wanted = 2;
-    if (!ready && !wanted) __builtin_amdgcn_s_sleep(32);
+    if (!ready && !wanted) __builtin_amdgcn_s_sleep(DDP_POLL_SLEEP);
   }
 #if defined(DDP_SCHED_DEBUG)
   if (was_waiting && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[12], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
