@@ -416,6 +416,15 @@ struct HelpSlot {
   int pad[4];
   TrialRes res[12];
 };
+// Polls after which a wait inside a launch (for a helper's record, a helper to leave, a trajectory's previous chunk:
+// direct_ddp.hip, next_work) counts as a scheduling error instead of hanging.  Round 6: 2^26 (a minute or more) instead of
+// 2^22 (1 - 5 s) - with two handles' kernels running next to each other, one launch in ~5000 saw a seventeenth of its waves
+// stand still for 13 - 15 s and then go on (not a lost update, not a deadlock: with the longer limit every one of 25 600 stress
+// launches completed bit-identically, two groups of four in 15.2 and 13.3 s instead of 0.3).
+#ifndef DDP_SPIN_LIMIT_LOG2
+#define DDP_SPIN_LIMIT_LOG2 26
+#endif
+constexpr int kSpinLimit = 1 << DDP_SPIN_LIMIT_LOG2;
 constexpr int kMaxBuf = 12;  // iterate buffers: `cur` + one per concurrently evaluated step, 0 .. 10 (3 without helpers)
 
 // ---- helper-assisted backward sweep (scheduling only, see Wave::bwd_sweep_t) -----------------------
@@ -490,6 +499,12 @@ struct Batch {
   int bforce;        // tests: the owner itself runs the helpers' half first (every knot but its first claim goes through a record)
   const void* self;  // this very struct in device memory: what the out-of-line halves of a shared sweep (front_cold, back_cold) are handed
   unsigned long long* bvisits;  // [1] knots whose front half a helper (or the forced split) computed (observability; may be null)
+#if defined(DDP_SCHED_DEBUG)   // development builds: where every persistent wave of the launch currently is (direct_ddp.hip, next_work's time-out record)
+  int* mark;                   // [grid]
+#define DDP_DBG_MARK(Bq, v) do { if ((Bq).mark != nullptr && threadIdx.x == 0) (Bq).mark[blockIdx.x] = (v); } while (0)
+#else
+#define DDP_DBG_MARK(Bq, v) ((void)0)
+#endif
 #if defined(DDP_TIMELINE)  // debug builds (tools/timeline.py): wall-clock stamps per trajectory and outer iteration
   unsigned long long* tl;  // [B][kTimelineDepth][4]: start, end of the backward sweeps, end (100 MHz), knots that came through records
 #endif
@@ -1609,7 +1624,7 @@ struct Wave {
     int spins = 0;
     while (a_load(flag_ptr(k)) != tag) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 22)) {
+      if (++spins > kSpinLimit) {
         proto_error();
         return 0;
       }
@@ -1647,7 +1662,7 @@ struct Wave {
     while (inside) {
       __builtin_amdgcn_s_sleep(2);
       inside = a_load((int*)&bs->word) & (int)kBsCountMask;
-      if (++spins > (1 << 22)) {
+      if (++spins > kSpinLimit) {
         proto_error();
         break;
       }
@@ -2809,7 +2824,7 @@ struct Wave {
     int spins = 0;
     while (a_load(&hs->active) != 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 22)) {
+      if (++spins > kSpinLimit) {
         proto_error();
         break;
       }
@@ -2867,7 +2882,7 @@ struct Wave {
     int spins = 0;
     while (a_load(&hs->done[r]) != tag) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1 << 22)) {
+      if (++spins > kSpinLimit) {
         proto_error();
         return 0;
       }
@@ -3401,6 +3416,7 @@ struct Wave {
     while (true) {
       int mine = (helper || opened) ? share_claim(hs) : r_eval;
       if (mine > last_round) mine = -1;
+      DDP_DBG_MARK(B, (helper ? 200 : 100) + (mine < 0 ? 99 : mine));
       if (helper && (mine < 0 || share_cancelled(hs))) break;
       TrialRes res[2];
       res[0].alive = 0;
@@ -3724,7 +3740,9 @@ struct Wave {
           bs_leave(bsf);
           return;
         }
+        DDP_DBG_MARK(B, 11);
         if (bwd_sweep()) break;
+        DDP_DBG_MARK(B, 12);
         note_failed_sweep();
         if (st.reg == 24 && st.bp_failed) st.bp_no_upd++;
         else st.bp_no_upd = 0;
@@ -3745,13 +3763,16 @@ struct Wave {
 #if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
     if (tl_ != nullptr && threadIdx.x == 0) { tl_[1] = __builtin_amdgcn_s_memrealtime(); tl_[3] = (unsigned long long)tl_split_; }
 #endif
+    DDP_DBG_MARK(B, 20);
     fwd_pass(helper);
+    DDP_DBG_MARK(B, 30);
     if (helper) return;
 #if defined(DDP_TIMELINE) && !defined(DIRECT_EMULATE)
     if (tl_ != nullptr && threadIdx.x == 0) tl_[2] = __builtin_amdgcn_s_memrealtime();
 #endif
     DDP_MARK("X_A");
     exit_rules();
+    DDP_DBG_MARK(B, 31);
   }
 
   // what follows forwardpass() in one trip of the outer loop (DDP:312-410): bookkeeping and the exit rules

@@ -101,7 +101,9 @@ struct Sched {
   // next_work() on tickets of epochs to come and keep the other launch's workgroups off the CUs.  Scheduling only: which
   // wave runs a ticket never shows in the results (the holder of the earliest unfinished ticket is always among those
   // that stay).  0: off.
-  int* dbg;           // [12] what a wait that ran into the spin limit saw (direct_ddp_sched_debug)
+  int* dbg;           // [64] what a wait that ran into the spin limit saw (direct_ddp_sched_debug)
+  int* mark;          // development builds: [2 x grid] Batch::mark
+  int grid;
   int* waves;         // [1] waves of this launch still inside the kernel
   int* alive;         // [1] trajectories still in their outer loop (Batch::live when the line search is shared)
   int yield_k, yield_min;
@@ -137,10 +139,11 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
   int spins = 0;
   const unsigned long long wait_t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz (diagnostics of a timeout only)
 #if defined(DDP_SCHED_DEBUG)  // development builds: how many waves wait / run, and a snapshot a quarter of a second into a long wait
+  if (S.mark != nullptr && threadIdx.x == 0) S.mark[blockIdx.x] = 60;
   if (!ready && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[12], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int was_waiting = !ready;
 #endif
-  for (; !ready && !wanted && spins < (1 << 22); spins++) {
+  for (; !ready && !wanted && spins < kSpinLimit; spins++) {
 #if defined(DDP_SCHED_DEBUG)
     if (spins == (1 << 18) && threadIdx.x == 0 && __hip_atomic_exchange(&S.dbg[23], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       S.dbg[16] = (int)t; S.dbg[17] = e; S.dbg[18] = S.done_epoch[b];
@@ -191,6 +194,19 @@ __device__ __attribute__((noinline)) int next_work(Sched S, HelpSlot* slots, Bwd
         S.dbg[8] = (int)((__builtin_amdgcn_s_memrealtime() - wait_t0) / 100000ull);  // the wait in milliseconds
         S.dbg[9] = (int)nb; S.dbg[10] = (int)total; S.dbg[11] = spins;
 #if defined(DDP_SCHED_DEBUG)
+        if (S.mark != nullptr) {  // where the launch's waves are: a histogram of their marks, and three of the waves inside a chunk
+          int n_in = 0;
+          for (int q = 32; q < 64; q++) S.dbg[q] = 0;
+          for (int w = 0; w < S.grid; w++) {
+            const int m = __hip_atomic_load(&S.mark[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int bucket = m == 0 ? 32 : m == 5 ? 33 : m == 6 ? 34 : m == 11 ? 35 : m == 12 ? 36 : m == 20 ? 37 : m == 30 ? 38 : m == 31 ? 39 : m == 40 ? 40
+                               : m == 60 ? 41 : (m >= 100 && m < 200) ? 42 + (m - 100 < 11 ? m - 100 : 11) : (m >= 200 ? 54 : 55);
+            S.dbg[bucket]++;
+            if (m != 0 && m != 40 && m != 60 && n_in < 3) { S.dbg[56 + 2 * n_in] = w; S.dbg[57 + 2 * n_in] = S.mark[S.grid + w]; n_in++; }
+          }
+        }
+        S.dbg[28] = __hip_atomic_load(&S.dbg[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // publish sections entered / left at the timeout
+        S.dbg[29] = __hip_atomic_load(&S.dbg[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         S.dbg[14] = __hip_atomic_load(&S.dbg[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // waves waiting / running chunks at the timeout
         S.dbg[15] = __hip_atomic_load(&S.dbg[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -265,12 +281,18 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
     }
 #if defined(DDP_SCHED_DEBUG)
     if (!help && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[13], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DDP_DBG_MARK(B, help ? 6 : 5);
+    if (B.mark != nullptr && threadIdx.x == 0) B.mark[gridDim.x + blockIdx.x] = b;  // the trajectory
 #endif
     if (run) W.iterate(n, help);
+    DDP_DBG_MARK(B, 40);
 #if defined(DDP_SCHED_DEBUG)
     if (!help && threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[13], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     if (!help) {
+#if defined(DDP_SCHED_DEBUG)
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(&S.dbg[26], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // entered the publish section
+#endif
       if (run) W.store_state();
       const int fin = __builtin_amdgcn_readfirstlane(lds.st.done) ? kDoneBit : 0;
       int* const alive = B.live != nullptr ? B.live : S.alive;
@@ -279,7 +301,12 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       // max, not store: done_epoch only ever grows, and a trajectory that a timed-out waiter has retired
       // (kDoneBit | n_epochs, below) stays retired when its straggling chunk completes afterwards
-      if (threadIdx.x == 0) __hip_atomic_fetch_max(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_max(&S.done_epoch[b], (e + 1) | fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(DDP_SCHED_DEBUG)
+        __hip_atomic_fetch_add(&S.dbg[27], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // left it
+#endif
+      }
     }
   }
   DDP_MARK("Z_E");
@@ -536,7 +563,8 @@ struct direct_ddp_handle_s {
   int sched_tail = 8;    // rounds of help-only tickets behind the last epoch (DIRECT_DDP_TAIL=0: none; next_work)
   int yield_k = 0;       // DIRECT_FLAG_YIELD / DIRECT_DDP_YIELD=k: surplus waves leave the hot kernel (Sched::yield_k); 0 = off
   int* nwaves = nullptr; // device [16]: waves inside the kernel, per class launch
-  int* sched_dbg = nullptr;  // device [8]: Sched::dbg
+  int* sched_dbg = nullptr;  // device [64]: Sched::dbg
+  int* sched_mark = nullptr; // development builds: device [2 x 8192]
   bool dynamic = true;
   // current batch
   int B = 0;
@@ -783,6 +811,10 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.prio = h->sched_prio;
       S.tail = help ? h->sched_tail : 0;
       S.dbg = h->sched_dbg;
+      S.mark = nullptr; S.grid = slots;
+#if defined(DDP_SCHED_DEBUG)
+      if (slots <= 8192) { S.mark = h->sched_mark; Bt.mark = h->sched_mark; (void)hipMemsetAsync(h->sched_mark, 0, 2 * 8192 * sizeof(int), st); }
+#endif
       S.waves = h->nwaves + (ci < 16 ? ci : 15);
       S.alive = h->live + (ci < 16 ? ci : 15);
       S.yield_k = h->yield_k;
@@ -1074,8 +1106,9 @@ direct_status_t direct_ddp_create(const direct_ddp_config_t* cfg, direct_ddp_han
   A(&h->visits, 4 * sizeof(unsigned long long));  // [0] backward knots, [1] forward trial-knots, [2] knots whose front half a helper computed, [3] accepted line searches
   A(&h->live, 16 * sizeof(int));
   A(&h->nwaves, 16 * sizeof(int));
-  A(&h->sched_dbg, 24 * sizeof(int));
-  if (st == DIRECT_OK && hipMemset(h->sched_dbg, 0, 24 * sizeof(int)) != hipSuccess) st = fail(DIRECT_ERR_DEVICE, "hipMemset");
+  A(&h->sched_mark, 2 * 8192 * sizeof(int));
+  A(&h->sched_dbg, 64 * sizeof(int));
+  if (st == DIRECT_OK && hipMemset(h->sched_dbg, 0, 64 * sizeof(int)) != hipSuccess) st = fail(DIRECT_ERR_DEVICE, "hipMemset");
   A(&h->tickets, 16 * sizeof(int));
   A(&h->order, B * sizeof(int32_t)); A(&h->cls_dev, B * sizeof(int32_t));
   if (const char* ev = getenv("DIRECT_DDP_CHUNK")) h->sched_chunk = atoi(ev) > 0 ? atoi(ev) : 1;
@@ -1554,9 +1587,9 @@ direct_status_t direct_ddp_last_counters(direct_ddp_handle_t h, uint64_t* out4) 
   return DIRECT_OK;
 }
 
-direct_status_t direct_ddp_sched_debug(direct_ddp_handle_t h, int32_t* out24) {
-  if (!h || !out24) return fail(DIRECT_ERR_INVALID, "null argument");
-  HIP_TRY(hipMemcpyAsync(out24, h->sched_dbg, 24 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+direct_status_t direct_ddp_sched_debug(direct_ddp_handle_t h, int32_t* out64) {
+  if (!h || !out64) return fail(DIRECT_ERR_INVALID, "null argument");
+  HIP_TRY(hipMemcpyAsync(out64, h->sched_dbg, 64 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return DIRECT_OK;
 }

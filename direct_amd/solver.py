@@ -312,12 +312,15 @@ class DdpSolver:
 
     def sched_debug(self):
         """what the first wait that ran into the spin limit saw (include/direct_ddp.h, direct_ddp_sched_debug)"""
-        v = (C.c_int32 * 24)()
+        v = (C.c_int32 * 64)()
         _check(lib().direct_ddp_sched_debug(self.h, v))
         return dict(zip(("ticket", "epoch", "trajectory", "done_epoch", "ticket_counter", "waves", "alive", "set", "wait_ms", "batch",
                          "tickets", "spins", "dbg_waiting_now", "dbg_running_now", "dbg_waiting_at_timeout", "dbg_running_at_timeout",
                          "dbg_early_ticket", "dbg_early_epoch", "dbg_early_done_epoch", "dbg_early_counter", "dbg_early_waiting",
-                         "dbg_early_running", "dbg_early_ms", "dbg_early_set"), list(v)))
+                         "dbg_early_running", "dbg_early_ms", "dbg_early_set", "pad24", "pad25", "dbg_pub_in_now", "dbg_pub_out_now", "dbg_pub_in_at_timeout", "dbg_pub_out_at_timeout", "pad30", "pad31",
+                         "m_none", "m_chunk", "m_help", "m_bwd", "m_bwd_failed", "m_before_fwd", "m_after_fwd", "m_after_exit", "m_done", "m_wait",
+                         "m_r0", "m_r1", "m_r2", "m_r3", "m_r4", "m_r5", "m_r6", "m_r7", "m_r8", "m_r9", "m_r10", "m_rend", "m_helper", "m_other",
+                         "w0", "b0", "w1", "b1", "w2", "b2", "pad62", "pad63"), list(v)))
 
     def best_cost(self, cost, rtn, mem=abi.MEM_HOST, batch=None):
         """(index, cost) of the cheapest trajectory with rtn >= 0.  cost/rtn: numpy arrays or raw pointers."""

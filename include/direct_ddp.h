@@ -197,9 +197,10 @@ direct_status_t direct_ddp_solve_batch(direct_ddp_handle_t h, const direct_ddp_p
 /* Synchronises the handle's stream and reads the sticky scheduler-error flag (see above). */
 direct_status_t direct_ddp_sched_error(direct_ddp_handle_t h, int32_t* flag);
 /* What the FIRST wait that ran into the spin limit saw, since the handle was created (diagnostics; all zero when none did):
- * out24[0..11] = { ticket, epoch it waited for, trajectory, done_epoch[trajectory], ticket counter, waves inside, unfinished
- * trajectories, 1, milliseconds waited, batch, tickets of the launch, spins }; [12..23]: development builds only. */
-direct_status_t direct_ddp_sched_debug(direct_ddp_handle_t h, int32_t* out24);
+ * out64[0..11] = { ticket, epoch it waited for, trajectory, done_epoch[trajectory], ticket counter, waves inside, unfinished
+ * trajectories, 1, milliseconds waited, batch, tickets of the launch, spins }; [12..63]: development builds
+ * (-DDDP_SCHED_DEBUG) only: waves waiting / inside a chunk, a histogram of where the launch's waves stand. */
+direct_status_t direct_ddp_sched_debug(direct_ddp_handle_t h, int32_t* out64);
 
 /* fastTrajPlanning's protocol (teach_repeat_planner.cpp:886-921) for a batch: phase 0
  * (params0: zero init, infeasible start), UpdateTime where rtn0 == 2, phase 1 (params1) from

@@ -1,7 +1,9 @@
 """Stress of DIRECT_FLAG_YIELD (not a pytest test): for several batch sizes R pipelined launches on two yielding handles must
 reproduce one serial launch of an ordinary handle bit for bit, natural exits and fixed-20, scheduler error flags clear.
 usage: python tests/soak/yield_stress.py [launches per size]"""
+import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -10,6 +12,7 @@ sys.path.insert(0, ".")
 from direct_amd import abi, devmem, problems, solver  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+os.makedirs("gpurun_out", exist_ok=True)
 dev = torch.device("cuda:0")
 total = 0
 SIZES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None
@@ -27,18 +30,26 @@ for B, kind, dt in ((1, "corridor", np.float32), (33, "free", np.float32), (700,
     for h, s in zip(hs, st):
         h.set_stream(s.cuda_stream)
     outs = [devmem.DeviceResult(B, 100, dt, dev) for _ in range(4)]
+    slow = []
     for p in (abi.phase1_params(iter_max=20, fixed_iters=1), abi.phase1_params(iter_max=40)):
         one.solve_device(p, din.cin, ref.cout)
         torch.cuda.synchronize()
         for base in range(0, R, 4):
+            tg = time.perf_counter()
             for i in range(4):
                 hs[i % 2].solve_device(p, din.cin, outs[i].cout)
             torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            slow.append(tg)
             for i in range(4):
                 for k in ref.t:
                     if not torch.equal(outs[i].t[k], ref.t[k]):
                         d = torch.nonzero((outs[i].t[k] != ref.t[k]).reshape(B, -1).any(dim=1)).flatten()
                         idx = d[:5].cpu().numpy()
+                        np.savez_compressed("gpurun_out/yield_mismatch.npz", fwd=outs[i].t["fwd_passes"].cpu().numpy(), fwd_ref=ref.t["fwd_passes"].cpu().numpy(),
+                                            rtn=outs[i].t["rtn"].cpu().numpy(), rtn_ref=ref.t["rtn"].cpu().numpy(), iters=outs[i].t["iter_used"].cpu().numpy(),
+                                            iters_ref=ref.t["iter_used"].cpu().numpy(), cost=outs[i].t["cost"].cpu().numpy(), cost_ref=ref.t["cost"].cpu().numpy(),
+                                            others=np.stack([outs[j].t["fwd_passes"].cpu().numpy() for j in range(4)]), launch=base + i, fixed=p.fixed_iters)
                         raise SystemExit("MISMATCH B=%d %s fixed=%d launch %d field %s: %d trajectories, first %s; rtn %s vs %s, fwd_passes %s vs %s, sched_error %s"
                                          % (B, kind, p.fixed_iters, base + i, k, len(d), idx, outs[i].t["rtn"][idx].cpu().numpy(), ref.t["rtn"][idx].cpu().numpy(),
                                             outs[i].t["fwd_passes"][idx].cpu().numpy(), ref.t["fwd_passes"][idx].cpu().numpy(), [(h.sched_error(), h.sched_debug()) for h in hs])
@@ -47,5 +58,6 @@ for B, kind, dt in ((1, "corridor", np.float32), (33, "free", np.float32), (700,
         assert one.sched_error() == 0 and all(h.sched_error() == 0 for h in hs)
     for h in hs + [one]:
         h.close()
-    print("B = %d (%s, %s): %d pipelined launches per workload reproduce the serial launch" % (B, kind, np.dtype(dt).name, R), flush=True)
+    print("B = %d (%s, %s): %d pipelined launches per workload reproduce the serial launch; groups of 4 launches: median %.0f ms, max %.0f ms, over 1 s: %d"
+          % (B, kind, np.dtype(dt).name, R, 1e3 * float(np.median(slow)), 1e3 * max(slow), sum(1 for v in slow if v > 1.0)), flush=True)
 print("ok: %d launches" % total)
