@@ -417,12 +417,12 @@ struct HelpSlot {
   TrialRes res[12];
 };
 // Polls after which a wait inside a launch (for a helper's record, a helper to leave, a trajectory's previous chunk:
-// direct_ddp.hip, next_work) counts as a scheduling error instead of hanging.  Round 6: 2^26 (a minute or more) instead of
+// direct_ddp.hip, next_work) counts as a scheduling error instead of hanging.  Round 6: 2^27 (two minutes or more) instead of
 // 2^22 (1 - 5 s) - with two handles' kernels running next to each other, one launch in ~5000 saw a seventeenth of its waves
-// stand still for 13 - 15 s and then go on (not a lost update, not a deadlock: with the longer limit every one of 25 600 stress
-// launches completed bit-identically, two groups of four in 15.2 and 13.3 s instead of 0.3).
+// stand still for 10 - 64 s and then go on (not a lost update, not a deadlock: with longer limits every one of 64 000 stress
+// launches completed bit-identically, nine groups of four in 10 .. 64 s instead of 0.3).
 #ifndef DDP_SPIN_LIMIT_LOG2
-#define DDP_SPIN_LIMIT_LOG2 26
+#define DDP_SPIN_LIMIT_LOG2 27
 #endif
 constexpr int kSpinLimit = 1 << DDP_SPIN_LIMIT_LOG2;
 constexpr int kMaxBuf = 12;  // iterate buffers: `cur` + one per concurrently evaluated step, 0 .. 10 (3 without helpers)

@@ -248,6 +248,11 @@ __global__ __launch_bounds__(64, (RPL > 7 ? DDP_WAVES_WIDER : (RPL > 4 ? DDP_WAV
       if (__builtin_amdgcn_readfirstlane(go)) break;
     }
     DDP_MARK("X_T");
+#if !defined(DDP_KEEP_PRIO_WHILE_WAITING)
+    // a wave that looks for work (and may have to wait for it) does so at the base priority: the raised one belongs to the
+    // chunk it has just finished
+    if (S.prio) __builtin_amdgcn_s_setprio(0);
+#endif
     const int t = __builtin_amdgcn_readfirstlane(next_work(S, B.help, SHARE ? B.bshare : nullptr, B.idx, nb, total, total_help, held, &waited, &help_v));
     const int help = __builtin_amdgcn_readfirstlane(help_v);
     DDP_MARK("X_G");
