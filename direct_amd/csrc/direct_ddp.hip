@@ -102,8 +102,10 @@ struct Sched {
   // wave runs a ticket never shows in the results (the holder of the earliest unfinished ticket is always among those
   // that stay).  0: off.
   int* dbg;           // [64] what a wait that ran into the spin limit saw (direct_ddp_sched_debug)
+#if defined(DDP_SCHED_DEBUG)
   int* mark;          // development builds: [2 x grid] Batch::mark
   int grid;
+#endif
   int* waves;         // [1] waves of this launch still inside the kernel
   int* alive;         // [1] trajectories still in their outer loop (Batch::live when the line search is shared)
   int yield_k, yield_min;
@@ -816,8 +818,8 @@ static void launch_iterate_t(direct_ddp_handle_t h, int n, int mode) {
       S.prio = h->sched_prio;
       S.tail = help ? h->sched_tail : 0;
       S.dbg = h->sched_dbg;
-      S.mark = nullptr; S.grid = slots;
 #if defined(DDP_SCHED_DEBUG)
+      S.mark = nullptr; S.grid = slots;
       if (slots <= 8192) { S.mark = h->sched_mark; Bt.mark = h->sched_mark; (void)hipMemsetAsync(h->sched_mark, 0, 2 * 8192 * sizeof(int), st); }
 #endif
       S.waves = h->nwaves + (ci < 16 ? ci : 15);
