@@ -1,6 +1,8 @@
 """Stress of DIRECT_FLAG_YIELD (not a pytest test): for several batch sizes R pipelined launches on two yielding handles must
 reproduce one serial launch of an ordinary handle bit for bit, natural exits and fixed-20, scheduler error flags clear.
-usage: python tests/soak/yield_stress.py [launches per size]"""
+usage: python tests/soak/yield_stress.py [launches per size] [sizes, comma separated] [launches of every size but the last]
+(the third argument separates "the earlier stages existed" - handles and streams created and closed - from "the earlier stages
+ran for minutes" when looking for what makes the last stage stall: DESIGN.md 7.6)"""
 import os
 import sys
 import time
@@ -16,10 +18,12 @@ os.makedirs("gpurun_out", exist_ok=True)
 dev = torch.device("cuda:0")
 total = 0
 SIZES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None
+R_ALL, R_PRE = R, (int(sys.argv[3]) if len(sys.argv) > 3 else R)
 for B, kind, dt in ((1, "corridor", np.float32), (33, "free", np.float32), (700, "corridor", np.float64), (3100, "free", np.float32),
                     (4096, "corridor", np.float32), (4600, "free", np.float32), (9000, "corridor", np.float32)):
     if SIZES is not None and B not in SIZES:
         continue
+    R = R_ALL if B == (max(SIZES) if SIZES is not None else 9000) else R_PRE
     b = problems.make_batch(kind, B, 100, seed=6000 + B).astype(dt)
     one = solver.DdpSolver(B, 100, b.p_max, dt)
     g0 = one.solve(abi.phase0_params(), b)
