@@ -11,12 +11,12 @@ import numpy as np
 sys.path.insert(0, ".")
 from direct_amd import abi, problems  # noqa: E402
 from oracle import refapi  # noqa: E402
-from tests import helpers, stuck_lib  # noqa: E402
+from tests import helpers, soak_lib, stuck_lib  # noqa: E402
 from tests.emu import emuapi  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/emu_soak.json"
-rep = dict(plans=0, rtn_same=0, iters_same=0, cost_max=0.0, T_max=0.0, bez_max=0.0, rtn_hist={}, stuck=dict(problems=0, accepted=0, worst=0.0), shapes=[])
+rep = dict(plans=0, rtn_same=0, iters_same=0, iters_differ_where_the_oracle_flips_under_one_ulp=0, cost_max=0.0, T_max=0.0, bez_max=0.0, rtn_hist={}, stuck=dict(problems=0, accepted=0, worst=0.0), shapes=[])
 t0 = time.time()
 for kind in ("free", "corridor"):
     for N in (3, 5, 8, 12, 17, 24):
@@ -34,8 +34,14 @@ for kind in ("free", "corridor"):
             b1 = rb.phase1_inputs(r0, monomial=False)
             r1, _ = refapi.solve_batch(p1, b1)
             e1 = emuapi.solve_batch(p1, rb.phase1_inputs(e0, monomial=False))
-            for r, e in ((r0, e0), (r1, e1)):
+            for r, e, pp, bb in ((r0, e0, p0, rb), (r1, e1, p1, b1)):
                 same = (r.rtn == e.rtn) & (r.iter_used == e.iter_used)
+                if not same.all():  # control: does the ORACLE keep its own count when its inputs move by one ulp?
+                    flips = np.zeros(B, bool)
+                    for cs in (11, 12, 13, 14):
+                        rc = refapi.solve_batch(pp, soak_lib.perturb_ulp(bb, cs))[0]
+                        flips |= (rc.iter_used != r.iter_used) | (rc.rtn != r.rtn)
+                    rep["iters_differ_where_the_oracle_flips_under_one_ulp"] += int((flips & ~same).sum())
                 rep["plans"] += B
                 rep["rtn_same"] += int((r.rtn == e.rtn).sum())
                 rep["iters_same"] += int(same.sum())
